@@ -1,0 +1,319 @@
+/*
+ * flux_mi355x.h — C-ABI of the MI355X-native FLUX.1 denoise path (libflux_mi355x.so).
+ *
+ * This is the drop-in boundary for the hot path of EricLBuehler/diffusion-rs
+ * (SURVEY.md §8b).  Everything here is `extern "C"`, plain pointers and sizes, no torch /
+ * candle types.  A Rust `extern "C"` block (or cgo / ctypes) binds it 1:1; INTEGRATION.md
+ * shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - Every function returning `int` returns FMI_OK (0) or a negative fmi_status; the
+ *     message is available from fmi_last_error() (thread-local).  The reference's only
+ *     native library (diffusion_rs_backend/kernels/bitsandbytes/dequant.cu:172-232) has
+ *     void returns and no error channel; the `dequantize_*` entry points below keep that
+ *     exact signature so the reference's ffi.rs binds them unchanged.
+ *   - All tensors are row-major, contiguous unless a leading dimension is given.
+ *   - Data pointers are DEVICE pointers borrowed for the call unless the parameter name
+ *     ends in `_host` or the doc says "host or device" (those go through
+ *     hipMemcpyDefault).  The caller owns every output buffer (same ownership rule as
+ *     the reference's CustomOp::cuda_fwd call sites, bitsandbytes/op.rs:204-228).
+ *   - `stream` is a hipStream_t passed as void*; NULL = the null stream.  All compute is
+ *     asynchronous on that stream unless stated.
+ *   - Not thread-safe per handle (the reference serialises on a Mutex too,
+ *     diffusion_rs_core/src/pipelines/mod.rs:110-113); distinct handles are independent.
+ */
+#ifndef FLUX_MI355X_H
+#define FLUX_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMI_ABI_VERSION 1
+
+typedef enum fmi_status {
+  FMI_OK = 0,
+  FMI_ERR_INVALID = -1,     /* bad argument / shape / unknown tensor name */
+  FMI_ERR_HIP = -2,         /* a HIP runtime call failed */
+  FMI_ERR_STATE = -3,       /* missing weights, wrong call order */
+  FMI_ERR_UNSUPPORTED = -4, /* valid request this build does not implement */
+  FMI_ERR_NOMEM = -5
+} fmi_status;
+
+/* Element types of tensors crossing the boundary (host side of set_tensor, or device
+ * activations).  NF4/FP4/INT8 are the bitsandbytes storage types of
+ * diffusion_rs_backend/src/bitsandbytes/mod.rs:26-31. */
+typedef enum fmi_dtype {
+  FMI_F32 = 0,
+  FMI_F16 = 1,
+  FMI_BF16 = 2,
+  FMI_U8 = 3,
+  FMI_I8 = 4
+} fmi_dtype;
+
+/* Mirrors diffusion_rs_core::ModelDType (util/auto_dtype.rs) — the compute dtype of the
+ * DiT/VAE weights and activations.  This build computes in BF16 on MFMA with f32
+ * accumulation; Auto resolves to BF16.  F16/F32 are rejected with FMI_ERR_UNSUPPORTED. */
+typedef enum fmi_model_dtype { FMI_MODEL_AUTO = 0, FMI_MODEL_BF16 = 1, FMI_MODEL_F16 = 2, FMI_MODEL_F32 = 3 } fmi_model_dtype;
+
+const char* fmi_last_error(void);
+int fmi_abi_version(void);
+/* Select the HIP device for this thread (hipSetDevice) and warm the runtime. */
+int fmi_init(int device_ordinal);
+/* Device / build info as a JSON string (static storage, valid until next call). */
+const char* fmi_device_info(void);
+
+/* ------------------------------------------------------------------------------------
+ * FLUX DiT — replaces diffusion_rs_core::models::flux::Flux (model.rs:709-838)
+ * ---------------------------------------------------------------------------------- */
+
+/* Mirrors `Config` (model.rs:21-31) + the model constants (model.rs:16-19).  hidden_size
+ * must be num_attention_heads*128 (pe_dim = sum(axes_dim) = 128); mlp_ratio is fixed 4. */
+typedef struct fmi_flux_config {
+  int in_channels;           /* 64 */
+  int pooled_projection_dim; /* 768 */
+  int joint_attention_dim;   /* 4096 */
+  int num_attention_heads;   /* 24 */
+  int num_layers;            /* 19 double-stream blocks */
+  int num_single_layers;     /* 38 single-stream blocks */
+  int guidance_embeds;       /* 1 = dev, 0 = schnell */
+  int axes_dim[3];           /* {16,56,56} */
+  int theta;                 /* 10000 */
+} fmi_flux_config;
+
+typedef struct fmi_flux fmi_flux; /* opaque */
+
+/* Fill `cfg` with the public FLUX.1 config (dev if guidance_embeds else schnell). */
+void fmi_flux_default_config(fmi_flux_config* cfg, int guidance_embeds);
+
+/* Allocate the model: one bf16 weight arena in HBM sized from cfg (23.8 GB for FLUX.1),
+ * zero-initialised.  == Flux::new (model.rs:722-787) minus the tensor reads. */
+int fmi_flux_create(const fmi_flux_config* cfg, fmi_model_dtype dtype, fmi_flux** out);
+void fmi_flux_destroy(fmi_flux*);
+
+/* Provide one tensor by its diffusers name, exactly the names VarBuilder looks up in
+ * Flux::new (model.rs:165-772), e.g.
+ *   "x_embedder.weight", "context_embedder.bias",
+ *   "time_text_embed.timestep_embedder.linear_1.weight",
+ *   "transformer_blocks.3.attn.to_q.weight", "transformer_blocks.3.norm1.linear.bias",
+ *   "transformer_blocks.3.attn.norm_added_k.weight", "transformer_blocks.3.ff.net.0.proj.weight",
+ *   "single_transformer_blocks.7.proj_mlp.weight", "single_transformer_blocks.7.attn.norm_q.weight",
+ *   "norm_out.linear.weight", "proj_out.bias".
+ * `data` may be a host or device pointer; `dtype` F32/F16/BF16 is converted to bf16 (RNE)
+ * and placed into the fused layouts the kernels read (q|k|v|proj_mlp rows concatenated,
+ * all modulation linears in one matrix).  Shape is checked against cfg. Synchronous. */
+int fmi_flux_set_tensor(fmi_flux*, const char* name, const void* data, fmi_dtype dtype,
+                        const int64_t* shape, int rank);
+
+/* bitsandbytes 4-bit weight for linear `prefix` (e.g. "transformer_blocks.0.attn.to_q"):
+ * packed u8 (out*in/2), f32 absmax (out*in/blocksize), quant type 1=fp4 2=nf4
+ * (bitsandbytes/mod.rs:137-222; nested absmax must be resolved by the caller with
+ * fmi_dequantize_blockwise first, as BnbLinear::dequantize_4bit does, mod.rs:230-239).
+ * The layer then runs through the fused dequant-GEMM. host or device pointers. */
+int fmi_flux_set_linear_bnb4(fmi_flux*, const char* prefix, const uint8_t* packed,
+                             const float* absmax, int blocksize, int quant_type,
+                             int out_features, int in_features);
+
+/* Number of tensors still missing (never set); names via fmi_flux_missing_name(i). */
+int fmi_flux_missing_count(const fmi_flux*);
+const char* fmi_flux_missing_name(const fmi_flux*, int i);
+/* Bytes of HBM held by the model (weights + current workspace). */
+size_t fmi_flux_size_in_bytes(const fmi_flux*);
+
+/* One denoise-model evaluation == Flux::forward (model.rs:790-833).
+ *   img      (B,S,in_channels)         img_dtype  F32|BF16
+ *   img_ids  (B,S,3)  f32              (row/col positions; reference builds them in
+ *                                        State::new, flux/sampling.rs:134-148)
+ *   txt      (B,T,joint_attention_dim) txt_dtype  F32|BF16
+ *   txt_ids  (B,T,3)  f32
+ *   timesteps(B) f32,  y (B,pooled_projection_dim) y_dtype F32|BF16,
+ *   guidance (B) f32 or NULL (must be non-NULL iff cfg.guidance_embeds, as model.rs:814-819)
+ *   pred_out (B,S,in_channels) f32
+ * Only batch element 0's ids are used to build the RoPE table when ids are identical
+ * across the batch (they always are in the reference, sampling.rs:147-150); set
+ * `ids_per_sample`=1 to build one table per sample. */
+typedef struct fmi_flux_inputs {
+  const void* img;      fmi_dtype img_dtype;
+  const float* img_ids;
+  const void* txt;      fmi_dtype txt_dtype;
+  const float* txt_ids;
+  const float* timesteps;
+  const void* y;        fmi_dtype y_dtype;
+  const float* guidance;
+  int B, S, T;
+  int ids_per_sample;
+} fmi_flux_inputs;
+
+int fmi_flux_forward(fmi_flux*, const fmi_flux_inputs* in, float* pred_out, void* stream);
+
+/* The whole denoise loop == Sampler::sample(FlowMatchEulerDiscrete)
+ * (pipelines/sampling.rs:25-48) around the step closure (pipelines/flux/mod.rs:305-318):
+ *   for (t_curr,t_prev) in windows(timesteps): img += forward(img, t_curr) * (t_prev-t_curr)
+ * `in->img` must be F32 and is the state: `img_inout` (B,S,C) f32 is updated in place
+ * (in->img is ignored; in->timesteps is ignored, `timesteps_host` (n_steps+1 f64, host)
+ * drives the loop, exactly the Vec<f64> of SchedulerConfig::get_timesteps).
+ * The latent stays f32 between steps. */
+int fmi_flux_denoise(fmi_flux*, const fmi_flux_inputs* in, float* img_inout,
+                     const double* timesteps_host, int n_steps, void* stream);
+
+/* Per-phase device time of the last forward in ms (hipEvents; enabled by
+ * fmi_flux_set_profiling(1), which also serialises phases).  Phases: see fmi_flux_phase_name. */
+int fmi_flux_set_profiling(fmi_flux*, int enable);
+int fmi_flux_phase_count(void);
+const char* fmi_flux_phase_name(int i);
+int fmi_flux_phase_ms(fmi_flux*, float* ms_out /* [phase_count] */);
+
+/* ------------------------------------------------------------------------------------
+ * VAE decoder — replaces AutoEncoderKl::decode (vaes/autoencoder_kl.rs:112-119) and
+ * Decoder::forward (vaes/vae.rs:436-456)
+ * ---------------------------------------------------------------------------------- */
+typedef struct fmi_vae_config {
+  int in_channels;           /* 3  (unused by decode) */
+  int out_channels;          /* 3 */
+  int block_out_channels[4]; /* {128,256,512,512} */
+  int n_blocks;              /* 4 */
+  int layers_per_block;      /* 2 */
+  int latent_channels;       /* 16 */
+  int norm_num_groups;       /* 32 */
+  int mid_block_add_attention;
+  int use_post_quant_conv;   /* 0 for FLUX */
+  double scaling_factor;     /* 0.3611 */
+  double shift_factor;       /* 0.1159 */
+} fmi_vae_config;
+
+typedef struct fmi_vae fmi_vae;
+void fmi_vae_default_config(fmi_vae_config* cfg);
+int fmi_vae_create(const fmi_vae_config* cfg, fmi_model_dtype dtype, fmi_vae** out);
+void fmi_vae_destroy(fmi_vae*);
+/* diffusers names under "decoder." / "post_quant_conv.", e.g.
+ * "decoder.conv_in.weight", "decoder.mid_block.resnets.0.norm1.weight",
+ * "decoder.mid_block.attentions.0.to_q.weight", "decoder.up_blocks.2.resnets.0.conv_shortcut.weight",
+ * "decoder.up_blocks.0.upsamplers.0.conv.bias", "decoder.conv_norm_out.weight" (vae.rs:371-433).
+ * Conv weights are (Cout,Cin,kh,kw) as stored; they are re-laid out for the implicit-GEMM
+ * kernels.  host or device pointer, F32/F16/BF16. */
+int fmi_vae_set_tensor(fmi_vae*, const char* name, const void* data, fmi_dtype dtype,
+                       const int64_t* shape, int rank);
+int fmi_vae_missing_count(const fmi_vae*);
+const char* fmi_vae_missing_name(const fmi_vae*, int i);
+double fmi_vae_scale_factor(const fmi_vae*); /* VAEModel::scale_factor, vaes/mod.rs:15-28 */
+double fmi_vae_shift_factor(const fmi_vae*);
+/* z (B,latent_channels,h,w) f32 NCHW -> image (B,out_channels,8h,8w) f32 NCHW.
+ * == VAEModel::decode. */
+int fmi_vae_decode(fmi_vae*, const float* z, int B, int h, int w, float* image_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pipeline glue on device — the tensor code of FluxPipeline::forward
+ * (pipelines/flux/mod.rs:270-332) and flux/sampling.rs
+ * ---------------------------------------------------------------------------------- */
+/* State::new patchify: latent (B,C,h,w) f32 -> img (B,(h/2)*(w/2),C*4) f32 and
+ * img_ids (B,(h/2)(w/2),3) f32  (flux/sampling.rs:131-148). */
+int fmi_pack_latents(const float* latent, int B, int C, int h, int w, float* img_out,
+                     float* img_ids_out, void* stream);
+/* unpack (flux/sampling.rs:162-169) fused with `img/scale_factor + shift_factor`
+ * (flux/mod.rs:329): img (B,(h/2)(w/2),C*4) -> z (B,C,h,w). */
+int fmi_unpack_latents(const float* img, int B, int C, int h, int w, double scale_factor,
+                       double shift_factor, float* z_out, void* stream);
+/* ((clamp(x,-1,1)+1)*127.5) as u8, truncating (flux/mod.rs:332, cpu_backend/mod.rs:2571-2574),
+ * NCHW f32 -> NCHW u8 (interleave=0) or NHWC u8 (interleave=1, what Pipeline::forward hands
+ * to RgbImage::from_raw, pipelines/mod.rs:253-266). */
+int fmi_postprocess_u8(const float* image, int B, int C, int H, int W, int interleave,
+                       uint8_t* out, void* stream);
+/* Deterministic N(0,1) latents from a counter-based Philox4x32-10 generator
+ * (the reference's RNG is unseedable; this is the explicit-seed extension).
+ * element i of sample b uses counter (i, b) and key (seed). */
+int fmi_randn(float* out, int64_t n_per_sample, int B, uint64_t seed, uint64_t first_sample,
+              void* stream);
+
+/* Host-side schedule helpers (f64, bit-for-bit the reference formulas). */
+double fmi_calculate_shift(int image_seq_len, int base_seq_len, int max_seq_len,
+                           double base_shift, double max_shift); /* flux/sampling.rs:171-181 */
+typedef struct fmi_scheduler_config { /* SchedulerConfig, pipelines/scheduler.rs:4-20 */
+  int base_image_seq_len; double base_shift; int max_image_seq_len; double max_shift;
+  double shift; int use_dynamic_shifting;
+} fmi_scheduler_config;
+/* out_host[num_steps+1]; mu is ignored unless use_dynamic_shifting. (scheduler.rs:28-51) */
+int fmi_get_timesteps(const fmi_scheduler_config* cfg, int num_steps, double mu, double* out_host);
+
+/* ------------------------------------------------------------------------------------
+ * Operator-level entry points (seam S3) — used by the parity tests and
+ * usable as CustomOp::cuda_fwd replacements.
+ * ---------------------------------------------------------------------------------- */
+typedef enum fmi_epilogue {
+  FMI_EPI_NONE = 0,      /* y = x W^T (+bias) */
+  FMI_EPI_GELU_TANH = 1, /* y = gelu_tanh(x W^T + bias)  (Mlp, model.rs:459-463) */
+  FMI_EPI_SILU = 2
+} fmi_epilogue;
+
+/* y(M,N) = epi(x(M,K) · W(N,K)^T + bias(N)); x,W,y bf16, bias bf16 or NULL, f32 accumulate.
+ * == UnquantLinear::forward (unquantized/mod.rs:34-77). K % 64 == 0 required. */
+int fmi_linear_bf16(const void* x, const void* w, const void* bias, void* y, int M, int N,
+                    int K, fmi_epilogue epi, void* stream);
+/* Same with a bitsandbytes 4-bit weight: W = dequant(packed, absmax, blocksize) fused into
+ * the GEMM's weight-tile load (BnbLinear::forward semantics, bitsandbytes/mod.rs:301-312,
+ * minus the dense round trip).  quant_type 1=fp4, 2=nf4. K % 64 == 0, blocksize % 64 == 0. */
+int fmi_linear_bnb4_bf16(const void* x, const uint8_t* packed, const float* absmax,
+                         int blocksize, int quant_type, const void* bias, void* y, int M,
+                         int N, int K, fmi_epilogue epi, void* stream);
+/* softmax(q k^T * scale) v, q,k,v,o (B,H,L,d) bf16, d == 128, non-causal; o is written
+ * token-major (B,L,H*d) when `out_token_major`, else (B,H,L,d).
+ * == backend::ops::sdpa fallback (ops.rs:247-262) without materialising the scores. */
+int fmi_sdpa_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
+                  int Lk, int d, float scale, int out_token_major, void* stream);
+/* LayerNorm(eps, no affine) then x*(1+scale)+shift: x (rows,D) f32 -> out bf16;
+ * scale/shift f32 (D) (layer_norm helper model.rs:33-38 + ModulationOut::scale_shift :218-221).
+ * scale/shift may be NULL (plain LN). */
+int fmi_layernorm_mod(const float* x, const float* scale, const float* shift, void* out_bf16,
+                      int rows, int D, float eps, void* stream);
+/* GroupNorm (+optional SiLU) on NHWC bf16 activations, f32 two-pass statistics
+ * (nn/group_norm.rs:39-74): x (B,HW,C). */
+int fmi_groupnorm_nhwc(const void* x_bf16, const float* weight, const float* bias, void* out_bf16,
+                       int B, int HW, int C, int groups, float eps, int fuse_silu, void* stream);
+/* 3x3/1x1 stride-1 conv, zero pad k/2, NHWC bf16, weights (Cout,kh,kw,Cin) bf16, bias f32;
+ * optional nearest-2x upsample folded into the input gather (Upsample::forward vae.rs:223-229)
+ * and optional residual add (ResnetBlock::forward vae.rs:157-172). (in_h,in_w) is the stored
+ * input size; output is (in_h*(up?2:1), in_w*(up?2:1)). */
+int fmi_conv2d_nhwc(const void* x_bf16, const void* w_bf16, const float* bias,
+                    const void* residual_bf16, void* out_bf16, int B, int in_h, int in_w, int Cin,
+                    int Cout, int ksize, int upsample2x, void* stream);
+
+/* The reference's own extern "C" convention, kept verbatim so ffi.rs:5-114 binds without
+ * edits (CUstream -> hipStream_t).  n = number of OUTPUT elements; blocksize as stored in
+ * quant_state; `code` is the 256-entry map for int8 and ignored for fp4/nf4 (the kernels
+ * use the constant tree/LUT of dequant.cu:12-92). */
+void dequantize_blockwise_f32_int8(const float* code, const uint8_t* A, const float* absmax, float* out, int blocksize, int n, void* stream);
+void dequantize_blockwise_f32_fp4(const float* code, const uint8_t* A, const float* absmax, float* out, int blocksize, int n, void* stream);
+void dequantize_blockwise_f32_nf4(const float* code, const uint8_t* A, const float* absmax, float* out, int blocksize, int n, void* stream);
+void dequantize_blockwise_f16_int8(const float* code, const uint8_t* A, const float* absmax, void* out, int blocksize, int n, void* stream);
+void dequantize_blockwise_f16_fp4(const float* code, const uint8_t* A, const float* absmax, void* out, int blocksize, int n, void* stream);
+void dequantize_blockwise_f16_nf4(const float* code, const uint8_t* A, const float* absmax, void* out, int blocksize, int n, void* stream);
+void dequantize_blockwise_bf16_int8(const float* code, const uint8_t* A, const float* absmax, void* out, int blocksize, int n, void* stream);
+void dequantize_blockwise_bf16_fp4(const float* code, const uint8_t* A, const float* absmax, void* out, int blocksize, int n, void* stream);
+void dequantize_blockwise_bf16_nf4(const float* code, const uint8_t* A, const float* absmax, void* out, int blocksize, int n, void* stream);
+/* LLM.int8 weight: out[i] = w[i]*SCB[i/col]/127 (dequant.cu:205-232). The reference
+ * launches these on the legacy default stream; so do we (stream argument absent, as in ffi.rs). */
+void dequantize_8bit_kernel_f32(const int8_t* weight, const float* scb, float* out, int row, int col, int n);
+void dequantize_8bit_kernel_f16(const int8_t* weight, const float* scb, void* out, int row, int col, int n);
+void dequantize_8bit_kernel_bf16(const int8_t* weight, const float* scb, void* out, int row, int col, int n);
+
+/* ------------------------------------------------------------------------------------
+ * Small device-memory helpers so a non-HIP host (Rust, ctypes) needs nothing else.
+ * ---------------------------------------------------------------------------------- */
+int fmi_malloc(void** dptr, size_t bytes);
+int fmi_free(void* dptr);
+int fmi_memcpy(void* dst, const void* src, size_t bytes, void* stream); /* hipMemcpyDefault, async */
+int fmi_memset(void* dst, int value, size_t bytes, void* stream);
+int fmi_stream_synchronize(void* stream);
+/* Event timing on an arbitrary stream (bench.py uses these so the timed region is measured
+ * on the stream the kernels are launched on). */
+int fmi_event_create(void** ev);
+int fmi_event_record(void* ev, void* stream);
+int fmi_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int fmi_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUX_MI355X_H */

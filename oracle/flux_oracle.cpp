@@ -1,0 +1,990 @@
+// flux_oracle.cpp — CPU oracle for the FLUX.1 denoise path.  TEST INFRASTRUCTURE ONLY.
+//
+// A plain C++17, f32 restatement of what the reference (EricLBuehler/diffusion-rs @
+// 2025-05-23) computes on its CPU backend with ModelDType::F32 for the path named in
+// BASELINE.json.  Every function cites the reference file:line it follows (paths relative
+// to /root/reference).  The reference is Rust and cannot be built in this image (no
+// cargo/rustc), so this file is the checker; see flux_oracle.h for pin status.
+//
+// Numerics choices where the reference leaves freedom (all f32 unless noted):
+//  * GEMM accumulation order: 8-lane partial sums per 256-deep K chunk, then a horizontal
+//    sum — the reference's order lives in the un-vendored `gemm` 0.17.1 crate and is
+//    unpinned.
+//  * LayerNorm: sequential f32 sum / sum2, var = E[x^2]-mean^2 — exactly nn/ops.rs:1020-1041.
+//  * GroupNorm / RMS-norm slow path / softmax: two-pass f32 with sequential accumulation
+//    (the reference accumulates with SIMD-lane partial sums, core/cpu/kernels.rs; the
+//    difference is f32 round-off, < 1e-5 relative).
+#include "flux_oracle.h"
+
+#include <immintrin.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef float v8f __attribute__((vector_size(32)));
+
+static int g_threads = 0;
+extern "C" void orc_set_threads(int n) {
+  g_threads = n;
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#endif
+}
+extern "C" int orc_get_threads(void) {
+#ifdef _OPENMP
+  return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
+// half / bf16 rounding (the `half` 2.4.1 crate: round-to-nearest-even conversions)
+// ---------------------------------------------------------------------------------------
+extern "C" float orc_round_bf16(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) {  // NaN: keep quiet NaN
+    u |= 0x00400000u;
+    u &= 0xffff0000u;
+  } else {
+    uint32_t lsb = (u >> 16) & 1u;
+    u += 0x7fffu + lsb;
+    u &= 0xffff0000u;
+  }
+  float r;
+  memcpy(&r, &u, 4);
+  return r;
+}
+extern "C" float orc_round_f16(float v) {
+  // F16C round-to-nearest-even, same as half::f16::from_f32
+  unsigned short h = _cvtss_sh(v, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+  return _cvtsh_ss(h);
+}
+static inline float round_out(float v, int out_dtype) {
+  return out_dtype == 1 ? orc_round_f16(v) : out_dtype == 2 ? orc_round_bf16(v) : v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Linear: y = x W^T + b.  UnquantLinear::forward (diffusion_rs_backend/src/unquantized/
+// mod.rs:34-77, CPU branch `a.matmul(&w.t()?)?.broadcast_add(&b)`); W is (N,K) row-major.
+// ---------------------------------------------------------------------------------------
+static inline float hsum(v8f v) {
+  return ((v[0] + v[4]) + (v[1] + v[5])) + ((v[2] + v[6]) + (v[3] + v[7]));
+}
+
+static void gemm_nt(const float* __restrict x, int64_t ldx, const float* __restrict w, int64_t ldw,
+                    const float* bias, int M, int N, int K, float* __restrict y, int64_t ldy, float alpha) {
+  const int MB = 48, NB = 64, KB = 256;
+  const int mt = (M + MB - 1) / MB, nt = (N + NB - 1) / NB;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+  for (int tm = 0; tm < mt; ++tm) {
+    for (int tn = 0; tn < nt; ++tn) {
+      const int m0 = tm * MB, n0 = tn * NB;
+      const int mb = std::min(MB, M - m0), nb = std::min(NB, N - n0);
+      float acc[MB][NB];
+      for (int i = 0; i < mb; ++i)
+        for (int j = 0; j < nb; ++j) acc[i][j] = 0.f;
+      for (int k0 = 0; k0 < K; k0 += KB) {
+        const int kb = std::min(KB, K - k0);
+        const int kv = kb & ~7;
+        for (int i = 0; i < mb; i += 4) {
+          const int ib = std::min(4, mb - i);
+          for (int j = 0; j < nb; j += 4) {
+            const int jb = std::min(4, nb - j);
+            if (ib == 4 && jb == 4) {
+              v8f c[4][4];
+              for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) c[a][b] = (v8f){0, 0, 0, 0, 0, 0, 0, 0};
+              const float* xp[4];
+              const float* wp[4];
+              for (int a = 0; a < 4; ++a) xp[a] = x + (int64_t)(m0 + i + a) * ldx + k0;
+              for (int b = 0; b < 4; ++b) wp[b] = w + (int64_t)(n0 + j + b) * ldw + k0;
+              for (int k = 0; k < kv; k += 8) {
+                v8f xv[4], wv[4];
+                for (int a = 0; a < 4; ++a) memcpy(&xv[a], xp[a] + k, 32);
+                for (int b = 0; b < 4; ++b) memcpy(&wv[b], wp[b] + k, 32);
+                for (int a = 0; a < 4; ++a)
+                  for (int b = 0; b < 4; ++b) c[a][b] += xv[a] * wv[b];
+              }
+              for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) {
+                  float s = hsum(c[a][b]);
+                  for (int k = kv; k < kb; ++k) s += xp[a][k] * wp[b][k];
+                  acc[i + a][j + b] += s;
+                }
+            } else {
+              for (int a = 0; a < ib; ++a)
+                for (int b = 0; b < jb; ++b) {
+                  const float* xr = x + (int64_t)(m0 + i + a) * ldx + k0;
+                  const float* wr = w + (int64_t)(n0 + j + b) * ldw + k0;
+                  v8f c = (v8f){0, 0, 0, 0, 0, 0, 0, 0};
+                  for (int k = 0; k < kv; k += 8) {
+                    v8f xv, wv;
+                    memcpy(&xv, xr + k, 32);
+                    memcpy(&wv, wr + k, 32);
+                    c += xv * wv;
+                  }
+                  float s = hsum(c);
+                  for (int k = kv; k < kb; ++k) s += xr[k] * wr[k];
+                  acc[i + a][j + b] += s;
+                }
+            }
+          }
+        }
+      }
+      for (int i = 0; i < mb; ++i)
+        for (int j = 0; j < nb; ++j) {
+          float v = acc[i][j] * alpha;
+          if (bias) v += bias[n0 + j];
+          y[(int64_t)(m0 + i) * ldy + n0 + j] = v;
+        }
+    }
+  }
+}
+
+extern "C" void orc_linear(const float* x, const float* w, const float* bias, int M, int N, int K, float* y) {
+  gemm_nt(x, K, w, K, bias, M, N, K, y, N, 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------
+// Elementwise.  Gelu = tanh approximation, diffusion_rs_common/src/core/op.rs:539-582 (f32 arm);
+// Silu = v/(1+exp(-v)), op.rs:699-721.
+// ---------------------------------------------------------------------------------------
+static inline float gelu_f32(float v) {
+  const float SQRT_TWO_OVER_PI = 0.79788456080286535587989211986876373f;
+  return 0.5f * v * (1.0f + tanhf(SQRT_TWO_OVER_PI * v * (1.0f + 0.044715f * v * v)));
+}
+static inline float silu_f32(float v) { return v / (1.0f + expf(-v)); }
+extern "C" void orc_gelu(const float* x, int64_t n, float* out) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < n; ++i) out[i] = gelu_f32(x[i]);
+}
+extern "C" void orc_silu(const float* x, int64_t n, float* out) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < n; ++i) out[i] = silu_f32(x[i]);
+}
+
+// LayerNorm fast path, diffusion_rs_common/src/nn/ops.rs:1020-1041 (CPU fwd of ops::layer_norm).
+extern "C" void orc_layer_norm(const float* x, const float* alpha, const float* beta, float eps, int rows, int cols, float* out) {
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r) {
+    const float* s = x + (int64_t)r * cols;
+    float* d = out + (int64_t)r * cols;
+    float sum = 0.f, sum2 = 0.f;
+    for (int i = 0; i < cols; ++i) {
+      float v = s[i];
+      sum += v;
+      sum2 += v * v;
+    }
+    float mean = sum / (float)cols;
+    float var = sum2 / (float)cols - mean * mean;
+    float inv_std = 1.0f / sqrtf(var + eps);
+    for (int i = 0; i < cols; ++i) {
+      float a = alpha ? alpha[i] : 1.f, b = beta ? beta[i] : 0.f;
+      d[i] = (s[i] - mean) * inv_std * a + b;
+    }
+  }
+}
+
+// RmsNorm<RmsNormNonQuantized> -> LayerNorm{remove_mean:false} slow path,
+// diffusion_rs_common/src/nn/layer_norm.rs:136-153: x / sqrt(mean(x^2)+eps) * weight (+0).
+extern "C" void orc_rms_norm_slow(const float* x, const float* alpha, float eps, int rows, int cols, float* out) {
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r) {
+    const float* s = x + (int64_t)r * cols;
+    float* d = out + (int64_t)r * cols;
+    float sum2 = 0.f;
+    for (int i = 0; i < cols; ++i) sum2 += s[i] * s[i];
+    float norm_x = sum2 / (float)cols;
+    float den = sqrtf(norm_x + eps);
+    for (int i = 0; i < cols; ++i) d[i] = (s[i] / den) * (alpha ? alpha[i] : 1.f);
+  }
+}
+
+// softmax_last_dim CPU fwd, diffusion_rs_common/src/nn/ops.rs:419-448.
+extern "C" void orc_softmax_last_dim(const float* x, int rows, int cols, float* out) {
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r) {
+    const float* s = x + (int64_t)r * cols;
+    float* d = out + (int64_t)r * cols;
+    float mx = -INFINITY;
+    for (int i = 0; i < cols; ++i) mx = std::max(mx, s[i]);
+    float sum = 0.f;
+    for (int i = 0; i < cols; ++i) {
+      d[i] = expf(s[i] - mx);
+      sum += d[i];
+    }
+    for (int i = 0; i < cols; ++i) d[i] /= sum;
+  }
+}
+
+// GroupNorm::forward, diffusion_rs_common/src/nn/group_norm.rs:39-74. x is (B,C,HW) NCHW.
+extern "C" void orc_group_norm(const float* x, const float* w, const float* b, int B, int C, int HW, int groups, float eps, float* out) {
+  const int cpg = C / groups;
+  const int64_t hidden = (int64_t)cpg * HW;
+#pragma omp parallel for collapse(2)
+  for (int bi = 0; bi < B; ++bi)
+    for (int g = 0; g < groups; ++g) {
+      const float* s = x + ((int64_t)bi * C + (int64_t)g * cpg) * HW;
+      float* d = out + ((int64_t)bi * C + (int64_t)g * cpg) * HW;
+      float sum = 0.f;
+      for (int64_t i = 0; i < hidden; ++i) sum += s[i];
+      float mean = sum / (float)hidden;
+      float sq = 0.f;
+      for (int64_t i = 0; i < hidden; ++i) {
+        float c = s[i] - mean;
+        sq += c * c;
+      }
+      float den = sqrtf(sq / (float)hidden + eps);
+      for (int c = 0; c < cpg; ++c) {
+        float ww = w ? w[g * cpg + c] : 1.f, bb = b ? b[g * cpg + c] : 0.f;
+        for (int i = 0; i < HW; ++i) {
+          int64_t o = (int64_t)c * HW + i;
+          d[o] = ((s[o] - mean) / den) * ww + bb;
+        }
+      }
+    }
+}
+
+// Conv2d: Tensor::conv2d (core/conv.rs:278-318) -> im2col + GEMM, cpu_backend/mod.rs:869-942
+// (Im2Col: column layout (b, h_out*w_out, c_in*kh*kw) with c_in outermost) and :3430-3477;
+// bias added by nn/conv.rs:212-230.  NCHW in, weight (Cout,Cin,kh,kw), NCHW out.
+extern "C" void orc_conv2d(const float* x, const float* w, const float* bias, int B, int Cin, int H, int W, int Cout, int kh, int kw, int pad, int stride, int dilation, float* out) {
+  const int Ho = (H + 2 * pad - dilation * (kh - 1) - 1) / stride + 1;
+  const int Wo = (W + 2 * pad - dilation * (kw - 1) - 1) / stride + 1;
+  const int K = Cin * kh * kw;
+  const int64_t P = (int64_t)Ho * Wo;
+  const int64_t CH = 8192;  // pixels per im2col chunk (bounds memory at 1024^2)
+  std::vector<float> col((size_t)std::min<int64_t>(CH, P) * K);
+  std::vector<float> res((size_t)std::min<int64_t>(CH, P) * Cout);
+  for (int b = 0; b < B; ++b) {
+    const float* xb = x + (int64_t)b * Cin * H * W;
+    float* ob = out + (int64_t)b * Cout * P;
+    for (int64_t p0 = 0; p0 < P; p0 += CH) {
+      const int64_t pn = std::min(CH, P - p0);
+#pragma omp parallel for
+      for (int64_t pi = 0; pi < pn; ++pi) {
+        const int64_t p = p0 + pi;
+        const int oh = (int)(p / Wo), ow = (int)(p % Wo);
+        float* c = col.data() + pi * K;
+        for (int ci = 0; ci < Cin; ++ci)
+          for (int ky = 0; ky < kh; ++ky)
+            for (int kx = 0; kx < kw; ++kx) {
+              int ih = oh * stride + ky * dilation - pad;
+              int iw = ow * stride + kx * dilation - pad;
+              float v = 0.f;
+              if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = xb[((int64_t)ci * H + ih) * W + iw];
+              c[(ci * kh + ky) * kw + kx] = v;
+            }
+      }
+      gemm_nt(col.data(), K, w, K, nullptr, (int)pn, Cout, K, res.data(), Cout, 1.0f);
+#pragma omp parallel for
+      for (int co = 0; co < Cout; ++co) {
+        float bb = bias ? bias[co] : 0.f;
+        for (int64_t pi = 0; pi < pn; ++pi) ob[(int64_t)co * P + p0 + pi] = res[pi * Cout + co] + bb;
+      }
+    }
+  }
+}
+
+// UpsampleNearest2D, diffusion_rs_common/src/core/cpu_backend/mod.rs:425-460.
+extern "C" void orc_upsample_nearest2d(const float* x, int B, int C, int H, int W, int dstH, int dstW, float* out) {
+  const double sh = (double)H / (double)dstH, sw = (double)W / (double)dstW;
+  std::vector<int> hi(dstH), wi(dstW);
+  for (int i = 0; i < dstH; ++i) hi[i] = std::min(H - 1, (int)((double)i * sh));
+  for (int i = 0; i < dstW; ++i) wi[i] = std::min(W - 1, (int)((double)i * sw));
+#pragma omp parallel for
+  for (int bc = 0; bc < B * C; ++bc) {
+    const float* s = x + (int64_t)bc * H * W;
+    float* d = out + (int64_t)bc * dstH * dstW;
+    for (int i = 0; i < dstH; ++i)
+      for (int j = 0; j < dstW; ++j) d[(int64_t)i * dstW + j] = s[(int64_t)hi[i] * W + wi[j]];
+  }
+}
+
+// sdpa fallback, diffusion_rs_backend/src/ops.rs:247-262 (softcapping == 1.0 branch):
+// att = softmax_last_dim((q k^T) * scale); att v.   q,k,v (B,H,L,d).
+extern "C" void orc_sdpa(const float* q, const float* k, const float* v, int B, int H, int Lq, int Lk, int d, float scale, float* out) {
+  std::vector<float> att((size_t)Lq * Lk), vt((size_t)d * Lk);
+  for (int bh = 0; bh < B * H; ++bh) {
+    const float* qp = q + (int64_t)bh * Lq * d;
+    const float* kp = k + (int64_t)bh * Lk * d;
+    const float* vp = v + (int64_t)bh * Lk * d;
+    gemm_nt(qp, d, kp, d, nullptr, Lq, Lk, d, att.data(), Lk, 1.0f);
+    // `(q.matmul(k^T) * scale)`: affine after the matmul (ops.rs:252)
+#pragma omp parallel for
+    for (int64_t i = 0; i < (int64_t)Lq * Lk; ++i) att[i] *= scale;
+    orc_softmax_last_dim(att.data(), Lq, Lk, att.data());
+#pragma omp parallel for
+    for (int j = 0; j < d; ++j)
+      for (int i = 0; i < Lk; ++i) vt[(size_t)j * Lk + i] = vp[(size_t)i * d + j];
+    gemm_nt(att.data(), Lk, vt.data(), Lk, nullptr, Lq, d, Lk, out + (int64_t)bh * Lq * d, d, 1.0f);
+  }
+}
+
+// rope() + EmbedNd::forward, diffusion_rs_core/src/models/flux/model.rs:65-84,142-157.
+// ids (n, n_axes) -> pe (n, sum(axes)/2, 2, 2) with [[cos,-sin],[sin,cos]].
+extern "C" void orc_rope_table(const float* ids, int n, int n_axes, const int* axes_dim, int theta, float* pe) {
+  int half_total = 0;
+  for (int a = 0; a < n_axes; ++a) half_total += axes_dim[a] / 2;
+  for (int r = 0; r < n; ++r) {
+    int off = 0;
+    for (int a = 0; a < n_axes; ++a) {
+      const int dim = axes_dim[a];
+      const float pos = ids[(int64_t)r * n_axes + a];
+      for (int i = 0; i < dim; i += 2) {
+        // model.rs:73: 1f32 / theta.powf(i/dim) as f32   (pow in f64, then f32)
+        float inv_freq = 1.0f / (float)pow((double)theta, (double)i / (double)dim);
+        float f = pos * inv_freq;
+        float c = cosf(f), s = sinf(f);
+        float* o = pe + ((int64_t)r * half_total + off + i / 2) * 4;
+        o[0] = c;
+        o[1] = -s;
+        o[2] = s;
+        o[3] = c;
+      }
+      off += dim / 2;
+    }
+  }
+}
+
+// apply_rope, model.rs:86-95: out[...,0] = pe[..,0,0]*x0 + pe[..,0,1]*x1 ; out[...,1] = pe[..,1,0]*x0 + pe[..,1,1]*x1
+// x (H,L,d) for one batch element, pe (L,d/2,2,2).
+extern "C" void orc_apply_rope(const float* x, const float* pe, int H, int L, int d, float* out) {
+#pragma omp parallel for collapse(2)
+  for (int h = 0; h < H; ++h)
+    for (int l = 0; l < L; ++l) {
+      const float* xp = x + ((int64_t)h * L + l) * d;
+      float* op = out + ((int64_t)h * L + l) * d;
+      const float* p = pe + (int64_t)l * (d / 2) * 4;
+      for (int i = 0; i < d / 2; ++i) {
+        float x0 = xp[2 * i], x1 = xp[2 * i + 1];
+        op[2 * i] = p[4 * i + 0] * x0 + p[4 * i + 1] * x1;
+        op[2 * i + 1] = p[4 * i + 2] * x0 + p[4 * i + 3] * x1;
+      }
+    }
+}
+
+// timestep_embedding, model.rs:104-122.  t (B) -> (B, dim) = [cos(args), sin(args)].
+extern "C" void orc_timestep_embedding(const float* t, int B, int dim, float* out) {
+  const int half = dim / 2;
+  for (int b = 0; b < B; ++b) {
+    // (t * TIME_FACTOR): affine with the scalar rounded to f32 (tensor is f32)
+    float ts = t[b] * 1000.0f;
+    for (int i = 0; i < half; ++i) {
+      // arange * (-ln(10000)/half) : f32 tensor * f64 scalar -> scalar rounded to f32 (affine)
+      float fr = expf((float)i * (float)(-log(10000.0) / (double)half));
+      float a = ts * fr;
+      out[(int64_t)b * dim + i] = cosf(a);
+      out[(int64_t)b * dim + half + i] = sinf(a);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// bitsandbytes dequant — CUDA-kernel semantics (the reference CPU op.rs path is
+// wrong for nf4/fp4; the CUDA kernels = real bitsandbytes are the truth).
+// diffusion_rs_backend/kernels/bitsandbytes/dequant.cu:12-37 (fp4 tree), :39-92 (nf4 tree),
+// :94-159 (kDequantizeBlockwise), :205-214 (dequantize_8bit_kernel).
+// ---------------------------------------------------------------------------------------
+static inline float dq_fp4(unsigned char val, float absmax) {
+  float sign = (val & 0b1000) == 8 ? -1.0f : 1.0f;
+  if ((val & 0b0100) == 4) {
+    if ((val & 0b0010) == 2) {
+      if ((val & 0b0001) == 1) return 0.25000000f * absmax * sign;
+      return 0.16666667f * absmax * sign;
+    }
+    if ((val & 0b0001) == 1) return 0.50000000f * absmax * sign;
+    return 0.33333333f * absmax * sign;
+  }
+  if ((val & 0b0010) == 2) {
+    if ((val & 0b0001) == 1) return 1.00000000f * absmax * sign;
+    return 0.66666667f * absmax * sign;
+  }
+  if ((val & 0b0001) == 1) return 5.208333333e-03f * absmax * sign;
+  return 0.00000000f * absmax * sign;
+}
+static const float NF4_LUT[16] = {-1.0f,
+                                  -0.6961928009986877f,
+                                  -0.5250730514526367f,
+                                  -0.39491748809814453f,
+                                  -0.28444138169288635f,
+                                  -0.18477343022823334f,
+                                  -0.09105003625154495f,
+                                  0.0f,
+                                  0.07958029955625534f,
+                                  0.16093020141124725f,
+                                  0.24611230194568634f,
+                                  0.33791524171829224f,
+                                  0.44070982933044434f,
+                                  0.5626170039176941f,
+                                  0.7229568362236023f,
+                                  1.0f};
+static const float FP4_ABS[8] = {0.0f, 5.208333333e-03f, 0.66666667f, 1.0f, 0.33333333f, 0.5f, 0.16666667f, 0.25f};
+
+extern "C" void orc_dequantize_blockwise(const float* code, const uint8_t* A, const float* absmax, float* out, int blocksize, int n, int quant_type, int out_dtype) {
+  if (quant_type == 0) {
+    // General8bit: out[i] = code[A[i]] * absmax[i / blocksize]   (dequant.cu:125,132-137)
+    for (int64_t i = 0; i < n; ++i) out[i] = round_out(code[A[i]] * absmax[i / blocksize], out_dtype);
+    return;
+  }
+  // 4-bit: byte b -> outputs 2b (high nibble) and 2b+1 (low nibble); the launcher passes
+  // blocksize/2 so absmax index = byte / (blocksize/2) (dequant.cu:125,167).
+  const int64_t nbytes = ((int64_t)n + 1) / 2;
+  const int half = blocksize / 2;
+  for (int64_t b = 0; b < nbytes; ++b) {
+    float am = absmax[b / half];
+    unsigned char q = A[b];
+    float hi, lo;
+    if (quant_type == 1) {
+      hi = dq_fp4(q >> 4, am);
+      lo = dq_fp4(q & 0x0F, am);
+    } else {
+      hi = NF4_LUT[q >> 4] * am;
+      lo = NF4_LUT[q & 0x0F] * am;
+    }
+    out[2 * b] = round_out(hi, out_dtype);
+    if (2 * b + 1 < n) out[2 * b + 1] = round_out(lo, out_dtype);
+  }
+}
+
+extern "C" void orc_dequantize_8bit(const int8_t* w, const float* scb, float* out, int row, int col, int n, int out_dtype) {
+  (void)row;
+  for (int64_t i = 0; i < n; ++i) out[i] = round_out(((float)w[i] * scb[i / col]) / 127.f, out_dtype);
+}
+
+extern "C" void orc_quantize_blockwise_4bit(const float* w, int64_t n, int blocksize, int quant_type, uint8_t* packed, float* absmax) {
+  const int64_t nblocks = (n + blocksize - 1) / blocksize;
+  for (int64_t blk = 0; blk < nblocks; ++blk) {
+    const int64_t s = blk * blocksize, e = std::min<int64_t>(n, s + blocksize);
+    float am = 0.f;
+    for (int64_t i = s; i < e; ++i) am = std::max(am, fabsf(w[i]));
+    absmax[blk] = am;
+    for (int64_t i = s; i < e; ++i) {
+      float v = am > 0.f ? w[i] / am : 0.f;
+      int best = 0;
+      float bd = 1e30f;
+      for (int c = 0; c < 16; ++c) {
+        float cv = quant_type == 2 ? NF4_LUT[c] : ((c & 8) ? -FP4_ABS[c & 7] : FP4_ABS[c & 7]);
+        float dd = fabsf(cv - v);
+        if (dd < bd) {
+          bd = dd;
+          best = c;
+        }
+      }
+      if ((i & 1) == 0)
+        packed[i / 2] = (uint8_t)(best << 4);
+      else
+        packed[i / 2] |= (uint8_t)best;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pipeline-level host math
+// ---------------------------------------------------------------------------------------
+// calculate_shift, diffusion_rs_core/src/pipelines/flux/sampling.rs:70-80.
+extern "C" double orc_calculate_shift(int image_seq_len, int base_seq_len, int max_seq_len, double base_shift, double max_shift) {
+  double m = (max_shift - base_shift) / (double)(max_seq_len - base_seq_len);
+  double b = base_shift - m * (double)base_seq_len;
+  return (double)image_seq_len * m + b;
+}
+// SchedulerConfig::get_timesteps + time_shift, pipelines/scheduler.rs:22-51.
+extern "C" void orc_get_timesteps(int num_steps, int use_dynamic_shifting, double mu, double shift, double* out) {
+  for (int i = 0; i <= num_steps; ++i) {
+    double sigma = (double)(num_steps - i) / (double)num_steps;
+    if (use_dynamic_shifting) {
+      double e = exp(mu);
+      out[i] = e / (e + pow(1.0 / sigma - 1.0, 1.0));
+    } else {
+      out[i] = shift * sigma / (1.0 + (shift - 1.0) * sigma);
+    }
+  }
+}
+// State::new patchify + img_ids, pipelines/flux/sampling.rs:26-48.
+extern "C" void orc_pack_latents(const float* latent, int B, int C, int h, int w, float* img, float* img_ids) {
+  const int h2 = h / 2, w2 = w / 2;
+  for (int b = 0; b < B; ++b)
+    for (int i = 0; i < h2; ++i)
+      for (int j = 0; j < w2; ++j) {
+        int64_t tok = ((int64_t)b * h2 + i) * w2 + j;
+        for (int c = 0; c < C; ++c)
+          for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw)
+              img[tok * (C * 4) + (c * 2 + ph) * 2 + pw] = latent[(((int64_t)b * C + c) * h + (2 * i + ph)) * w + (2 * j + pw)];
+        if (img_ids) {
+          img_ids[tok * 3 + 0] = 0.f;
+          img_ids[tok * 3 + 1] = (float)i;
+          img_ids[tok * 3 + 2] = (float)j;
+        }
+      }
+}
+// unpack, pipelines/flux/sampling.rs:61-68.
+extern "C" void orc_unpack_latents(const float* img, int B, int C, int h, int w, float* out) {
+  const int h2 = h / 2, w2 = w / 2;
+  for (int b = 0; b < B; ++b)
+    for (int i = 0; i < h2; ++i)
+      for (int j = 0; j < w2; ++j) {
+        int64_t tok = ((int64_t)b * h2 + i) * w2 + j;
+        for (int c = 0; c < C; ++c)
+          for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw)
+              out[(((int64_t)b * C + c) * h + (2 * i + ph)) * w + (2 * j + pw)] = img[tok * (C * 4) + (c * 2 + ph) * 2 + pw];
+      }
+}
+// ((x.clamp(-1,1)+1)*127.5).to_dtype(U8): pipelines/flux/mod.rs:332; the cast is Rust `as u8`
+// (truncate toward zero, saturating; NaN -> 0), cpu_backend/mod.rs:2571-2574.
+extern "C" void orc_postprocess_u8(const float* x, int64_t n, uint8_t* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    float v = x[i];
+    v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v);  // clamp; NaN propagates like f32::clamp
+    v = (v + 1.0f) * 127.5f;
+    uint8_t u;
+    if (!(v == v))
+      u = 0;
+    else if (v <= 0.f)
+      u = 0;
+    else if (v >= 255.f)
+      u = 255;
+    else
+      u = (uint8_t)v;
+    out[i] = u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// FLUX model — diffusion_rs_core/src/models/flux/model.rs
+// ---------------------------------------------------------------------------------------
+struct orc_flux {
+  int in_channels, pooled_dim, joint_dim, heads, n_double, n_single, guidance;
+  int axes[3], theta;
+  int D, M;
+  std::map<std::string, std::vector<float>> t;
+  const float* get(const std::string& name, int64_t numel) const {
+    auto it = t.find(name);
+    if (it == t.end()) {
+      fprintf(stderr, "[oracle] missing tensor %s\n", name.c_str());
+      return nullptr;
+    }
+    if ((int64_t)it->second.size() != numel) {
+      fprintf(stderr, "[oracle] tensor %s has %zu elements, expected %lld\n", name.c_str(), it->second.size(), (long long)numel);
+      return nullptr;
+    }
+    return it->second.data();
+  }
+};
+
+extern "C" orc_flux* orc_flux_create(int in_channels, int pooled_projection_dim, int joint_attention_dim, int num_attention_heads, int num_layers, int num_single_layers, int guidance_embeds, const int* axes_dim, int theta) {
+  orc_flux* m = new orc_flux();
+  m->in_channels = in_channels;
+  m->pooled_dim = pooled_projection_dim;
+  m->joint_dim = joint_attention_dim;
+  m->heads = num_attention_heads;
+  m->n_double = num_layers;
+  m->n_single = num_single_layers;
+  m->guidance = guidance_embeds;
+  for (int i = 0; i < 3; ++i) m->axes[i] = axes_dim[i];
+  m->theta = theta;
+  // HIDDEN_SIZE = 3072 = 24*128 in the reference (model.rs:17); generalised as heads * pe_dim
+  // with pe_dim = sum(axes_dim) so reduced test configs stay self-consistent.
+  m->D = num_attention_heads * (axes_dim[0] + axes_dim[1] + axes_dim[2]);
+  m->M = 4 * m->D;  // MLP_RATIO = 4 (model.rs:16)
+  return m;
+}
+extern "C" void orc_flux_destroy(orc_flux* m) { delete m; }
+extern "C" int orc_flux_set_tensor(orc_flux* m, const char* name, const float* data, int64_t numel) {
+  m->t[name] = std::vector<float>(data, data + numel);
+  return 0;
+}
+
+namespace {
+struct Lin {
+  const float* w;
+  const float* b;
+  int in, out;
+  bool ok() const { return w != nullptr; }
+};
+Lin get_lin(const orc_flux* m, const std::string& p, int in, int out, bool bias = true) {
+  Lin l;
+  l.in = in;
+  l.out = out;
+  l.w = m->get(p + ".weight", (int64_t)in * out);
+  l.b = bias ? m->get(p + ".bias", out) : nullptr;
+  if (bias && !l.b) l.w = nullptr;
+  return l;
+}
+void lin_fwd(const Lin& l, const float* x, int rows, float* y) { gemm_nt(x, l.in, l.w, l.in, l.b, rows, l.out, l.in, y, l.out, 1.0f); }
+
+// layer_norm() helper model.rs:33-38 (weight = 1, bias = 0, eps 1e-6) then
+// ModulationOut::scale_shift model.rs:218-221: xs*(scale+1)+shift
+void ln_mod(const float* x, const float* shift, const float* scale, int rows, int D, float* out) {
+  orc_layer_norm(x, nullptr, nullptr, 1e-6f, rows, D, out);
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r)
+    for (int i = 0; i < D; ++i) {
+      float* o = out + (int64_t)r * D + i;
+      *o = *o * (scale[i] + 1.0f) + shift[i];
+    }
+}
+// (rows, H*d) token-major -> (H, rows, d)   [reshape + transpose(1,2), model.rs:414-423]
+void to_heads(const float* x, int rows, int H, int d, float* out, int row_off, int Ltot) {
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r)
+    for (int h = 0; h < H; ++h) memcpy(out + ((int64_t)h * Ltot + row_off + r) * d, x + ((int64_t)r * H + h) * d, sizeof(float) * d);
+}
+// attention(), model.rs:97-102: rope on q,k; sdpa in f32 (model.rs:40-50); (H,L,d)->(L,H*d)
+void attention(const float* q, const float* k, const float* v, const float* pe, int H, int L, int d, float* out_tok) {
+  std::vector<float> qr((size_t)H * L * d), kr((size_t)H * L * d), o((size_t)H * L * d);
+  orc_apply_rope(q, pe, H, L, d, qr.data());
+  orc_apply_rope(k, pe, H, L, d, kr.data());
+  float scale = (float)(1.0 / sqrt((double)d));
+  orc_sdpa(qr.data(), kr.data(), v, 1, H, L, L, d, scale, o.data());
+#pragma omp parallel for
+  for (int l = 0; l < L; ++l)
+    for (int h = 0; h < H; ++h) memcpy(out_tok + ((int64_t)l * H + h) * d, o.data() + ((int64_t)h * L + l) * d, sizeof(float) * d);
+}
+// SelfAttention::qkv, model.rs:399-427: three linears, head split, QkNorm on q and k.
+bool qkv(const orc_flux* m, const std::string& p, const char* qn, const char* kn, const char* vn, const char* nq, const char* nk, const float* x, int rows, int row_off, int Ltot, float* Q, float* K, float* V) {
+  const int D = m->D, H = m->heads, d = D / H;
+  Lin lq = get_lin(m, p + qn, D, D), lk = get_lin(m, p + kn, D, D), lv = get_lin(m, p + vn, D, D);
+  const float* wq = m->get(p + nq + ".weight", d);
+  const float* wk = m->get(p + nk + ".weight", d);
+  if (!lq.ok() || !lk.ok() || !lv.ok() || !wq || !wk) return false;
+  std::vector<float> tmp((size_t)rows * D), tmp2((size_t)rows * D);
+  lin_fwd(lq, x, rows, tmp.data());
+  orc_rms_norm_slow(tmp.data(), wq, 1e-6f, rows * H, d, tmp2.data());
+  to_heads(tmp2.data(), rows, H, d, Q, row_off, Ltot);
+  lin_fwd(lk, x, rows, tmp.data());
+  orc_rms_norm_slow(tmp.data(), wk, 1e-6f, rows * H, d, tmp2.data());
+  to_heads(tmp2.data(), rows, H, d, K, row_off, Ltot);
+  lin_fwd(lv, x, rows, tmp.data());
+  to_heads(tmp.data(), rows, H, d, V, row_off, Ltot);
+  return true;
+}
+// Modulation1/2::forward, model.rs:244-259,278-299: lin(silu(vec)) chunked
+bool modulation(const orc_flux* m, const std::string& p, const float* vec, int n_chunks, std::vector<float>& out) {
+  const int D = m->D;
+  Lin l = get_lin(m, p + ".linear", D, n_chunks * D);
+  if (!l.ok()) return false;
+  std::vector<float> sv(D);
+  orc_silu(vec, D, sv.data());
+  out.resize((size_t)n_chunks * D);
+  lin_fwd(l, sv.data(), 1, out.data());
+  return true;
+}
+// x += gate * y   (ModulationOut::gate model.rs:223-225 + residual add)
+void add_gated(float* x, const float* gate, const float* y, int rows, int D) {
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r)
+    for (int i = 0; i < D; ++i) x[(int64_t)r * D + i] += gate[i] * y[(int64_t)r * D + i];
+}
+}  // namespace
+
+// DoubleStreamBlock::forward, model.rs:523-565 (one batch element).
+static int double_block_one(orc_flux* m, int idx, float* img, float* txt, const float* vec, const float* pe, int S, int T) {
+  const int D = m->D, H = m->heads, d = D / H, M = m->M, L = S + T;
+  const std::string p = "transformer_blocks." + std::to_string(idx) + ".";
+  std::vector<float> imod, tmod;
+  if (!modulation(m, p + "norm1", vec, 6, imod)) return -1;          // img_mod  (model.rs:484,530)
+  if (!modulation(m, p + "norm1_context", vec, 6, tmod)) return -1;  // txt_mod  (model.rs:497,531)
+  std::vector<float> Q((size_t)H * L * d), K((size_t)H * L * d), V((size_t)H * L * d);
+  std::vector<float> xm((size_t)S * D), tm((size_t)T * D);
+  // chunks: shift=0, scale=1, gate=2 | shift=3, scale=4, gate=5  (model.rs:288-297)
+  ln_mod(img, imod.data() + 0 * D, imod.data() + 1 * D, S, D, xm.data());
+  if (!qkv(m, p + "attn.", "to_q", "to_k", "to_v", "norm_q", "norm_k", xm.data(), S, T, L, Q.data(), K.data(), V.data())) return -1;
+  ln_mod(txt, tmod.data() + 0 * D, tmod.data() + 1 * D, T, D, tm.data());
+  if (!qkv(m, p + "attn.", "add_q_proj", "add_k_proj", "add_v_proj", "norm_added_q", "norm_added_k", tm.data(), T, 0, L, Q.data(), K.data(), V.data())) return -1;
+  // cat([txt, img], seq) is realised by the row offsets above (model.rs:540-542)
+  std::vector<float> attn((size_t)L * D);
+  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data());
+  const float* txt_attn = attn.data();
+  const float* img_attn = attn.data() + (size_t)T * D;
+  Lin ip = get_lin(m, p + "attn.to_out.0", D, D), tp = get_lin(m, p + "attn.to_add_out", D, D);
+  Lin i1 = get_lin(m, p + "ff.net.0.proj", D, M), i2 = get_lin(m, p + "ff.net.2", M, D);
+  Lin t1 = get_lin(m, p + "ff_context.net.0.proj", D, M), t2 = get_lin(m, p + "ff_context.net.2", M, D);
+  if (!ip.ok() || !tp.ok() || !i1.ok() || !i2.ok() || !t1.ok() || !t2.ok()) return -1;
+  {
+    std::vector<float> y((size_t)S * D), h((size_t)S * M);
+    lin_fwd(ip, img_attn, S, y.data());
+    add_gated(img, imod.data() + 2 * D, y.data(), S, D);  // model.rs:548
+    ln_mod(img, imod.data() + 3 * D, imod.data() + 4 * D, S, D, xm.data());
+    lin_fwd(i1, xm.data(), S, h.data());
+    orc_gelu(h.data(), (int64_t)S * M, h.data());
+    lin_fwd(i2, h.data(), S, y.data());
+    add_gated(img, imod.data() + 5 * D, y.data(), S, D);  // model.rs:549-554
+  }
+  {
+    std::vector<float> y((size_t)T * D), h((size_t)T * M);
+    lin_fwd(tp, txt_attn, T, y.data());
+    add_gated(txt, tmod.data() + 2 * D, y.data(), T, D);  // model.rs:556
+    ln_mod(txt, tmod.data() + 3 * D, tmod.data() + 4 * D, T, D, tm.data());
+    lin_fwd(t1, tm.data(), T, h.data());
+    orc_gelu(h.data(), (int64_t)T * M, h.data());
+    lin_fwd(t2, h.data(), T, y.data());
+    add_gated(txt, tmod.data() + 5 * D, y.data(), T, D);  // model.rs:557-562
+  }
+  return 0;
+}
+
+// SingleStreamBlock::forward, model.rs:638-662 (one batch element).
+static int single_block_one(orc_flux* m, int idx, float* x, const float* vec, const float* pe, int L) {
+  const int D = m->D, H = m->heads, d = D / H, M = m->M;
+  const std::string p = "single_transformer_blocks." + std::to_string(idx) + ".";
+  std::vector<float> mod;
+  if (!modulation(m, p + "norm", vec, 3, mod)) return -1;  // shift, scale, gate (model.rs:254-258)
+  std::vector<float> xm((size_t)L * D);
+  ln_mod(x, mod.data() + 0 * D, mod.data() + 1 * D, L, D, xm.data());
+  std::vector<float> Q((size_t)H * L * d), K((size_t)H * L * d), V((size_t)H * L * d);
+  if (!qkv(m, p + "attn.", "to_q", "to_k", "to_v", "norm_q", "norm_k", xm.data(), L, 0, L, Q.data(), K.data(), V.data())) return -1;
+  Lin pm = get_lin(m, p + "proj_mlp", D, M), l2 = get_lin(m, p + "proj_out", D + M, D);
+  if (!pm.ok() || !l2.ok()) return -1;
+  std::vector<float> cat((size_t)L * (D + M)), mlp((size_t)L * M), attn((size_t)L * D);
+  lin_fwd(pm, xm.data(), L, mlp.data());
+  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data());
+  orc_gelu(mlp.data(), (int64_t)L * M, mlp.data());
+#pragma omp parallel for
+  for (int l = 0; l < L; ++l) {  // Tensor::cat(&[attn, mlp.gelu()], 2)  (model.rs:660)
+    memcpy(cat.data() + (size_t)l * (D + M), attn.data() + (size_t)l * D, sizeof(float) * D);
+    memcpy(cat.data() + (size_t)l * (D + M) + D, mlp.data() + (size_t)l * M, sizeof(float) * M);
+  }
+  std::vector<float> y((size_t)L * D);
+  lin_fwd(l2, cat.data(), L, y.data());
+  add_gated(x, mod.data() + 2 * D, y.data(), L, D);  // xs + mod_.gate(&output)  (model.rs:661)
+  return 0;
+}
+
+extern "C" int orc_flux_double_block(orc_flux* m, int idx, float* img, float* txt, const float* vec, const float* pe, int B, int S, int T) {
+  const int D = m->D, L = S + T, d = D / m->heads;
+  for (int b = 0; b < B; ++b)
+    if (double_block_one(m, idx, img + (int64_t)b * S * D, txt + (int64_t)b * T * D, vec + (int64_t)b * D, pe + (int64_t)b * L * (d / 2) * 4, S, T)) return -1;
+  return 0;
+}
+extern "C" int orc_flux_single_block(orc_flux* m, int idx, float* x, const float* vec, const float* pe, int B, int L) {
+  const int D = m->D, d = D / m->heads;
+  for (int b = 0; b < B; ++b)
+    if (single_block_one(m, idx, x + (int64_t)b * L * D, vec + (int64_t)b * D, pe + (int64_t)b * L * (d / 2) * 4, L)) return -1;
+  return 0;
+}
+
+// MlpEmbedder::forward, model.rs:178-183: out_layer(silu(in_layer(x)))
+static bool mlp_embedder(const orc_flux* m, const std::string& p, int in_sz, const float* x, int B, float* out) {
+  const int D = m->D;
+  Lin a = get_lin(m, p + ".linear_1", in_sz, D), b = get_lin(m, p + ".linear_2", D, D);
+  if (!a.ok() || !b.ok()) return false;
+  std::vector<float> h((size_t)B * D);
+  lin_fwd(a, x, B, h.data());
+  orc_silu(h.data(), (int64_t)B * D, h.data());
+  lin_fwd(b, h.data(), B, out);
+  return true;
+}
+
+// Flux::forward, model.rs:790-833.
+extern "C" int orc_flux_forward(orc_flux* m, const float* img, const float* img_ids, const float* txt, const float* txt_ids, const float* timesteps, const float* y, const float* guidance, int B, int S, int T, float* pred) {
+  const int D = m->D, H = m->heads, d = D / H, L = S + T, C = m->in_channels;
+  // pe = EmbedNd(cat([txt_ids, img_ids], 1))  (model.rs:807-810)
+  std::vector<float> ids((size_t)B * L * 3), pe((size_t)B * L * (d / 2) * 4);
+  for (int b = 0; b < B; ++b) {
+    memcpy(ids.data() + (size_t)b * L * 3, txt_ids + (size_t)b * T * 3, sizeof(float) * T * 3);
+    memcpy(ids.data() + ((size_t)b * L + T) * 3, img_ids + (size_t)b * S * 3, sizeof(float) * S * 3);
+  }
+  orc_rope_table(ids.data(), B * L, 3, m->axes, m->theta, pe.data());
+  Lin txt_in = get_lin(m, "context_embedder", m->joint_dim, D), img_in = get_lin(m, "x_embedder", C, D);
+  if (!txt_in.ok() || !img_in.ok()) return -1;
+  std::vector<float> t((size_t)B * T * D), x((size_t)B * S * D);
+  lin_fwd(txt_in, txt, B * T, t.data());  // model.rs:811
+  lin_fwd(img_in, img, B * S, x.data());  // model.rs:812
+  // vec_ (model.rs:813-820)
+  std::vector<float> temb((size_t)B * 256), vec((size_t)B * D), tmp((size_t)B * D);
+  orc_timestep_embedding(timesteps, B, 256, temb.data());
+  if (!mlp_embedder(m, "time_text_embed.timestep_embedder", 256, temb.data(), B, vec.data())) return -1;
+  if (m->guidance && guidance) {
+    orc_timestep_embedding(guidance, B, 256, temb.data());
+    if (!mlp_embedder(m, "time_text_embed.guidance_embedder", 256, temb.data(), B, tmp.data())) return -1;
+    for (size_t i = 0; i < vec.size(); ++i) vec[i] += tmp[i];
+  }
+  if (!mlp_embedder(m, "time_text_embed.text_embedder", m->pooled_dim, y, B, tmp.data())) return -1;
+  for (size_t i = 0; i < vec.size(); ++i) vec[i] += tmp[i];
+
+  for (int i = 0; i < m->n_double; ++i)
+    if (orc_flux_double_block(m, i, x.data(), t.data(), vec.data(), pe.data(), B, S, T)) return -1;
+  // cat([txt, img], 1) (model.rs:827)
+  std::vector<float> xs((size_t)B * L * D);
+  for (int b = 0; b < B; ++b) {
+    memcpy(xs.data() + (size_t)b * L * D, t.data() + (size_t)b * T * D, sizeof(float) * T * D);
+    memcpy(xs.data() + ((size_t)b * L + T) * D, x.data() + (size_t)b * S * D, sizeof(float) * S * D);
+  }
+  for (int i = 0; i < m->n_single; ++i)
+    if (orc_flux_single_block(m, i, xs.data(), vec.data(), pe.data(), B, L)) return -1;
+  // LastLayer::forward (model.rs:694-705): chunks = (scale, shift)
+  Lin ada = get_lin(m, "norm_out.linear", D, 2 * D), proj = get_lin(m, "proj_out", D, C);
+  if (!ada.ok() || !proj.ok()) return -1;
+  for (int b = 0; b < B; ++b) {
+    std::vector<float> sv(D), ss((size_t)2 * D), xn((size_t)S * D);
+    orc_silu(vec.data() + (size_t)b * D, D, sv.data());
+    lin_fwd(ada, sv.data(), 1, ss.data());
+    const float* scale = ss.data();
+    const float* shift = ss.data() + D;
+    ln_mod(xs.data() + ((size_t)b * L + T) * D, shift, scale, S, D, xn.data());
+    lin_fwd(proj, xn.data(), S, pred + (size_t)b * S * C);
+  }
+  return 0;
+}
+
+// Sampler::sample (FlowMatchEulerDiscrete), diffusion_rs_core/src/pipelines/sampling.rs:25-48.
+extern "C" int orc_flux_denoise(orc_flux* m, float* img, const float* img_ids, const float* txt, const float* txt_ids, const float* y, const float* guidance, int B, int S, int T, const double* timesteps, int n_steps) {
+  const int C = m->in_channels;
+  std::vector<float> tv(B), pred((size_t)B * S * C);
+  for (int s = 0; s < n_steps; ++s) {
+    double t_curr = timesteps[s], t_prev = timesteps[s + 1];
+    // &t_vec * t_curr : f32 tensor (ones) * f64 scalar -> affine with scalar as f32
+    for (int b = 0; b < B; ++b) tv[b] = 1.0f * (float)t_curr;
+    if (orc_flux_forward(m, img, img_ids, txt, txt_ids, tv.data(), y, guidance, B, S, T, pred.data())) return -1;
+    float dt = (float)(t_prev - t_curr);  // pred * (t_prev - t_curr): affine, scalar rounded to the tensor dtype
+    for (size_t i = 0; i < pred.size(); ++i) img[i] = img[i] + pred[i] * dt;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// VAE decoder — diffusion_rs_core/src/models/vaes/vae.rs
+// ---------------------------------------------------------------------------------------
+struct orc_vae {
+  std::vector<int> boc;
+  int layers_per_block, latent, out_ch, groups, mid_attn, post_quant;
+  std::map<std::string, std::vector<float>> t;
+  const float* get(const std::string& name, int64_t numel) const {
+    auto it = t.find(name);
+    if (it == t.end() || (int64_t)it->second.size() != numel) {
+      fprintf(stderr, "[oracle] vae tensor %s missing or wrong size (want %lld)\n", name.c_str(), (long long)numel);
+      return nullptr;
+    }
+    return it->second.data();
+  }
+};
+extern "C" orc_vae* orc_vae_create(const int* boc, int n_blocks, int layers_per_block, int latent_channels, int out_channels, int norm_num_groups, int mid_block_add_attention, int use_post_quant_conv) {
+  orc_vae* v = new orc_vae();
+  v->boc.assign(boc, boc + n_blocks);
+  v->layers_per_block = layers_per_block;
+  v->latent = latent_channels;
+  v->out_ch = out_channels;
+  v->groups = norm_num_groups;
+  v->mid_attn = mid_block_add_attention;
+  v->post_quant = use_post_quant_conv;
+  return v;
+}
+extern "C" void orc_vae_destroy(orc_vae* v) { delete v; }
+extern "C" int orc_vae_set_tensor(orc_vae* v, const char* name, const float* data, int64_t numel) {
+  v->t[name] = std::vector<float>(data, data + numel);
+  return 0;
+}
+namespace {
+typedef std::vector<float> F;
+bool v_conv(const orc_vae* v, const std::string& p, const F& x, int B, int Cin, int H, int W, int Cout, int k, F& out) {
+  const float* w = v->get(p + ".weight", (int64_t)Cout * Cin * k * k);
+  const float* b = v->get(p + ".bias", Cout);
+  if (!w || !b) return false;
+  out.resize((size_t)B * Cout * H * W);
+  orc_conv2d(x.data(), w, b, B, Cin, H, W, Cout, k, k, k / 2, 1, 1, out.data());
+  return true;
+}
+bool v_gn(const orc_vae* v, const std::string& p, const F& x, int B, int C, int HW, F& out, bool silu) {
+  const float* w = v->get(p + ".weight", C);
+  const float* b = v->get(p + ".bias", C);
+  if (!w || !b) return false;
+  out.resize(x.size());
+  orc_group_norm(x.data(), w, b, B, C, HW, v->groups, 1e-6f, out.data());
+  if (silu) orc_silu(out.data(), (int64_t)out.size(), out.data());
+  return true;
+}
+// ResnetBlock::forward, vae.rs:157-172
+bool v_resnet(const orc_vae* v, const std::string& p, F& x, int B, int Cin, int Cout, int H, int W) {
+  F h, h2;
+  if (!v_gn(v, p + ".norm1", x, B, Cin, H * W, h, true)) return false;
+  if (!v_conv(v, p + ".conv1", h, B, Cin, H, W, Cout, 3, h2)) return false;
+  if (!v_gn(v, p + ".norm2", h2, B, Cout, H * W, h, true)) return false;
+  if (!v_conv(v, p + ".conv2", h, B, Cout, H, W, Cout, 3, h2)) return false;
+  if (Cin != Cout) {
+    F sc;
+    if (!v_conv(v, p + ".conv_shortcut", x, B, Cin, H, W, Cout, 1, sc)) return false;
+    x.swap(sc);
+  }
+  for (size_t i = 0; i < x.size(); ++i) x[i] += h2[i];
+  return true;
+}
+// AttnBlock::forward, vae.rs:95-111 with the local sdpa vae.rs:28-33 (model dtype = f32 here).
+// to_q/to_k/to_v/to_out.0 are Linear weights used as 1x1 convs (vae.rs:47-82).
+bool v_attn(const orc_vae* v, const std::string& p, F& x, int B, int C, int H, int W) {
+  const int HW = H * W;
+  F xn;
+  if (!v_gn(v, p + ".group_norm", x, B, C, HW, xn, false)) return false;
+  const float *wq = v->get(p + ".to_q.weight", (int64_t)C * C), *bq = v->get(p + ".to_q.bias", C);
+  const float *wk = v->get(p + ".to_k.weight", (int64_t)C * C), *bk = v->get(p + ".to_k.bias", C);
+  const float *wv = v->get(p + ".to_v.weight", (int64_t)C * C), *bv = v->get(p + ".to_v.bias", C);
+  const float *wo = v->get(p + ".to_out.0.weight", (int64_t)C * C), *bo = v->get(p + ".to_out.0.bias", C);
+  if (!wq || !bq || !wk || !bk || !wv || !bv || !wo || !bo) return false;
+  for (int b = 0; b < B; ++b) {
+    // (C,HW) -> (HW,C) tokens
+    F tok((size_t)HW * C), q((size_t)HW * C), k((size_t)HW * C), vv((size_t)HW * C), o((size_t)HW * C), oo((size_t)HW * C);
+    for (int c = 0; c < C; ++c)
+      for (int i = 0; i < HW; ++i) tok[(size_t)i * C + c] = xn[((size_t)b * C + c) * HW + i];
+    gemm_nt(tok.data(), C, wq, C, bq, HW, C, C, q.data(), C, 1.f);
+    gemm_nt(tok.data(), C, wk, C, bk, HW, C, C, k.data(), C, 1.f);
+    gemm_nt(tok.data(), C, wv, C, bv, HW, C, C, vv.data(), C, 1.f);
+    float scale = (float)(1.0 / sqrt((double)C));
+    orc_sdpa(q.data(), k.data(), vv.data(), 1, 1, HW, HW, C, scale, o.data());
+    gemm_nt(o.data(), C, wo, C, bo, HW, C, C, oo.data(), C, 1.f);
+    for (int c = 0; c < C; ++c)
+      for (int i = 0; i < HW; ++i) x[((size_t)b * C + c) * HW + i] += oo[(size_t)i * C + c];
+  }
+  return true;
+}
+}  // namespace
+
+// Decoder::forward, vae.rs:436-456 (+ AutoEncoderKl::decode, autoencoder_kl.rs:112-119).
+extern "C" int orc_vae_decode(orc_vae* v, const float* z, int B, int h, int w, float* out) {
+  const int nb = (int)v->boc.size();
+  int block_in = v->boc[nb - 1];
+  int H = h, W = w;
+  F x(z, z + (size_t)B * v->latent * h * w), y;
+  if (!v_conv(v, "decoder.conv_in", x, B, v->latent, H, W, block_in, 3, y)) return -1;
+  x.swap(y);
+  if (!v_resnet(v, "decoder.mid_block.resnets.0", x, B, block_in, block_in, H, W)) return -1;
+  if (v->mid_attn && !v_attn(v, "decoder.mid_block.attentions.0", x, B, block_in, H, W)) return -1;
+  if (!v_resnet(v, "decoder.mid_block.resnets.1", x, B, block_in, block_in, H, W)) return -1;
+  for (int lvl = 0; lvl < nb; ++lvl) {
+    const int block_out = v->boc[nb - 1 - lvl];
+    const std::string p = "decoder.up_blocks." + std::to_string(lvl);
+    for (int i = 0; i <= v->layers_per_block; ++i) {
+      if (!v_resnet(v, p + ".resnets." + std::to_string(i), x, B, block_in, block_out, H, W)) return -1;
+      block_in = block_out;
+    }
+    if (lvl != 3) {  // `i_level != 3` is hard-coded in the reference (vae.rs:412)
+      F up((size_t)B * block_in * H * 2 * W * 2);
+      orc_upsample_nearest2d(x.data(), B, block_in, H, W, H * 2, W * 2, up.data());
+      H *= 2;
+      W *= 2;
+      if (!v_conv(v, p + ".upsamplers.0.conv", up, B, block_in, H, W, block_in, 3, x)) return -1;
+    }
+  }
+  F n;
+  if (!v_gn(v, "decoder.conv_norm_out", x, B, block_in, H * W, n, true)) return -1;
+  if (!v_conv(v, "decoder.conv_out", n, B, block_in, H, W, v->out_ch, 3, y)) return -1;
+  if (v->post_quant) {
+    // The reference applies post_quant_conv (latent_channels -> latent_channels, 1x1) AFTER the
+    // decoder (autoencoder_kl.rs:78-88,114-117), i.e. to a 3-channel image: a shape error for
+    // every real config.  FLUX ships use_post_quant_conv=false; reject like the reference would.
+    fprintf(stderr, "[oracle] use_post_quant_conv=true is a shape error in the reference\n");
+    return -2;
+  }
+  memcpy(out, y.data(), sizeof(float) * y.size());
+  return 0;
+}

@@ -1,0 +1,370 @@
+"""ctypes binding of the CPU oracle (oracle/libflux_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never by the product package (diffusion-rs_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libflux_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "flux_oracle.cpp")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+_lib = None
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+u8p = C.POINTER(C.c_uint8)
+i8p = C.POINTER(C.c_int8)
+i32p = C.POINTER(C.c_int)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_calculate_shift.restype = C.c_double
+        _lib.orc_round_bf16.restype = C.c_float
+        _lib.orc_round_bf16.argtypes = [C.c_float]
+        _lib.orc_round_f16.restype = C.c_float
+        _lib.orc_round_f16.argtypes = [C.c_float]
+        _lib.orc_flux_create.restype = C.c_void_p
+        _lib.orc_vae_create.restype = C.c_void_p
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(f32p)
+
+
+def _opt(a):
+    if a is None:
+        return None, None
+    return _f(a)
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def get_threads():
+    return lib().orc_get_threads()
+
+
+def linear(x, w, b=None):
+    x, xp = _f(x)
+    w, wp = _f(w)
+    b, bp = _opt(b)
+    M, K = int(np.prod(x.shape[:-1])), x.shape[-1]
+    N = w.shape[0]
+    assert w.shape[1] == K
+    y = np.empty(x.shape[:-1] + (N,), np.float32)
+    lib().orc_linear(xp, wp, bp, M, N, K, y.ctypes.data_as(f32p))
+    return y
+
+
+def layer_norm(x, alpha=None, beta=None, eps=1e-5):
+    x, xp = _f(x)
+    a, ap = _opt(alpha)
+    b, bp = _opt(beta)
+    out = np.empty_like(x)
+    lib().orc_layer_norm(xp, ap, bp, C.c_float(eps), int(np.prod(x.shape[:-1])), x.shape[-1], out.ctypes.data_as(f32p))
+    return out
+
+
+def rms_norm_slow(x, alpha=None, eps=1e-5):
+    x, xp = _f(x)
+    a, ap = _opt(alpha)
+    out = np.empty_like(x)
+    lib().orc_rms_norm_slow(xp, ap, C.c_float(eps), int(np.prod(x.shape[:-1])), x.shape[-1], out.ctypes.data_as(f32p))
+    return out
+
+
+def softmax_last_dim(x):
+    x, xp = _f(x)
+    out = np.empty_like(x)
+    lib().orc_softmax_last_dim(xp, int(np.prod(x.shape[:-1])), x.shape[-1], out.ctypes.data_as(f32p))
+    return out
+
+
+def group_norm(x, w, b, groups, eps=1e-5):
+    x, xp = _f(x)
+    w_, wp = _opt(w)
+    b_, bp = _opt(b)
+    B, Cc = x.shape[0], x.shape[1]
+    HW = int(np.prod(x.shape[2:]))
+    out = np.empty_like(x)
+    lib().orc_group_norm(xp, wp, bp, B, Cc, HW, groups, C.c_float(eps), out.ctypes.data_as(f32p))
+    return out
+
+
+def conv2d(x, w, bias=None, pad=0, stride=1, dilation=1):
+    x, xp = _f(x)
+    w, wp = _f(w)
+    b, bp = _opt(bias)
+    B, Cin, H, W = x.shape
+    Cout, Cin2, kh, kw = w.shape
+    assert Cin == Cin2
+    Ho = (H + 2 * pad - dilation * (kh - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dilation * (kw - 1) - 1) // stride + 1
+    out = np.empty((B, Cout, Ho, Wo), np.float32)
+    lib().orc_conv2d(xp, wp, bp, B, Cin, H, W, Cout, kh, kw, pad, stride, dilation, out.ctypes.data_as(f32p))
+    return out
+
+
+def upsample_nearest2d(x, dh, dw):
+    x, xp = _f(x)
+    B, Cc, H, W = x.shape
+    out = np.empty((B, Cc, dh, dw), np.float32)
+    lib().orc_upsample_nearest2d(xp, B, Cc, H, W, dh, dw, out.ctypes.data_as(f32p))
+    return out
+
+
+def gelu(x):
+    x, xp = _f(x)
+    out = np.empty_like(x)
+    lib().orc_gelu(xp, C.c_int64(x.size), out.ctypes.data_as(f32p))
+    return out
+
+
+def silu(x):
+    x, xp = _f(x)
+    out = np.empty_like(x)
+    lib().orc_silu(xp, C.c_int64(x.size), out.ctypes.data_as(f32p))
+    return out
+
+
+def sdpa(q, k, v, scale):
+    q, qp = _f(q)
+    k, kp = _f(k)
+    v, vp = _f(v)
+    B, H, Lq, d = q.shape
+    Lk = k.shape[2]
+    out = np.empty_like(q)
+    lib().orc_sdpa(qp, kp, vp, B, H, Lq, Lk, d, C.c_float(scale), out.ctypes.data_as(f32p))
+    return out
+
+
+def rope_table(ids, axes_dim, theta):
+    ids, ip = _f(ids)
+    n = int(np.prod(ids.shape[:-1]))
+    na = ids.shape[-1]
+    ax = (C.c_int * na)(*axes_dim)
+    half = sum(axes_dim) // 2
+    pe = np.empty(ids.shape[:-1] + (half, 2, 2), np.float32)
+    lib().orc_rope_table(ip, n, na, ax, theta, pe.ctypes.data_as(f32p))
+    return pe
+
+
+def apply_rope(x, pe):
+    """x (H,L,d), pe (L,d/2,2,2)."""
+    x, xp = _f(x)
+    pe, pp = _f(pe)
+    H, L, d = x.shape
+    out = np.empty_like(x)
+    lib().orc_apply_rope(xp, pp, H, L, d, out.ctypes.data_as(f32p))
+    return out
+
+
+def timestep_embedding(t, dim=256):
+    t, tp = _f(t)
+    out = np.empty((t.shape[0], dim), np.float32)
+    lib().orc_timestep_embedding(tp, t.shape[0], dim, out.ctypes.data_as(f32p))
+    return out
+
+
+QUANT = {"int8": 0, "fp4": 1, "nf4": 2}
+ODT = {"f32": 0, "f16": 1, "bf16": 2}
+
+
+def dequantize_blockwise(code, A, absmax, blocksize, n, quant_type, out_dtype="f32"):
+    A = np.ascontiguousarray(A, np.uint8)
+    absmax, ap = _f(absmax)
+    code_, cp = _opt(code)
+    out = np.empty(n, np.float32)
+    lib().orc_dequantize_blockwise(cp, A.ctypes.data_as(u8p), ap, out.ctypes.data_as(f32p), blocksize, n, QUANT[quant_type], ODT[out_dtype])
+    return out
+
+
+def dequantize_8bit(w, scb, row, col, out_dtype="f32"):
+    w = np.ascontiguousarray(w, np.int8)
+    scb, sp = _f(scb)
+    n = row * col
+    out = np.empty(n, np.float32)
+    lib().orc_dequantize_8bit(w.ctypes.data_as(i8p), sp, out.ctypes.data_as(f32p), row, col, n, ODT[out_dtype])
+    return out
+
+
+def quantize_blockwise_4bit(w, blocksize, quant_type):
+    w, wp = _f(w)
+    n = w.size
+    packed = np.zeros((n + 1) // 2, np.uint8)
+    absmax = np.zeros((n + blocksize - 1) // blocksize, np.float32)
+    lib().orc_quantize_blockwise_4bit(wp, C.c_int64(n), blocksize, QUANT[quant_type], packed.ctypes.data_as(u8p), absmax.ctypes.data_as(f32p))
+    return packed, absmax
+
+
+def round_bf16(a):
+    a = np.ascontiguousarray(a, np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    r[nan] = (u[nan].astype(np.uint32) | 0x00400000) & 0xFFFF0000
+    return r.view(np.float32).reshape(a.shape)
+
+
+def calculate_shift(image_seq_len, base_seq_len=256, max_seq_len=4096, base_shift=0.5, max_shift=1.15):
+    return lib().orc_calculate_shift(image_seq_len, base_seq_len, max_seq_len, C.c_double(base_shift), C.c_double(max_shift))
+
+
+def get_timesteps(num_steps, use_dynamic_shifting, mu=0.0, shift=1.0):
+    out = np.empty(num_steps + 1, np.float64)
+    lib().orc_get_timesteps(num_steps, int(use_dynamic_shifting), C.c_double(mu), C.c_double(shift), out.ctypes.data_as(f64p))
+    return out
+
+
+def pack_latents(latent):
+    latent, lp = _f(latent)
+    B, Cc, h, w = latent.shape
+    img = np.empty((B, (h // 2) * (w // 2), Cc * 4), np.float32)
+    ids = np.empty((B, (h // 2) * (w // 2), 3), np.float32)
+    lib().orc_pack_latents(lp, B, Cc, h, w, img.ctypes.data_as(f32p), ids.ctypes.data_as(f32p))
+    return img, ids
+
+
+def unpack_latents(img, Cc, h, w):
+    img, ip = _f(img)
+    B = img.shape[0]
+    out = np.empty((B, Cc, h, w), np.float32)
+    lib().orc_unpack_latents(ip, B, Cc, h, w, out.ctypes.data_as(f32p))
+    return out
+
+
+def postprocess_u8(x):
+    x, xp = _f(x)
+    out = np.empty(x.shape, np.uint8)
+    lib().orc_postprocess_u8(xp, C.c_int64(x.size), out.ctypes.data_as(u8p))
+    return out
+
+
+class Flux:
+    """CPU oracle of models::flux::Flux (model.rs:709-838), f32."""
+
+    def __init__(self, cfg):
+        self.cfg = dict(cfg)
+        ax = (C.c_int * 3)(*cfg["axes_dim"])
+        self.h = C.c_void_p(lib().orc_flux_create(cfg["in_channels"], cfg["pooled_projection_dim"], cfg["joint_attention_dim"],
+                                                  cfg["num_attention_heads"], cfg["num_layers"], cfg["num_single_layers"],
+                                                  int(cfg["guidance_embeds"]), ax, cfg["theta"]))
+        self.D = cfg["num_attention_heads"] * sum(cfg["axes_dim"])
+
+    def __del__(self):
+        try:
+            lib().orc_flux_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_tensor(self, name, arr):
+        a, ap = _f(arr)
+        lib().orc_flux_set_tensor(self.h, name.encode(), ap, C.c_int64(a.size))
+
+    def load(self, tensors):
+        for k, v in tensors.items():
+            self.set_tensor(k, v)
+
+    def forward(self, img, img_ids, txt, txt_ids, timesteps, y, guidance=None):
+        img, a = _f(img)
+        img_ids, b = _f(img_ids)
+        txt, c = _f(txt)
+        txt_ids, d = _f(txt_ids)
+        timesteps, e = _f(timesteps)
+        y, f = _f(y)
+        g_, g = _opt(guidance)
+        B, S, _ = img.shape
+        T = txt.shape[1]
+        pred = np.empty_like(img)
+        rc = lib().orc_flux_forward(self.h, a, b, c, d, e, f, g, B, S, T, pred.ctypes.data_as(f32p))
+        if rc:
+            raise RuntimeError("oracle flux_forward failed (missing tensor?)")
+        return pred
+
+    def denoise(self, img, img_ids, txt, txt_ids, y, guidance, timesteps):
+        img = np.array(img, dtype=np.float32, order="C", copy=True)
+        img_ids, b = _f(img_ids)
+        txt, c = _f(txt)
+        txt_ids, d = _f(txt_ids)
+        y, f = _f(y)
+        g_, g = _opt(guidance)
+        ts = np.ascontiguousarray(timesteps, np.float64)
+        B, S, _ = img.shape
+        T = txt.shape[1]
+        rc = lib().orc_flux_denoise(self.h, img.ctypes.data_as(f32p), b, c, d, f, g, B, S, T, ts.ctypes.data_as(f64p), len(ts) - 1)
+        if rc:
+            raise RuntimeError("oracle flux_denoise failed")
+        return img
+
+    def double_block(self, idx, img, txt, vec, pe):
+        img = np.array(img, dtype=np.float32, order="C", copy=True)
+        txt = np.array(txt, dtype=np.float32, order="C", copy=True)
+        vec, v = _f(vec)
+        pe, p = _f(pe)
+        B, S, _ = img.shape
+        T = txt.shape[1]
+        rc = lib().orc_flux_double_block(self.h, idx, img.ctypes.data_as(f32p), txt.ctypes.data_as(f32p), v, p, B, S, T)
+        if rc:
+            raise RuntimeError("oracle double_block failed")
+        return img, txt
+
+    def single_block(self, idx, x, vec, pe):
+        x = np.array(x, dtype=np.float32, order="C", copy=True)
+        vec, v = _f(vec)
+        pe, p = _f(pe)
+        B, L, _ = x.shape
+        rc = lib().orc_flux_single_block(self.h, idx, x.ctypes.data_as(f32p), v, p, B, L)
+        if rc:
+            raise RuntimeError("oracle single_block failed")
+        return x
+
+
+class Vae:
+    """CPU oracle of vaes::AutoEncoderKl::decode (autoencoder_kl.rs:112-119), f32."""
+
+    def __init__(self, cfg):
+        self.cfg = dict(cfg)
+        boc = cfg["block_out_channels"]
+        arr = (C.c_int * len(boc))(*boc)
+        self.h = C.c_void_p(lib().orc_vae_create(arr, len(boc), cfg["layers_per_block"], cfg["latent_channels"], cfg["out_channels"],
+                                                 cfg["norm_num_groups"], int(cfg["mid_block_add_attention"]), int(cfg.get("use_post_quant_conv", False))))
+
+    def __del__(self):
+        try:
+            lib().orc_vae_destroy(self.h)
+        except Exception:
+            pass
+
+    def load(self, tensors):
+        for k, v in tensors.items():
+            a, ap = _f(v)
+            lib().orc_vae_set_tensor(self.h, k.encode(), ap, C.c_int64(a.size))
+
+    def decode(self, z):
+        z, zp = _f(z)
+        B, _, h, w = z.shape
+        # every level except i_level == 3 upsamples (hard-coded in the reference, vae.rs:412)
+        f = 2 ** sum(1 for lvl in range(len(self.cfg["block_out_channels"])) if lvl != 3)
+        out = np.empty((B, self.cfg["out_channels"], h * f, w * f), np.float32)
+        rc = lib().orc_vae_decode(self.h, zp, B, h, w, out.ctypes.data_as(f32p))
+        if rc:
+            raise RuntimeError("oracle vae_decode failed rc=%d" % rc)
+        return out
