@@ -1,0 +1,29 @@
+# Builds the product library (HIP, gfx950 only) and the CPU oracle (test infrastructure).
+#   make            -> diffusion-rs_amd/libflux_mi355x.so + oracle/libflux_oracle.so
+#   make lib / make oracle / make clean
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+PKG := diffusion-rs_amd
+CSRC := $(PKG)/csrc
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value -Wno-unused-result -ffp-contract=on
+SRCS := $(wildcard $(CSRC)/*.hip)
+OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
+LIB := $(PKG)/libflux_mi355x.so
+
+all: lib oracle
+lib: $(LIB)
+oracle:
+	$(MAKE) -C oracle -s
+
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/flux_mi355x.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -Wl,-soname,libflux_mi355x.so
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle clean

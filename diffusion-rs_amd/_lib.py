@@ -1,0 +1,129 @@
+"""ctypes loader for libflux_mi355x.so (the C-ABI of include/flux_mi355x.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this module raises, and
+every compute entry point raises FmiError on a non-zero status.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflux_mi355x.so")
+
+
+class FmiError(RuntimeError):
+    pass
+
+
+class FluxConfig(C.Structure):
+    """fmi_flux_config == models::flux::Config (model.rs:21-31) + model constants."""
+    _fields_ = [("in_channels", C.c_int), ("pooled_projection_dim", C.c_int), ("joint_attention_dim", C.c_int),
+                ("num_attention_heads", C.c_int), ("num_layers", C.c_int), ("num_single_layers", C.c_int),
+                ("guidance_embeds", C.c_int), ("axes_dim", C.c_int * 3), ("theta", C.c_int)]
+
+
+class FluxInputs(C.Structure):
+    _fields_ = [("img", C.c_void_p), ("img_dtype", C.c_int), ("img_ids", C.c_void_p), ("txt", C.c_void_p), ("txt_dtype", C.c_int),
+                ("txt_ids", C.c_void_p), ("timesteps", C.c_void_p), ("y", C.c_void_p), ("y_dtype", C.c_int), ("guidance", C.c_void_p),
+                ("B", C.c_int), ("S", C.c_int), ("T", C.c_int), ("ids_per_sample", C.c_int)]
+
+
+class VaeConfig(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("block_out_channels", C.c_int * 4), ("n_blocks", C.c_int),
+                ("layers_per_block", C.c_int), ("latent_channels", C.c_int), ("norm_num_groups", C.c_int),
+                ("mid_block_add_attention", C.c_int), ("use_post_quant_conv", C.c_int), ("scaling_factor", C.c_double),
+                ("shift_factor", C.c_double)]
+
+
+class SchedulerConfigC(C.Structure):
+    _fields_ = [("base_image_seq_len", C.c_int), ("base_shift", C.c_double), ("max_image_seq_len", C.c_int), ("max_shift", C.c_double),
+                ("shift", C.c_double), ("use_dynamic_shifting", C.c_int)]
+
+
+F32, F16, BF16, U8, I8 = 0, 1, 2, 3, 4
+MODEL_AUTO, MODEL_BF16, MODEL_F16, MODEL_F32 = 0, 1, 2, 3
+
+_lib = None
+
+
+def load():
+    """Load the HIP library.  torch (if used in this process) must be imported first so that a
+    single libamdhip64.so.7 serves both (same SONAME; see DESIGN.md §process model)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FmiError(f"{LIB_PATH} not found — build it with `make lib` (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    try:
+        import torch  # noqa: F401  (ensures torch's HIP runtime is the one already mapped)
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib.fmi_last_error.restype = C.c_char_p
+    lib.fmi_device_info.restype = C.c_char_p
+    lib.fmi_flux_missing_name.restype = C.c_char_p
+    lib.fmi_vae_missing_name.restype = C.c_char_p
+    lib.fmi_flux_phase_name.restype = C.c_char_p
+    lib.fmi_flux_size_in_bytes.restype = C.c_size_t
+    lib.fmi_calculate_shift.restype = C.c_double
+    lib.fmi_calculate_shift.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+    lib.fmi_vae_scale_factor.restype = C.c_double
+    lib.fmi_vae_shift_factor.restype = C.c_double
+    lib.fmi_unpack_latents.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    lib.fmi_randn.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.fmi_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    lib.fmi_free.argtypes = [C.c_void_p]
+    lib.fmi_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.fmi_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    lib.fmi_flux_set_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
+    lib.fmi_vae_set_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
+    lib.fmi_flux_set_linear_bnb4.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.fmi_flux_forward.argtypes = [C.c_void_p, C.POINTER(FluxInputs), C.c_void_p, C.c_void_p]
+    lib.fmi_flux_denoise.argtypes = [C.c_void_p, C.POINTER(FluxInputs), C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_void_p]
+    lib.fmi_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.fmi_pack_latents.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fmi_postprocess_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.fmi_linear_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.fmi_linear_bnb4_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_void_p]
+    lib.fmi_sdpa_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                  C.c_void_p]
+    lib.fmi_layernorm_mod.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    lib.fmi_groupnorm_nhwc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                       C.c_void_p]
+    lib.fmi_conv2d_nhwc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p]
+    for name in ("f32", "f16", "bf16"):
+        for q in ("int8", "fp4", "nf4"):
+            getattr(lib, f"dequantize_blockwise_{name}_{q}").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+            getattr(lib, f"dequantize_blockwise_{name}_{q}").restype = None
+        getattr(lib, f"dequantize_8bit_kernel_{name}").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        getattr(lib, f"dequantize_8bit_kernel_{name}").restype = None
+    lib.fmi_event_create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.fmi_event_record.argtypes = [C.c_void_p, C.c_void_p]
+    lib.fmi_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    lib.fmi_event_destroy.argtypes = [C.c_void_p]
+    lib.fmi_stream_synchronize.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise FmiError(f"fmi status {rc}: {load().fmi_last_error().decode(errors='replace')}")
+
+
+# every symbol include/flux_mi355x.h declares (tests/test_abi.py checks they are all exported)
+EXPORTED = [
+    "fmi_last_error", "fmi_abi_version", "fmi_init", "fmi_device_info", "fmi_flux_default_config", "fmi_flux_create", "fmi_flux_destroy",
+    "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
+    "fmi_flux_forward", "fmi_flux_denoise", "fmi_flux_set_profiling", "fmi_flux_phase_count", "fmi_flux_phase_name", "fmi_flux_phase_ms",
+    "fmi_vae_default_config", "fmi_vae_create", "fmi_vae_destroy", "fmi_vae_set_tensor", "fmi_vae_missing_count", "fmi_vae_missing_name",
+    "fmi_vae_scale_factor", "fmi_vae_shift_factor", "fmi_vae_decode", "fmi_pack_latents", "fmi_unpack_latents", "fmi_postprocess_u8",
+    "fmi_randn", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_sdpa_bf16", "fmi_layernorm_mod",
+    "fmi_groupnorm_nhwc", "fmi_conv2d_nhwc",
+    "dequantize_blockwise_f32_int8", "dequantize_blockwise_f32_fp4", "dequantize_blockwise_f32_nf4", "dequantize_blockwise_f16_int8",
+    "dequantize_blockwise_f16_fp4", "dequantize_blockwise_f16_nf4", "dequantize_blockwise_bf16_int8", "dequantize_blockwise_bf16_fp4",
+    "dequantize_blockwise_bf16_nf4", "dequantize_8bit_kernel_f32", "dequantize_8bit_kernel_f16", "dequantize_8bit_kernel_bf16",
+    "fmi_malloc", "fmi_free", "fmi_memcpy", "fmi_memset", "fmi_stream_synchronize", "fmi_event_create", "fmi_event_record",
+    "fmi_event_elapsed_ms", "fmi_event_destroy",
+]

@@ -1,0 +1,323 @@
+// attention.hip — fused joint attention for the FLUX DiT, head dim 128, bf16 in / f32 softmax.
+//
+// Replaces scaled_dot_product_attention (diffusion_rs_core/src/models/flux/model.rs:40-50) ->
+// backend::ops::sdpa (diffusion_rs_backend/src/ops.rs:247-262), which on CUDA/CPU upcasts to f32
+// and materialises the full (B,24,L,L) score tensor (2 GB at L=4608) through three eager
+// kernels.  Here scores never leave the CU.
+//
+// CDNA4 design:
+//   * One workgroup = 8 waves = 256 query rows of one (batch, head); each wave owns 32 query rows.
+//   * Everything is computed TRANSPOSED so that a lane owns one query row:
+//       Sᵀ(kv,q)  = K · Qᵀ      (MFMA A operand = K rows from LDS, B operand = Q rows in VGPRs)
+//       Oᵀ(d ,q)  = Vᵀ · Pᵀ     (A = Vᵀ rows from LDS,             B = P of this lane's row)
+//     With the 32x32x16 MFMA the D layout puts column j = lane&31 in the lane, so the running max,
+//     the running sum and the O rescale are lane-local; the only cross-lane traffic per KV tile
+//     is one 32-lane swap of the row max.
+//   * The k-index of the second MFMA is free to permute as long as A and B agree, so P is fed
+//     straight from the S accumulator registers (8 consecutive regs -> one B operand) and the
+//     matching permutation (swap bits 2<->3 of kv within each group of 16) is baked into the Vᵀ
+//     layout that launch_v_transpose writes.  No ds_bpermute / permlane shuffles of P at all.
+//   * K tile (64 kv x 128 d) and Vᵀ tile (128 d x 64 kv) are DMA'd HBM->LDS with
+//     global_load_lds_dwordx4, double buffered (64 KiB LDS), XOR-swizzled through the source
+//     address so the ds_read_b128 operand reads are bank-conflict free.
+//   * Online softmax in the exp2 domain with deferred rescale (skip the O rescale while the row
+//     max grows by < THR; P stays bounded by 2^THR, cdna guide T13).
+#include "common.h"
+
+namespace fmi {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int ATT_THREADS = 512;
+constexpr int ATT_QBLK = 256;  // query rows per workgroup
+constexpr int ATT_KV = 64;     // kv rows per tile
+constexpr int HD = 128;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int THR_X16>  // rescale threshold in 1/16 units of log2 (0 = always rescale)
+__global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t* __restrict Q, const bf16_t* __restrict K,
+                                                                    const bf16_t* __restrict Vt, AttnOut out, int H, int Lq, int Lk,
+                                                                    int Lkpad, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 16384];  // [buf][K 16K | Vt 16K]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.y;
+  const int b = bh / H, h = bh % H;
+  const int q0 = blockIdx.x * ATT_QBLK + wave * 32;
+  const int hl = lane >> 5;   // half of the wave
+  const int l31 = lane & 31;  // query row within the wave / operand row
+
+  const bf16_t* Kb = K + (int64_t)bh * Lk * HD;
+  const bf16_t* Vb = Vt + (int64_t)bh * HD * Lkpad;
+
+  // ---- Q fragments (B operand): lane holds Q[q0+l31][16s + 8hl .. +7], s = 0..7
+  bf16x8_t qf[8];
+  {
+    int qr = q0 + l31;
+    qr = qr > Lq - 1 ? Lq - 1 : qr;
+    const bf16_t* qp = Q + ((int64_t)bh * Lq + qr) * HD + 8 * hl;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * s);
+  }
+
+  f32x16 ot[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  // per-lane LDS read offsets
+  // K tile: row-major [64][128] bf16 (256 B rows), slot c -> c ^ (row & 15)
+  int k_off[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) k_off[s] = l31 * 256 + (((s * 2 + hl) ^ (lane & 15)) << 4);
+  // Vt tile: [128][64] bf16 (128 B rows), slot c -> c ^ ((row>>1)&7)
+  int v_off[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v_off[c] = l31 * 128 + ((c ^ ((l31 >> 1) & 7)) << 4);
+
+  auto stage = [&](int tile, int buf) {
+    char* kd = smem + buf * 32768;
+    char* vd = kd + 16384;
+    const int kv0 = tile * ATT_KV;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int chunk = wave * 2 + i;  // 16 chunks of 4 K rows
+      const int row = chunk * 4 + (lane >> 4);
+      int kr = kv0 + row;
+      kr = kr > Lk - 1 ? Lk - 1 : kr;
+      const bf16_t* src = Kb + (int64_t)kr * HD + (((lane & 15) ^ (row & 15)) << 3);
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(kd + chunk * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int chunk = wave * 2 + i;  // 16 chunks of 8 Vt rows
+      const int row = chunk * 8 + (lane >> 3);
+      const bf16_t* src = Vb + (int64_t)row * Lkpad + kv0 + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(vd + chunk * 1024), 16, 0, 0);
+    }
+  };
+
+  const int ntiles = (Lk + ATT_KV - 1) / ATT_KV;
+  stage(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    __syncthreads();
+    if (t + 1 < ntiles) stage(t + 1, cur ^ 1);
+    const char* kl = smem + cur * 32768;
+    const char* vl = kl + 16384;
+
+    // ---- Sᵀ = K Qᵀ : two 32-kv sub-tiles
+    f32x16 st[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kl + u * 32 * 256 + k_off[s]);
+        st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[u], 0, 0, 0);
+      }
+    }
+    // ---- mask the ragged tail (kv >= Lk); kv_local = 32u + (r&3) + 8(r>>2) + 4hl
+    if ((t + 1) * ATT_KV > Lk) {
+      const int kvb = t * ATT_KV + 4 * hl;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kvb + 32 * u + (r & 3) + 8 * (r >> 2) >= Lk) st[u][r] = -1e30f;
+    }
+    // ---- online softmax (exp2 domain), lane-local row
+    float pmax = st[0][0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pmax = fmaxf(pmax, st[u][r]);
+    pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+    const float ps = pmax * scale_log2e;
+    if (__any(ps - m_run > (float)THR_X16 * 0.0625f)) {
+      const float mn = fmaxf(m_run, ps);
+      const float alpha = fast_exp2(m_run - mn);
+      m_run = mn;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+    }
+    float lsum = 0.f;
+    bf16x8_t pf[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      uint32_t pk[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = fast_exp2(st[u][r] * scale_log2e - m_run);
+        const float p1 = fast_exp2(st[u][r + 1] * scale_log2e - m_run);
+        lsum += p0 + p1;
+        pk[r >> 1] = pack_bf16x2(p0, p1);
+      }
+      uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      uint4 hi = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+      __builtin_memcpy(&pf[2 * u], &lo, 16);
+      __builtin_memcpy(&pf[2 * u + 1], &hi, 16);
+    }
+    l_run += lsum;
+    // ---- Oᵀ += Vᵀ Pᵀ : k-slot (hl,e) of step (u,w) <-> Vt position 32u + 16w + 8hl + e
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {  // c = 2u + w
+        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vl + dt * 32 * 128 + v_off[c * 2 + hl]);
+        ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c], ot[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: O[q][d] = Oᵀ / l ; d = 32dt + (r&3) + 8(r>>2) + 4hl
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < Lq) {
+    bf16_t* op;
+    if (out.head_major)
+      op = out.p1 + ((int64_t)bh * Lq + q) * HD;
+    else if (q < out.rows0)
+      op = out.p0 + (int64_t)b * out.bstride0 + (int64_t)q * out.ld0 + h * HD;
+    else
+      op = out.p1 + (int64_t)b * out.bstride1 + (int64_t)(q - out.rows0) * out.ld1 + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + g * 8 + 4 * hl;
+        const uint2 v = make_uint2(pack_bf16x2(ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv),
+                                   pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv));
+        *reinterpret_cast<uint2*>(op + d) = v;
+      }
+  }
+}
+
+int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
+                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream) {
+  if (Lq <= 0 || Lk <= 0) return fail(FMI_ERR_INVALID, "attention: empty sequence");
+  if (Lkpad % ATT_KV != 0 || Lkpad < Lk) return fail(FMI_ERR_INVALID, "attention: Lkpad must be a multiple of 64 and >= Lk");
+  dim3 grid(cdiv(Lq, ATT_QBLK), B * H);
+  const float sl = scale * 1.4426950408889634f;
+  if (rescale_thr_x16 == 0)
+    hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+  else
+    hipLaunchKernelGGL(attention_kernel<96>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
+int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int H, int Lq, int Lk, int Lkpad,
+                     float scale, int out_token_major, hipStream_t stream) {
+  AttnOut out{};
+  out.p0 = nullptr;
+  out.rows0 = 0;
+  out.p1 = o;
+  out.ld1 = H * HD;
+  out.bstride1 = (int64_t)Lq * H * HD;
+  out.head_major = out_token_major ? 0 : 1;
+  return launch_attention_ex(q, k, vt, out, B, H, Lq, Lk, Lkpad, scale, 96, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// V -> Vᵀ relayout.  vt[(bh*128 + d) * Lpad + pos] = V[b][row(pos) - row_off][h*128 + d] with
+// pos <-> kv: swap bits 2 and 3 of the index inside each group of 16 (see header comment).
+// Grid: (Lpad/64 groups restricted to the touched range, H, B); block 256.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int vt_perm(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict v, int ldv, int64_t v_bstride, bf16_t* __restrict vt,
+                                                          int H, int rows, int row_off, int Lpad, int g0) {
+  __shared__ bf16_t tile[64][HD + 2];
+  const int g = g0 + blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int pos0 = g * 64;
+  // load: 64 positions x 128 d; thread -> (pos = tid>>2, 32 d each)
+  {
+    const int p = tid >> 2, dq = (tid & 3) * 32;
+    const int kv = vt_perm(pos0 + p);  // original kv index stored at this position
+    const int r = kv - row_off;
+    if (r >= 0 && r < rows) {
+      const bf16_t* src = v + (int64_t)b * v_bstride + (int64_t)r * ldv + h * HD + dq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint4 x = *reinterpret_cast<const uint4*>(src + i * 8);
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[p][dq + i * 8 + j] = e[j];
+      }
+    }
+  }
+  __syncthreads();
+  // store: thread -> (d = tid>>1, 32 positions)
+  const int d = tid >> 1, ph = (tid & 1) * 32;
+  bf16_t* dst = vt + ((int64_t)(b * H + h) * HD + d) * Lpad + pos0 + ph;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf16_t e[8];
+    bool all = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int p = ph + i * 8 + j;
+      const int r = vt_perm(pos0 + p) - row_off;
+      const bool ok = (r >= 0 && r < rows);
+      all = all && ok;
+      e[j] = tile[p][d];
+    }
+    if (all) {
+      uint4 x;
+      __builtin_memcpy(&x, e, 16);
+      *reinterpret_cast<uint4*>(dst + i * 8) = x;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = vt_perm(pos0 + ph + i * 8 + j) - row_off;
+        if (r >= 0 && r < rows) dst[i * 8 + j] = e[j];
+      }
+    }
+  }
+}
+
+int launch_v_transpose(const bf16_t* v, int ldv, int64_t v_bstride, bf16_t* vt, int B, int H, int rows, int row_off, int Lpad,
+                       hipStream_t stream) {
+  if (rows <= 0) return FMI_OK;
+  if (ldv % 8) return fail(FMI_ERR_INVALID, "v_transpose: ldv must be a multiple of 8");
+  const int g0 = row_off / 64, g1 = (row_off + rows - 1) / 64;
+  hipLaunchKernelGGL(v_transpose_kernel, dim3(g1 - g0 + 1, H, B), dim3(256), 0, stream, v, ldv, v_bstride, vt, H, rows, row_off, Lpad, g0);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
+__global__ void vt_zero_pad_kernel(bf16_t* vt, int L, int Lpad) {
+  const int row = blockIdx.x;  // bh*128 + d
+  for (int p = L + threadIdx.x; p < Lpad; p += blockDim.x) {
+    // positions whose ORIGINAL kv index is >= L must be zero
+    vt[(int64_t)row * Lpad + p] = 0;
+  }
+}
+// Zero every position of the last (partial) 64-group whose source kv index is >= L.
+__global__ void vt_zero_tail_kernel(bf16_t* vt, int L, int Lpad) {
+  const int row = blockIdx.x;
+  const int p0 = (L / 16) * 16;
+  for (int p = p0 + threadIdx.x; p < Lpad; p += blockDim.x)
+    if (vt_perm(p) >= L) vt[(int64_t)row * Lpad + p] = 0;
+}
+int launch_vt_zero_pad(bf16_t* vt, int BH, int L, int Lpad, hipStream_t stream) {
+  if (Lpad == L) return FMI_OK;
+  hipLaunchKernelGGL(vt_zero_tail_kernel, dim3(BH * HD), dim3(64), 0, stream, vt, L, Lpad);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
+}  // namespace fmi

@@ -1,0 +1,176 @@
+// common.h — shared device/host helpers for libflux_mi355x (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/flux_mi355x.h"
+
+namespace fmi {
+
+// ---------------------------------------------------------------- error channel
+void set_error(const std::string& msg);
+int fail(fmi_status st, const std::string& msg);
+#define FMI_HIP_TRY(expr)                                                                       \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return ::fmi::fail(FMI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + \
+                                          __FILE__ + ":" + std::to_string(__LINE__));           \
+  } while (0)
+#define FMI_TRY(expr)        \
+  do {                       \
+    int _rc = (expr);        \
+    if (_rc != FMI_OK) return _rc; \
+  } while (0)
+#define FMI_LAUNCH_CHECK() FMI_HIP_TRY(hipGetLastError())
+
+// ---------------------------------------------------------------- bf16 helpers (device)
+typedef uint16_t bf16_t;  // raw bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserved (same rule as half::bf16::from_f32)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float f16_to_f32(uint16_t h) {
+  _Float16 v;
+  __builtin_memcpy(&v, &h, 2);
+  return (float)v;
+}
+__device__ __forceinline__ uint16_t f32_to_f16(float f) {
+  _Float16 v = (_Float16)f;  // v_cvt_f16_f32: RNE
+  uint16_t h;
+  __builtin_memcpy(&h, &v, 2);
+  return h;
+}
+
+// GELU tanh approximation (core/op.rs:539-582, f32 arm) and SiLU (op.rs:699-721)
+__device__ __forceinline__ float gelu_tanh(float v) {
+  const float k = 0.79788456080286535587989211986876373f;
+  float u = k * v * (1.0f + 0.044715f * v * v);
+  // tanh(u) = 1 - 2/(exp(2u)+1); saturates cleanly for large |u|
+  float e = __expf(2.0f * u);
+  float t = 1.0f - 2.0f / (e + 1.0f);
+  return 0.5f * v * (1.0f + t);
+}
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs (MFMA A/B operand)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+constexpr int NUM_XCD = 8;
+// Bijective XCD-aware remap: consecutive logical tiles land on the same XCD (= same L2).
+// (block b is dispatched to XCD b % 8; cdna guide T1 "XCD swizzle must be bijective")
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  int xcd = bid % NUM_XCD, idx = bid / NUM_XCD;
+  int q = nwg / NUM_XCD, r = nwg % NUM_XCD;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- kernel launchers (host)
+// GEMM problem: y = epi(x W^T + bias).  All leading dims in elements.
+enum GemmEpi : int {
+  EPI_STORE_BF16 = 0,      // out bf16 = acc + bias
+  EPI_GELU_BF16 = 1,       // out bf16 = gelu(acc + bias)
+  EPI_RESID_GATE_F32 = 2,  // resid f32 (in/out) += gate[n] * (acc + bias)
+  EPI_GELU_FROM_COL = 3,   // out bf16 = (n >= gelu_from ? gelu : id)(acc + bias)
+  EPI_STORE_F32 = 4,       // out f32 = acc*alpha + bias
+  EPI_SCALE_BF16 = 5,      // out bf16 = acc*alpha + bias
+  EPI_RESID_ADD_BF16 = 6,  // out bf16 = resid_bf16 + acc + bias   (VAE)
+  EPI_SILU_BF16 = 7
+};
+struct GemmProblem {
+  const bf16_t* A;  // (M, K) activations, row stride lda
+  const bf16_t* W;  // (N, K) weights, row stride ldw
+  const bf16_t* bias;  // (N) bf16 or null
+  void* out;        // bf16 or f32 (M, N), row stride ldo
+  const float* gate;  // (N) f32 for EPI_RESID_GATE_F32 (per batch: gate + batch*gate_bstride)
+  const void* resid;  // bf16 residual for EPI_RESID_ADD_BF16
+  int M, N, K;
+  int lda, ldw, ldo;
+  int epi;
+  int gelu_from;
+  float alpha;
+  int rows_per_batch;  // for per-batch gate vectors: batch = m / rows_per_batch (0 = single)
+  int gate_bstride;
+  // 4-bit weights (optional): W is ignored, Wq packed u8 (N, K/2), absmax (N*K/blocksize)
+  const uint8_t* Wq;
+  const float* absmax;
+  int q_blocksize;
+  int q_type;  // 0 none, 1 fp4, 2 nf4
+  // implicit-GEMM convolution (optional, cv_ks != 0): A is an NHWC image (B, cv_h, cv_w, cv_cin),
+  // M = B * (cv_h<<cv_up) * (cv_w<<cv_up) output pixels, K = cv_ks^2 * cv_cin with k = (tap, cin),
+  // W is (N, cv_ks, cv_ks, cv_cin); cv_up = 1 folds a nearest-2x upsample into the gather.
+  int cv_ks, cv_h, cv_w, cv_cin, cv_up;
+  const bf16_t* cv_zero;  // >= 128 B of zeros for padding taps
+};
+int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream);
+
+// attention output routing: query rows [0,rows0) -> p0, the rest -> p1 (token-major, head h at
+// column h*128); or head-major (B,H,Lq,128) in p1.
+struct AttnOut {
+  bf16_t* p0;
+  int rows0;
+  int ld0;
+  int64_t bstride0;
+  bf16_t* p1;
+  int ld1;
+  int64_t bstride1;
+  int head_major;
+};
+int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
+                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream);
+// flash attention, d = 128.  q,k: (BH, L, 128) bf16; vt: (BH, 128, Lpad) bf16 with the kv axis
+// permuted inside each group of 16 (see attention.hip); out token-major (B, L, H*128) or (BH,L,128)
+int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int H,
+                     int Lq, int Lk, int Lkpad, float scale, int out_token_major, hipStream_t stream);
+// (rows, 128)-per-head V -> V^T layout consumed by launch_attention.  v: token-major with row
+// stride ldv (elements) and head h at column h*128; rows [0,rows) of batch b land at kv = row_off+r
+int launch_v_transpose(const bf16_t* v, int ldv, int64_t v_bstride, bf16_t* vt, int B, int H, int rows,
+                       int row_off, int Lpad, hipStream_t stream);
+int launch_vt_zero_pad(bf16_t* vt, int BH, int L, int Lpad, hipStream_t stream);
+// q/k RMSNorm (eps 1e-6, weight (128)) + RoPE, token-major in (row stride ld, head h at col h*128)
+// -> head-major (B,H,Ltot,128) at row offset row_off.  pe: (B or 1, Ltot, 64, 2) f32 {cos,sin}
+int launch_qk_norm_rope(const bf16_t* q, const bf16_t* k, int ld, int64_t in_bstride, const bf16_t* wq,
+                        const bf16_t* wk, const float* pe, int64_t pe_bstride, bf16_t* qo, bf16_t* ko,
+                        int B, int H, int rows, int row_off, int Ltot, hipStream_t stream);
+int launch_rope_table(const float* txt_ids, const float* img_ids, int B, int T, int S, const int* axes,
+                      int theta, float* pe, hipStream_t stream);
+// LayerNorm(no affine) * (1+scale) + shift; x f32 (rows, D) -> bf16. scale/shift per batch
+// (vector + batch*mod_bstride), batch = row / rows_per_batch.
+int launch_layernorm_mod(const float* x, const float* scale, const float* shift, int mod_bstride,
+                         int rows_per_batch, bf16_t* out, int rows, int D, float eps, hipStream_t stream);
+// y(M,N) f32 (+)= act_in(x(M,K) f32) W(N,K)^T bf16 + bias bf16 ; M <= 8
+int launch_gemv(const float* x, const bf16_t* W, const bf16_t* bias, float* y, int M, int N, int K,
+                int silu_in, int accumulate, hipStream_t stream);
+int launch_timestep_embedding(const float* t, int B, int dim, float* out, hipStream_t stream);
+int launch_cast_to_bf16(const void* src, fmi_dtype dt, bf16_t* dst, int64_t n, hipStream_t stream);
+int launch_cast_to_f32(const void* src, fmi_dtype dt, float* dst, int64_t n, hipStream_t stream);
+int launch_euler_update(float* img, const float* pred, float dt, int64_t n, hipStream_t stream);
+int launch_split_rows_f32(const float* src, float* dst, int B, int rows_src_per_b, int row_off, int rows, int D, hipStream_t stream);
+
+}  // namespace fmi

@@ -1,0 +1,772 @@
+// flux_model.hip — host side of the FLUX DiT: weight arena, diffusers-name resolution, and the
+// kernel schedule of Flux::forward (diffusion_rs_core/src/models/flux/model.rs:790-833) and
+// Sampler::sample (pipelines/sampling.rs:25-48).
+//
+// Memory plan (MI355X, 288 GB HBM3E): one bf16 weight arena (23.8 GB for FLUX.1) holding FUSED
+// matrices — [q|k|v] per stream of a double block, [q|k|v|proj_mlp] per single block, and ONE
+// (344*D, D) matrix with every modulation linear of the model so all AdaLN vectors of a step
+// come from a single weight-streaming GEMV.  Activations live in a per-(B,S,T) workspace that is
+// allocated once and reused by every step; nothing is allocated inside a step.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "common.h"
+
+using namespace fmi;
+
+namespace {
+
+struct Dense {  // one (possibly fused) Linear: W (N,K) bf16 row-major, bias (N) bf16
+  bf16_t* w = nullptr;
+  bf16_t* b = nullptr;
+  int N = 0, K = 0;
+  // optional 4-bit form (bitsandbytes nf4/fp4), replaces w
+  uint8_t* wq = nullptr;
+  float* absmax = nullptr;
+  int q_type = 0, q_blocksize = 0;
+};
+
+struct Dest {  // where a named tensor lands
+  void* ptr;
+  int64_t numel;
+  int rows, cols;  // expected shape (cols == 0 -> 1-D of `rows`)
+};
+
+enum Phase { PH_EMBED = 0, PH_MOD, PH_LN, PH_GEMM_QKV, PH_RELAYOUT, PH_ATTN, PH_GEMM_PROJ, PH_GEMM_MLP, PH_FINAL, PH_COUNT };
+const char* kPhaseNames[PH_COUNT] = {"embed", "modulation_gemv", "layernorm_mod", "gemm_qkv", "qk_norm_rope_vT", "attention",
+                                     "gemm_proj", "gemm_mlp", "final_layer"};
+
+}  // namespace
+
+struct fmi_flux {
+  fmi_flux_config cfg;
+  int D, M, H;
+  // arena
+  char* arena = nullptr;
+  size_t arena_bytes = 0, arena_used = 0;
+  // weights
+  Dense img_in, txt_in, time1, time2, guid1, guid2, vecin1, vecin2, final_proj;
+  Dense mod_all;  // (n_mod, D)
+  struct DoubleW {
+    Dense qkv[2], proj[2], mlp1[2], mlp2[2];  // [0]=img, [1]=txt
+    bf16_t* nq[2];
+    bf16_t* nk[2];
+    int64_t mod_off[2];
+  };
+  struct SingleW {
+    Dense w1, w2;
+    bf16_t* nq;
+    bf16_t* nk;
+    int64_t mod_off;
+  };
+  std::vector<DoubleW> dbl;
+  std::vector<SingleW> sgl;
+  int64_t mod_final_off = 0, n_mod = 0;
+  std::map<std::string, Dest> names;
+  std::set<std::string> missing;
+  std::vector<std::string> missing_list;  // materialised for the C accessor
+  // workspace
+  struct WS {
+    int B = 0, S = 0, T = 0;
+    char* base = nullptr;
+    size_t bytes = 0;
+    float *x_img, *x_txt, *x, *vec, *mod, *temb, *h1, *yf, *pe, *img_f32, *pred_tmp, *tv;
+    bf16_t *img_bf, *txt_bf, *xm, *qkv_img, *qkv_txt, *big, *Qh, *Kh, *Vt, *attn_img, *attn_txt, *hid;
+    int Lpad = 0;
+  } ws;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float phase_ms[PH_COUNT] = {0};
+  int attn_thr = 96;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T>
+T* arena_take(fmi_flux* m, size_t count) {
+  size_t off = align_up(m->arena_used, 256);
+  m->arena_used = off + count * sizeof(T);
+  return reinterpret_cast<T*>(m->arena + off);
+}
+
+// two passes: pass 0 counts bytes (arena == nullptr), pass 1 hands out pointers
+void layout_dense(fmi_flux* m, Dense& d, int N, int K, bool bias = true) {
+  d.N = N;
+  d.K = K;
+  d.w = arena_take<bf16_t>(m, (size_t)N * K);
+  d.b = bias ? arena_take<bf16_t>(m, (size_t)N) : nullptr;
+}
+
+void reg(fmi_flux* m, const std::string& name, void* ptr, int rows, int cols) {
+  Dest d{ptr, (int64_t)rows * (cols ? cols : 1), rows, cols};
+  m->names[name] = d;
+  m->missing.insert(name);
+}
+// register W/bias of a Linear that occupies rows [r0, r0+rows) of a fused Dense
+void reg_lin(fmi_flux* m, const std::string& prefix, Dense& d, int r0, int rows) {
+  reg(m, prefix + ".weight", d.w + (size_t)r0 * d.K, rows, d.K);
+  if (d.b) reg(m, prefix + ".bias", d.b + r0, rows, 0);
+}
+
+void build_layout(fmi_flux* m) {
+  const fmi_flux_config& c = m->cfg;
+  const int D = m->D, M = m->M;
+  m->arena_used = 0;
+  m->names.clear();
+  m->missing.clear();
+  layout_dense(m, m->img_in, D, c.in_channels);
+  layout_dense(m, m->txt_in, D, c.joint_attention_dim);
+  layout_dense(m, m->time1, D, 256);
+  layout_dense(m, m->time2, D, D);
+  if (c.guidance_embeds) {
+    layout_dense(m, m->guid1, D, 256);
+    layout_dense(m, m->guid2, D, D);
+  }
+  layout_dense(m, m->vecin1, D, c.pooled_projection_dim);
+  layout_dense(m, m->vecin2, D, D);
+  layout_dense(m, m->final_proj, c.in_channels, D);
+  m->n_mod = (int64_t)c.num_layers * 12 * D + (int64_t)c.num_single_layers * 3 * D + 2 * D;
+  layout_dense(m, m->mod_all, (int)m->n_mod, D);
+  m->dbl.resize(c.num_layers);
+  m->sgl.resize(c.num_single_layers);
+  int64_t moff = 0;
+  for (int i = 0; i < c.num_layers; ++i) {
+    auto& b = m->dbl[i];
+    for (int s = 0; s < 2; ++s) {
+      layout_dense(m, b.qkv[s], 3 * D, D);
+      layout_dense(m, b.proj[s], D, D);
+      layout_dense(m, b.mlp1[s], M, D);
+      layout_dense(m, b.mlp2[s], D, M);
+      b.nq[s] = arena_take<bf16_t>(m, 128);
+      b.nk[s] = arena_take<bf16_t>(m, 128);
+      b.mod_off[s] = moff;
+      moff += 6 * D;
+    }
+  }
+  for (int i = 0; i < c.num_single_layers; ++i) {
+    auto& b = m->sgl[i];
+    layout_dense(m, b.w1, 3 * D + M, D);
+    layout_dense(m, b.w2, D, D + M);
+    b.nq = arena_take<bf16_t>(m, 128);
+    b.nk = arena_take<bf16_t>(m, 128);
+    b.mod_off = moff;
+    moff += 3 * D;
+  }
+  m->mod_final_off = moff;
+
+  if (!m->arena) return;  // counting pass
+  // ---- names (diffusers names looked up by Flux::new, model.rs:165-772)
+  reg_lin(m, "x_embedder", m->img_in, 0, D);
+  reg_lin(m, "context_embedder", m->txt_in, 0, D);
+  reg_lin(m, "time_text_embed.timestep_embedder.linear_1", m->time1, 0, D);
+  reg_lin(m, "time_text_embed.timestep_embedder.linear_2", m->time2, 0, D);
+  if (c.guidance_embeds) {
+    reg_lin(m, "time_text_embed.guidance_embedder.linear_1", m->guid1, 0, D);
+    reg_lin(m, "time_text_embed.guidance_embedder.linear_2", m->guid2, 0, D);
+  }
+  reg_lin(m, "time_text_embed.text_embedder.linear_1", m->vecin1, 0, D);
+  reg_lin(m, "time_text_embed.text_embedder.linear_2", m->vecin2, 0, D);
+  reg_lin(m, "proj_out", m->final_proj, 0, c.in_channels);
+  reg_lin(m, "norm_out.linear", m->mod_all, (int)m->mod_final_off, 2 * D);
+  for (int i = 0; i < c.num_layers; ++i) {
+    auto& b = m->dbl[i];
+    const std::string p = "transformer_blocks." + std::to_string(i) + ".";
+    reg_lin(m, p + "norm1.linear", m->mod_all, (int)b.mod_off[0], 6 * D);
+    reg_lin(m, p + "norm1_context.linear", m->mod_all, (int)b.mod_off[1], 6 * D);
+    const char* qn[2][3] = {{"attn.to_q", "attn.to_k", "attn.to_v"}, {"attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj"}};
+    const char* on[2] = {"attn.to_out.0", "attn.to_add_out"};
+    const char* nqn[2] = {"attn.norm_q.weight", "attn.norm_added_q.weight"};
+    const char* nkn[2] = {"attn.norm_k.weight", "attn.norm_added_k.weight"};
+    const char* f1[2] = {"ff.net.0.proj", "ff_context.net.0.proj"};
+    const char* f2[2] = {"ff.net.2", "ff_context.net.2"};
+    for (int s = 0; s < 2; ++s) {
+      for (int j = 0; j < 3; ++j) reg_lin(m, p + qn[s][j], b.qkv[s], j * D, D);
+      reg_lin(m, p + on[s], b.proj[s], 0, D);
+      reg(m, p + nqn[s], b.nq[s], 128, 0);
+      reg(m, p + nkn[s], b.nk[s], 128, 0);
+      reg_lin(m, p + f1[s], b.mlp1[s], 0, M);
+      reg_lin(m, p + f2[s], b.mlp2[s], 0, D);
+    }
+  }
+  for (int i = 0; i < c.num_single_layers; ++i) {
+    auto& b = m->sgl[i];
+    const std::string p = "single_transformer_blocks." + std::to_string(i) + ".";
+    reg_lin(m, p + "norm.linear", m->mod_all, (int)b.mod_off, 3 * D);
+    reg_lin(m, p + "attn.to_q", b.w1, 0, D);
+    reg_lin(m, p + "attn.to_k", b.w1, D, D);
+    reg_lin(m, p + "attn.to_v", b.w1, 2 * D, D);
+    reg_lin(m, p + "proj_mlp", b.w1, 3 * D, M);
+    reg(m, p + "attn.norm_q.weight", b.nq, 128, 0);
+    reg(m, p + "attn.norm_k.weight", b.nk, 128, 0);
+    reg_lin(m, p + "proj_out", b.w2, 0, D);
+  }
+}
+
+int ensure_workspace(fmi_flux* m, int B, int S, int T) {
+  auto& w = m->ws;
+  if (w.base && w.B == B && w.S == S && w.T == T) return FMI_OK;
+  const int D = m->D, M = m->M, H = m->H, L = S + T;
+  const int Lpad = (L + 63) / 64 * 64;
+  const int C = m->cfg.in_channels, J = m->cfg.joint_attention_dim, P = m->cfg.pooled_projection_dim;
+  const int ldbig = 3 * D + M;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    off = align_up(off, 256);
+    size_t o = off;
+    off += bytes;
+    return o;
+  };
+  struct Item {
+    void** p;
+    size_t bytes;
+    size_t o;
+  };
+  std::vector<Item> items;
+  auto add = [&](void** p, size_t bytes) { items.push_back({p, bytes, take(bytes)}); };
+  add((void**)&w.x_img, (size_t)B * S * D * 4);
+  add((void**)&w.x_txt, (size_t)B * T * D * 4);
+  add((void**)&w.x, (size_t)B * L * D * 4);
+  add((void**)&w.vec, (size_t)B * D * 4);
+  add((void**)&w.mod, (size_t)B * m->n_mod * 4);
+  add((void**)&w.temb, (size_t)B * 256 * 4);
+  add((void**)&w.h1, (size_t)B * D * 4);
+  add((void**)&w.yf, (size_t)B * P * 4);
+  add((void**)&w.pe, (size_t)B * L * 64 * 2 * 4);
+  add((void**)&w.img_f32, (size_t)B * S * C * 4);
+  add((void**)&w.pred_tmp, (size_t)B * S * C * 4);
+  add((void**)&w.tv, 4096 * 4);
+  add((void**)&w.img_bf, (size_t)B * S * C * 2);
+  add((void**)&w.txt_bf, (size_t)B * T * J * 2);
+  add((void**)&w.xm, (size_t)B * L * D * 2);
+  add((void**)&w.qkv_img, (size_t)B * S * 3 * D * 2);
+  add((void**)&w.qkv_txt, (size_t)B * T * 3 * D * 2);
+  add((void**)&w.big, (size_t)B * L * ldbig * 2);
+  add((void**)&w.Qh, (size_t)B * H * L * 128 * 2);
+  add((void**)&w.Kh, (size_t)B * H * L * 128 * 2);
+  add((void**)&w.Vt, (size_t)B * H * 128 * Lpad * 2);
+  add((void**)&w.attn_img, (size_t)B * S * D * 2);
+  add((void**)&w.attn_txt, (size_t)B * T * D * 2);
+  add((void**)&w.hid, (size_t)B * L * M * 2);
+  const size_t total = align_up(off, 256);
+  if (w.base) {
+    FMI_HIP_TRY(hipDeviceSynchronize());
+    FMI_HIP_TRY(hipFree(w.base));
+    w.base = nullptr;
+  }
+  FMI_HIP_TRY(hipMalloc((void**)&w.base, total));
+  FMI_HIP_TRY(hipMemset(w.base, 0, total));  // also zeroes the Vt pad columns once
+  for (auto& it : items) *it.p = w.base + it.o;
+  w.bytes = total;
+  w.B = B, w.S = S, w.T = T, w.Lpad = Lpad;
+  return FMI_OK;
+}
+
+GemmProblem make_problem(const Dense& d, const bf16_t* A, int lda, int Mrows, void* out, int ldo, int epi) {
+  GemmProblem p{};
+  p.A = A;
+  p.W = d.w;
+  p.bias = d.b;
+  p.out = out;
+  p.M = Mrows;
+  p.N = d.N;
+  p.K = d.K;
+  p.lda = lda;
+  p.ldw = d.K;
+  p.ldo = ldo;
+  p.epi = epi;
+  p.alpha = 1.0f;
+  if (d.q_type) {
+    p.Wq = d.wq;
+    p.absmax = d.absmax;
+    p.q_type = d.q_type;
+    p.q_blocksize = d.q_blocksize;
+  }
+  return p;
+}
+void with_gate(GemmProblem& p, const float* gate, int rows_per_batch, int bstride) {
+  p.gate = gate;
+  p.rows_per_batch = rows_per_batch;
+  p.gate_bstride = bstride;
+}
+// launch 1 or 2 problems; quantised and dense problems cannot share a grid
+int gemm2(GemmProblem* p, int n, hipStream_t s) {
+  if (n == 2 && (p[0].q_type != 0) != (p[1].q_type != 0)) {
+    FMI_TRY(launch_gemm(p, 1, s));
+    return launch_gemm(p + 1, 1, s);
+  }
+  return launch_gemm(p, n, s);
+}
+
+struct PhaseTimer {
+  fmi_flux* m;
+  hipStream_t s;
+  int ph;
+  PhaseTimer(fmi_flux* m_, hipStream_t s_, int ph_) : m(m_), s(s_), ph(ph_) {
+    if (m->profiling) hipEventRecord(m->ev0, s);
+  }
+  ~PhaseTimer() {
+    if (m->profiling) {
+      hipEventRecord(m->ev1, s);
+      hipEventSynchronize(m->ev1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, m->ev0, m->ev1);
+      m->phase_ms[ph] += ms;
+    }
+  }
+};
+
+int check_ready(fmi_flux* m) {
+  if (!m->missing.empty())
+    return fail(FMI_ERR_STATE, "flux: " + std::to_string(m->missing.size()) + " tensors not set, first: " + *m->missing.begin());
+  return FMI_OK;
+}
+
+// Everything of Flux::forward that does not depend on the timestep: input casts + RoPE table.
+int prepare_static(fmi_flux* m, const fmi_flux_inputs* in, hipStream_t s) {
+  auto& w = m->ws;
+  const int B = in->B, S = in->S, T = in->T;
+  PhaseTimer pt(m, s, PH_EMBED);
+  FMI_TRY(launch_cast_to_bf16(in->txt, in->txt_dtype, w.txt_bf, (int64_t)B * T * m->cfg.joint_attention_dim, s));
+  FMI_TRY(launch_cast_to_f32(in->y, in->y_dtype, w.yf, (int64_t)B * m->cfg.pooled_projection_dim, s));
+  // pe = EmbedNd(cat([txt_ids, img_ids], 1)) (model.rs:807-810); one table per batch element
+  FMI_TRY(launch_rope_table(in->txt_ids, in->img_ids, in->ids_per_sample ? B : 1, T, S, m->cfg.axes_dim, m->cfg.theta, w.pe, s));
+  return FMI_OK;
+}
+
+// One model evaluation given prepared static inputs; img_f32 (B,S,C) -> pred (B,S,C) f32.
+int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, const float* timesteps_dev, float* pred, hipStream_t s) {
+  auto& w = m->ws;
+  const fmi_flux_config& c = m->cfg;
+  const int B = in->B, S = in->S, T = in->T, L = S + T;
+  const int D = m->D, Mh = m->M, H = m->H, C = c.in_channels;
+  const int nmod = (int)m->n_mod;
+  const int64_t pe_bs = in->ids_per_sample ? (int64_t)L * 128 : 0;
+  const float att_scale = 1.0f / sqrtf(128.0f);
+
+  {
+    PhaseTimer pt(m, s, PH_EMBED);
+    FMI_TRY(launch_cast_to_bf16(img_f32, FMI_F32, w.img_bf, (int64_t)B * S * C, s));
+    // vec_ = time_in(temb(t)) [+ guidance_in(temb(g))] + vector_in(y)   (model.rs:813-820)
+    FMI_TRY(launch_timestep_embedding(timesteps_dev, B, 256, w.temb, s));
+    FMI_TRY(launch_gemv(w.temb, m->time1.w, m->time1.b, w.h1, B, D, 256, 0, 0, s));
+    FMI_TRY(launch_gemv(w.h1, m->time2.w, m->time2.b, w.vec, B, D, D, 1, 0, s));
+    if (c.guidance_embeds) {
+      if (!in->guidance) return fail(FMI_ERR_INVALID, "flux: guidance_embeds model needs a guidance vector");
+      FMI_TRY(launch_timestep_embedding(in->guidance, B, 256, w.temb, s));
+      FMI_TRY(launch_gemv(w.temb, m->guid1.w, m->guid1.b, w.h1, B, D, 256, 0, 0, s));
+      FMI_TRY(launch_gemv(w.h1, m->guid2.w, m->guid2.b, w.vec, B, D, D, 1, 1, s));
+    }
+    FMI_TRY(launch_gemv(w.yf, m->vecin1.w, m->vecin1.b, w.h1, B, D, c.pooled_projection_dim, 0, 0, s));
+    FMI_TRY(launch_gemv(w.h1, m->vecin2.w, m->vecin2.b, w.vec, B, D, D, 1, 1, s));
+    // img = img_in(img), txt = txt_in(txt)   (model.rs:811-812) -> f32 residual streams
+    GemmProblem p[2];
+    p[0] = make_problem(m->img_in, w.img_bf, C, B * S, w.x_img, D, EPI_STORE_F32);
+    p[1] = make_problem(m->txt_in, w.txt_bf, c.joint_attention_dim, B * T, w.x_txt, D, EPI_STORE_F32);
+    FMI_TRY(gemm2(p, 2, s));
+  }
+  {
+    // every Modulation1/2 + LastLayer.ada_ln of the model in one GEMV: lin(silu(vec)) (model.rs:244-299,695-698)
+    PhaseTimer pt(m, s, PH_MOD);
+    FMI_TRY(launch_gemv(w.vec, m->mod_all.w, m->mod_all.b, w.mod, B, nmod, D, 1, 0, s));
+  }
+
+  // ---------------- double-stream blocks (model.rs:523-565)
+  for (int i = 0; i < c.num_layers; ++i) {
+    auto& bw = m->dbl[i];
+    const float* mi = w.mod + bw.mod_off[0];  // shift1, scale1, gate1, shift2, scale2, gate2
+    const float* mt = w.mod + bw.mod_off[1];
+    bf16_t* xm_txt = w.xm;
+    bf16_t* xm_img = w.xm + (size_t)B * T * D;
+    {
+      PhaseTimer pt(m, s, PH_LN);
+      FMI_TRY(launch_layernorm_mod(w.x_img, mi + D, mi, nmod, S, xm_img, B * S, D, 1e-6f, s));
+      FMI_TRY(launch_layernorm_mod(w.x_txt, mt + D, mt, nmod, T, xm_txt, B * T, D, 1e-6f, s));
+    }
+    {
+      PhaseTimer pt(m, s, PH_GEMM_QKV);
+      GemmProblem p[2];
+      p[0] = make_problem(bw.qkv[0], xm_img, D, B * S, w.qkv_img, 3 * D, EPI_STORE_BF16);
+      p[1] = make_problem(bw.qkv[1], xm_txt, D, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16);
+      FMI_TRY(gemm2(p, 2, s));
+    }
+    {
+      PhaseTimer pt(m, s, PH_RELAYOUT);
+      // q,k: QkNorm + rope + head-major, joint order [txt, img] (model.rs:540-542)
+      FMI_TRY(launch_qk_norm_rope(w.qkv_txt, w.qkv_txt + D, 3 * D, (int64_t)T * 3 * D, bw.nq[1], bw.nk[1], w.pe, pe_bs, w.Qh, w.Kh, B, H, T, 0, L, s));
+      FMI_TRY(launch_qk_norm_rope(w.qkv_img, w.qkv_img + D, 3 * D, (int64_t)S * 3 * D, bw.nq[0], bw.nk[0], w.pe, pe_bs, w.Qh, w.Kh, B, H, S, T, L, s));
+      FMI_TRY(launch_v_transpose(w.qkv_txt + 2 * D, 3 * D, (int64_t)T * 3 * D, w.Vt, B, H, T, 0, w.Lpad, s));
+      FMI_TRY(launch_v_transpose(w.qkv_img + 2 * D, 3 * D, (int64_t)S * 3 * D, w.Vt, B, H, S, T, w.Lpad, s));
+    }
+    {
+      PhaseTimer pt(m, s, PH_ATTN);
+      AttnOut o{};
+      o.p0 = w.attn_txt, o.rows0 = T, o.ld0 = D, o.bstride0 = (int64_t)T * D;
+      o.p1 = w.attn_img, o.ld1 = D, o.bstride1 = (int64_t)S * D;
+      FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, att_scale, m->attn_thr, s));
+    }
+    {
+      PhaseTimer pt(m, s, PH_GEMM_PROJ);
+      GemmProblem p[2];
+      p[0] = make_problem(bw.proj[0], w.attn_img, D, B * S, w.x_img, D, EPI_RESID_GATE_F32);
+      with_gate(p[0], mi + 2 * D, S, nmod);
+      p[1] = make_problem(bw.proj[1], w.attn_txt, D, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
+      with_gate(p[1], mt + 2 * D, T, nmod);
+      FMI_TRY(gemm2(p, 2, s));
+    }
+    {
+      PhaseTimer pt(m, s, PH_LN);
+      FMI_TRY(launch_layernorm_mod(w.x_img, mi + 4 * D, mi + 3 * D, nmod, S, xm_img, B * S, D, 1e-6f, s));
+      FMI_TRY(launch_layernorm_mod(w.x_txt, mt + 4 * D, mt + 3 * D, nmod, T, xm_txt, B * T, D, 1e-6f, s));
+    }
+    {
+      PhaseTimer pt(m, s, PH_GEMM_MLP);
+      bf16_t* hid_txt = w.hid;
+      bf16_t* hid_img = w.hid + (size_t)B * T * Mh;
+      GemmProblem p[2];
+      p[0] = make_problem(bw.mlp1[0], xm_img, D, B * S, hid_img, Mh, EPI_GELU_BF16);
+      p[1] = make_problem(bw.mlp1[1], xm_txt, D, B * T, hid_txt, Mh, EPI_GELU_BF16);
+      FMI_TRY(gemm2(p, 2, s));
+      p[0] = make_problem(bw.mlp2[0], hid_img, Mh, B * S, w.x_img, D, EPI_RESID_GATE_F32);
+      with_gate(p[0], mi + 5 * D, S, nmod);
+      p[1] = make_problem(bw.mlp2[1], hid_txt, Mh, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
+      with_gate(p[1], mt + 5 * D, T, nmod);
+      FMI_TRY(gemm2(p, 2, s));
+    }
+  }
+
+  // ---------------- cat([txt, img], 1) (model.rs:827) then single-stream blocks (model.rs:638-662)
+  for (int b = 0; b < B; ++b) {
+    FMI_HIP_TRY(hipMemcpyAsync(w.x + (size_t)b * L * D, w.x_txt + (size_t)b * T * D, (size_t)T * D * 4, hipMemcpyDeviceToDevice, s));
+    FMI_HIP_TRY(hipMemcpyAsync(w.x + ((size_t)b * L + T) * D, w.x_img + (size_t)b * S * D, (size_t)S * D * 4, hipMemcpyDeviceToDevice, s));
+  }
+  const int ldbig = 3 * D + Mh;
+  for (int i = 0; i < c.num_single_layers; ++i) {
+    auto& bw = m->sgl[i];
+    const float* mo = w.mod + bw.mod_off;  // shift, scale, gate
+    {
+      PhaseTimer pt(m, s, PH_LN);
+      FMI_TRY(launch_layernorm_mod(w.x, mo + D, mo, nmod, L, w.xm, B * L, D, 1e-6f, s));
+    }
+    {
+      PhaseTimer pt(m, s, PH_GEMM_QKV);
+      // [q|k|v|gelu(proj_mlp)] in one GEMM; the concat of model.rs:660 is never materialised
+      GemmProblem p = make_problem(bw.w1, w.xm, D, B * L, w.big, ldbig, EPI_GELU_FROM_COL);
+      p.gelu_from = 3 * D;
+      FMI_TRY(launch_gemm(&p, 1, s));
+    }
+    {
+      PhaseTimer pt(m, s, PH_RELAYOUT);
+      FMI_TRY(launch_qk_norm_rope(w.big, w.big + D, ldbig, (int64_t)L * ldbig, bw.nq, bw.nk, w.pe, pe_bs, w.Qh, w.Kh, B, H, L, 0, L, s));
+      FMI_TRY(launch_v_transpose(w.big + 2 * D, ldbig, (int64_t)L * ldbig, w.Vt, B, H, L, 0, w.Lpad, s));
+    }
+    {
+      PhaseTimer pt(m, s, PH_ATTN);
+      // attention output overwrites the (now consumed) v slot, right in front of gelu(mlp):
+      // big[:, 2D : 3D+M] is exactly cat([attn, gelu(mlp)], -1)
+      AttnOut o{};
+      o.p0 = nullptr, o.rows0 = 0;
+      o.p1 = w.big + 2 * D, o.ld1 = ldbig, o.bstride1 = (int64_t)L * ldbig;
+      FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, att_scale, m->attn_thr, s));
+    }
+    {
+      PhaseTimer pt(m, s, PH_GEMM_PROJ);
+      GemmProblem p = make_problem(bw.w2, w.big + 2 * D, ldbig, B * L, w.x, D, EPI_RESID_GATE_F32);
+      with_gate(p, mo + 2 * D, L, nmod);
+      FMI_TRY(launch_gemm(&p, 1, s));
+    }
+  }
+
+  // ---------------- img = img[:, T:] ; LastLayer (model.rs:694-705): chunks = (scale, shift)
+  {
+    PhaseTimer pt(m, s, PH_FINAL);
+    const float* mf = w.mod + m->mod_final_off;
+    for (int b = 0; b < B; ++b)
+      FMI_TRY(launch_layernorm_mod(w.x + ((size_t)b * L + T) * D, mf + (size_t)b * nmod, mf + (size_t)b * nmod + D, 0, 0,
+                                   w.xm + (size_t)b * S * D, S, D, 1e-6f, s));
+    GemmProblem p = make_problem(m->final_proj, w.xm, D, B * S, pred, C, EPI_STORE_F32);
+    FMI_TRY(launch_gemm(&p, 1, s));
+  }
+  return FMI_OK;
+}
+
+int check_inputs(fmi_flux* m, const fmi_flux_inputs* in) {
+  if (!m || !in) return fail(FMI_ERR_INVALID, "flux: null handle or inputs");
+  if (in->B <= 0 || in->S <= 0 || in->T <= 0) return fail(FMI_ERR_INVALID, "flux: B, S, T must be positive");
+  if (in->B > 8) return fail(FMI_ERR_UNSUPPORTED, "flux: batch > 8 per device not supported (shard across GPUs)");
+  if (!in->img_ids || !in->txt || !in->txt_ids || !in->y) return fail(FMI_ERR_INVALID, "flux: null input tensor");
+  return check_ready(m);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------- C-ABI
+extern "C" void fmi_flux_default_config(fmi_flux_config* cfg, int guidance_embeds) {
+  cfg->in_channels = 64;
+  cfg->pooled_projection_dim = 768;
+  cfg->joint_attention_dim = 4096;
+  cfg->num_attention_heads = 24;
+  cfg->num_layers = 19;
+  cfg->num_single_layers = 38;
+  cfg->guidance_embeds = guidance_embeds ? 1 : 0;
+  cfg->axes_dim[0] = 16, cfg->axes_dim[1] = 56, cfg->axes_dim[2] = 56;
+  cfg->theta = 10000;
+}
+
+extern "C" int fmi_flux_create(const fmi_flux_config* cfg, fmi_model_dtype dtype, fmi_flux** out) {
+  if (!cfg || !out) return fail(FMI_ERR_INVALID, "flux_create: null argument");
+  if (dtype == FMI_MODEL_F16 || dtype == FMI_MODEL_F32)
+    return fail(FMI_ERR_UNSUPPORTED, "flux_create: this build computes in bf16 on MFMA; F16/F32 model dtypes are not implemented");
+  if (cfg->axes_dim[0] + cfg->axes_dim[1] + cfg->axes_dim[2] != 128 || (cfg->axes_dim[0] | cfg->axes_dim[1] | cfg->axes_dim[2]) & 1)
+    return fail(FMI_ERR_INVALID, "flux_create: axes_dim must be even and sum to 128 (head dim)");
+  if (cfg->num_attention_heads <= 0 || cfg->num_layers < 0 || cfg->num_single_layers < 0) return fail(FMI_ERR_INVALID, "flux_create: bad layer counts");
+  if (cfg->in_channels % 64 || cfg->joint_attention_dim % 64 || cfg->pooled_projection_dim % 8)
+    return fail(FMI_ERR_INVALID, "flux_create: in_channels and joint_attention_dim must be multiples of 64, pooled dim of 8");
+  fmi_flux* m = new fmi_flux();
+  m->cfg = *cfg;
+  m->H = cfg->num_attention_heads;
+  m->D = m->H * 128;  // HIDDEN_SIZE (model.rs:17) generalised as heads * pe_dim
+  m->M = 4 * m->D;    // MLP_RATIO (model.rs:16)
+  build_layout(m);    // counting pass
+  m->arena_bytes = align_up(m->arena_used, 256) + 256;
+  hipError_t e = hipMalloc((void**)&m->arena, m->arena_bytes);
+  if (e != hipSuccess) {
+    size_t need = m->arena_bytes;
+    delete m;
+    return fail(FMI_ERR_NOMEM, "flux_create: hipMalloc of " + std::to_string(need) + " bytes failed: " + hipGetErrorString(e));
+  }
+  hipMemset(m->arena, 0, m->arena_bytes);
+  build_layout(m);
+  hipEventCreate(&m->ev0);
+  hipEventCreate(&m->ev1);
+  *out = m;
+  return FMI_OK;
+}
+
+extern "C" void fmi_flux_destroy(fmi_flux* m) {
+  if (!m) return;
+  hipDeviceSynchronize();
+  if (m->ws.base) hipFree(m->ws.base);
+  if (m->arena) hipFree(m->arena);
+  for (auto& b : m->dbl)
+    for (int s = 0; s < 2; ++s)
+      for (Dense* d : {&b.qkv[s], &b.proj[s], &b.mlp1[s], &b.mlp2[s]}) {
+        if (d->wq) hipFree(d->wq);
+        if (d->absmax) hipFree(d->absmax);
+      }
+  for (auto& b : m->sgl)
+    for (Dense* d : {&b.w1, &b.w2}) {
+      if (d->wq) hipFree(d->wq);
+      if (d->absmax) hipFree(d->absmax);
+    }
+  if (m->ev0) hipEventDestroy(m->ev0);
+  if (m->ev1) hipEventDestroy(m->ev1);
+  delete m;
+}
+
+extern "C" int fmi_flux_set_tensor(fmi_flux* m, const char* name, const void* data, fmi_dtype dtype, const int64_t* shape, int rank) {
+  if (!m || !name || !data) return fail(FMI_ERR_INVALID, "flux_set_tensor: null argument");
+  auto it = m->names.find(name);
+  if (it == m->names.end()) return fail(FMI_ERR_INVALID, std::string("flux_set_tensor: unknown tensor name '") + name + "'");
+  const Dest& d = it->second;
+  int64_t numel = 1;
+  for (int i = 0; i < rank; ++i) numel *= shape[i];
+  bool ok = numel == d.numel;
+  if (ok && d.cols) ok = rank == 2 && shape[0] == d.rows && shape[1] == d.cols;
+  if (ok && !d.cols) ok = rank == 1 && shape[0] == d.rows;
+  if (!ok) {
+    std::string got = "(";
+    for (int i = 0; i < rank; ++i) got += std::to_string(shape[i]) + (i + 1 < rank ? "," : "");
+    got += ")";
+    return fail(FMI_ERR_INVALID, std::string("flux_set_tensor: shape mismatch for ") + name + ": got " + got + ", expected (" +
+                                     std::to_string(d.rows) + (d.cols ? "," + std::to_string(d.cols) : "") + ")");
+  }
+  if (dtype != FMI_F32 && dtype != FMI_F16 && dtype != FMI_BF16) return fail(FMI_ERR_INVALID, "flux_set_tensor: dtype must be F32/F16/BF16");
+  const size_t esz = dtype == FMI_F32 ? 4 : 2;
+  if (dtype == FMI_BF16) {
+    FMI_HIP_TRY(hipMemcpy(d.ptr, data, numel * 2, hipMemcpyDefault));
+  } else {
+    void* tmp = nullptr;
+    FMI_HIP_TRY(hipMalloc(&tmp, numel * esz));
+    hipError_t e = hipMemcpy(tmp, data, numel * esz, hipMemcpyDefault);
+    int rc = e == hipSuccess ? launch_cast_to_bf16(tmp, dtype, (bf16_t*)d.ptr, numel, nullptr) : fail(FMI_ERR_HIP, hipGetErrorString(e));
+    hipDeviceSynchronize();
+    hipFree(tmp);
+    if (rc) return rc;
+  }
+  m->missing.erase(name);
+  return FMI_OK;
+}
+
+namespace {
+Dense* find_dense(fmi_flux* m, const std::string& prefix, int* row0) {
+  // only the MFMA-GEMM linears of the blocks take the fused 4-bit path
+  *row0 = 0;
+  const int D = m->D;
+  auto parse = [&](const char* head, int* idx, std::string* rest) {
+    const size_t hl = strlen(head);
+    if (prefix.compare(0, hl, head) != 0) return false;
+    size_t dot = prefix.find('.', hl);
+    if (dot == std::string::npos) return false;
+    *idx = atoi(prefix.substr(hl, dot - hl).c_str());
+    *rest = prefix.substr(dot + 1);
+    return true;
+  };
+  int idx;
+  std::string rest;
+  if (parse("transformer_blocks.", &idx, &rest) && idx >= 0 && idx < (int)m->dbl.size()) {
+    auto& b = m->dbl[idx];
+    const char* qn[2][3] = {{"attn.to_q", "attn.to_k", "attn.to_v"}, {"attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj"}};
+    for (int s = 0; s < 2; ++s) {
+      for (int j = 0; j < 3; ++j)
+        if (rest == qn[s][j]) {
+          *row0 = j * D;
+          return &b.qkv[s];
+        }
+    }
+    if (rest == "attn.to_out.0") return &b.proj[0];
+    if (rest == "attn.to_add_out") return &b.proj[1];
+    if (rest == "ff.net.0.proj") return &b.mlp1[0];
+    if (rest == "ff_context.net.0.proj") return &b.mlp1[1];
+    if (rest == "ff.net.2") return &b.mlp2[0];
+    if (rest == "ff_context.net.2") return &b.mlp2[1];
+  }
+  if (parse("single_transformer_blocks.", &idx, &rest) && idx >= 0 && idx < (int)m->sgl.size()) {
+    auto& b = m->sgl[idx];
+    if (rest == "attn.to_q") return &b.w1;
+    if (rest == "attn.to_k") {
+      *row0 = D;
+      return &b.w1;
+    }
+    if (rest == "attn.to_v") {
+      *row0 = 2 * D;
+      return &b.w1;
+    }
+    if (rest == "proj_mlp") {
+      *row0 = 3 * D;
+      return &b.w1;
+    }
+    if (rest == "proj_out") return &b.w2;
+  }
+  return nullptr;
+}
+}  // namespace
+
+extern "C" int fmi_flux_set_linear_bnb4(fmi_flux* m, const char* prefix, const uint8_t* packed, const float* absmax, int blocksize,
+                                        int quant_type, int out_features, int in_features) {
+  if (!m || !prefix || !packed || !absmax) return fail(FMI_ERR_INVALID, "set_linear_bnb4: null argument");
+  if (quant_type != 1 && quant_type != 2) return fail(FMI_ERR_INVALID, "set_linear_bnb4: quant_type must be 1 (fp4) or 2 (nf4)");
+  if (blocksize % 64 || blocksize <= 0 || in_features % blocksize)
+    return fail(FMI_ERR_UNSUPPORTED, "set_linear_bnb4: blocksize must be a multiple of 64 dividing in_features");
+  int row0 = 0;
+  Dense* d = find_dense(m, prefix, &row0);
+  const std::string wname = std::string(prefix) + ".weight";
+  if (!d) {
+    // not a block GEMM linear (embedders, modulation): dequantise once into the dense arena
+    auto it = m->names.find(wname);
+    if (it == m->names.end()) return fail(FMI_ERR_INVALID, std::string("set_linear_bnb4: unknown linear '") + prefix + "'");
+    const Dest& dst = it->second;
+    if (dst.rows != out_features || dst.cols != in_features) return fail(FMI_ERR_INVALID, "set_linear_bnb4: shape mismatch for " + wname);
+    const int64_t n = (int64_t)out_features * in_features;
+    uint8_t* dq = nullptr;
+    float* da = nullptr;
+    FMI_HIP_TRY(hipMalloc((void**)&dq, n / 2));
+    FMI_HIP_TRY(hipMalloc((void**)&da, n / blocksize * 4));
+    FMI_HIP_TRY(hipMemcpy(dq, packed, n / 2, hipMemcpyDefault));
+    FMI_HIP_TRY(hipMemcpy(da, absmax, n / blocksize * 4, hipMemcpyDefault));
+    if (quant_type == 2)
+      dequantize_blockwise_bf16_nf4(nullptr, dq, da, dst.ptr, blocksize, (int)n, nullptr);
+    else
+      dequantize_blockwise_bf16_fp4(nullptr, dq, da, dst.ptr, blocksize, (int)n, nullptr);
+    hipDeviceSynchronize();
+    hipFree(dq);
+    hipFree(da);
+    m->missing.erase(wname);
+    return FMI_OK;
+  }
+  if (in_features != d->K || row0 + out_features > d->N) return fail(FMI_ERR_INVALID, "set_linear_bnb4: shape mismatch for " + wname);
+  if (d->q_type && (d->q_type != quant_type || d->q_blocksize != blocksize))
+    return fail(FMI_ERR_UNSUPPORTED, "set_linear_bnb4: all parts of a fused projection must share quant type and blocksize");
+  if (!d->wq) {
+    FMI_HIP_TRY(hipMalloc((void**)&d->wq, (size_t)d->N * d->K / 2));
+    FMI_HIP_TRY(hipMalloc((void**)&d->absmax, (size_t)d->N * d->K / blocksize * 4));
+    FMI_HIP_TRY(hipMemset(d->wq, 0x77, (size_t)d->N * d->K / 2));  // nf4 code 7 = 0.0
+    FMI_HIP_TRY(hipMemset(d->absmax, 0, (size_t)d->N * d->K / blocksize * 4));
+  }
+  d->q_type = quant_type;
+  d->q_blocksize = blocksize;
+  const size_t n = (size_t)out_features * in_features;
+  FMI_HIP_TRY(hipMemcpy(d->wq + (size_t)row0 * d->K / 2, packed, n / 2, hipMemcpyDefault));
+  FMI_HIP_TRY(hipMemcpy(d->absmax + (size_t)row0 * d->K / blocksize, absmax, n / blocksize * 4, hipMemcpyDefault));
+  m->missing.erase(wname);
+  return FMI_OK;
+}
+
+extern "C" int fmi_flux_missing_count(const fmi_flux* m) { return m ? (int)m->missing.size() : 0; }
+extern "C" const char* fmi_flux_missing_name(const fmi_flux* m, int i) {
+  if (!m || i < 0 || i >= (int)m->missing.size()) return nullptr;
+  auto* mm = const_cast<fmi_flux*>(m);
+  mm->missing_list.assign(m->missing.begin(), m->missing.end());
+  return mm->missing_list[i].c_str();
+}
+extern "C" size_t fmi_flux_size_in_bytes(const fmi_flux* m) { return m ? m->arena_bytes + m->ws.bytes : 0; }
+
+extern "C" int fmi_flux_forward(fmi_flux* m, const fmi_flux_inputs* in, float* pred_out, void* stream) {
+  FMI_TRY(check_inputs(m, in));
+  if (!in->img || !in->timesteps || !pred_out) return fail(FMI_ERR_INVALID, "flux_forward: null img/timesteps/pred_out");
+  hipStream_t s = (hipStream_t)stream;
+  FMI_TRY(ensure_workspace(m, in->B, in->S, in->T));
+  FMI_TRY(prepare_static(m, in, s));
+  FMI_TRY(launch_cast_to_f32(in->img, in->img_dtype, m->ws.img_f32, (int64_t)in->B * in->S * m->cfg.in_channels, s));
+  return forward_core(m, in, m->ws.img_f32, in->timesteps, pred_out, s);
+}
+
+extern "C" int fmi_flux_denoise(fmi_flux* m, const fmi_flux_inputs* in, float* img_inout, const double* timesteps_host, int n_steps,
+                                void* stream) {
+  FMI_TRY(check_inputs(m, in));
+  if (!img_inout || !timesteps_host || n_steps < 0) return fail(FMI_ERR_INVALID, "flux_denoise: null img/timesteps or negative n_steps");
+  hipStream_t s = (hipStream_t)stream;
+  const int B = in->B;
+  FMI_TRY(ensure_workspace(m, B, in->S, in->T));
+  FMI_TRY(prepare_static(m, in, s));  // txt cast, y cast and the RoPE table are loop invariant
+  const int64_t n = (int64_t)B * in->S * m->cfg.in_channels;
+  // t_vec = full(1f32, B) * t_curr  (sampling.rs:35,42): all steps' vectors uploaded once
+  if ((int64_t)n_steps * B > 4096) return fail(FMI_ERR_UNSUPPORTED, "flux_denoise: n_steps * B > 4096");
+  std::vector<float> tv((size_t)(n_steps > 0 ? n_steps : 1) * B);
+  for (int i = 0; i < n_steps; ++i)
+    for (int b = 0; b < B; ++b) tv[(size_t)i * B + b] = 1.0f * (float)timesteps_host[i];
+  FMI_HIP_TRY(hipMemcpyAsync(m->ws.tv, tv.data(), tv.size() * 4, hipMemcpyHostToDevice, s));
+  FMI_HIP_TRY(hipStreamSynchronize(s));  // tv is pageable host memory: finish the copy before it dies
+  for (int i = 0; i < n_steps; ++i) {
+    FMI_TRY(forward_core(m, in, img_inout, m->ws.tv + (size_t)i * B, m->ws.pred_tmp, s));
+    // img = img + pred * (t_prev - t_curr)  (sampling.rs:43), scalar rounded to f32 like candle's affine
+    const float dt = (float)(timesteps_host[i + 1] - timesteps_host[i]);
+    FMI_TRY(launch_euler_update(img_inout, m->ws.pred_tmp, dt, n, s));
+  }
+  return FMI_OK;
+}
+
+extern "C" int fmi_flux_set_profiling(fmi_flux* m, int enable) {
+  if (!m) return fail(FMI_ERR_INVALID, "null handle");
+  m->profiling = enable != 0;
+  for (int i = 0; i < PH_COUNT; ++i) m->phase_ms[i] = 0;
+  return FMI_OK;
+}
+extern "C" int fmi_flux_phase_count(void) { return PH_COUNT; }
+extern "C" const char* fmi_flux_phase_name(int i) { return (i >= 0 && i < PH_COUNT) ? kPhaseNames[i] : nullptr; }
+extern "C" int fmi_flux_phase_ms(fmi_flux* m, float* ms_out) {
+  if (!m || !ms_out) return fail(FMI_ERR_INVALID, "null argument");
+  for (int i = 0; i < PH_COUNT; ++i) ms_out[i] = m->phase_ms[i];
+  return FMI_OK;
+}
+// test hook: 0 = rescale every tile, else deferred-rescale threshold (default)
+extern "C" int fmi_flux_set_attention_rescale_threshold(fmi_flux* m, int thr_x16) {
+  if (!m) return fail(FMI_ERR_INVALID, "null handle");
+  m->attn_thr = thr_x16;
+  return FMI_OK;
+}

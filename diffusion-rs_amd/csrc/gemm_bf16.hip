@@ -1,0 +1,355 @@
+// gemm_bf16.hip — grouped bf16 GEMM  y = epi(x · Wᵀ + bias)  on v_mfma_f32_32x32x16_bf16,
+// plus the implicit-GEMM 3x3 / 1x1 convolution of the VAE decoder on the same main loop.
+//
+// Replaces every Linear on the FLUX hot path: UnquantLinear::forward
+// (diffusion_rs_backend/src/unquantized/mod.rs:34-77: cuBLASLt TN batched matmul with bias as C)
+// and, with QUANT, BnbLinear::forward (bitsandbytes/mod.rs:301-312) without the dense
+// dequantised round trip through HBM; with CONV, Conv2d::forward (nn/conv.rs:212-230 ->
+// im2col + GEMM + strided copy, cuda_backend/mod.rs:1544-1599) without materialising im2col.
+//
+// CDNA4 design (not a port of the reference's cuBLAS call):
+//   * 256 x (128|256) x 64 macro tile, 8 waves (2 along M x 4 along N), each wave owns
+//     128 x (32|64) of C as 4 x NJ accumulators of the 32x32x16 MFMA.
+//   * A and W tiles are DMA'd HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip),
+//     double buffered.  The LDS image is lane-linear, so the bank-conflict XOR swizzle (16-B
+//     slot c -> c ^ ((row>>1)&7) inside each 128-B row) is applied on the per-lane *source*
+//     address and again on the ds_read_b128 address.
+//   * Operands are swapped (W rows feed the MFMA A operand, x rows feed B) so every lane ends
+//     up with 4 consecutive output columns of one row: 8-byte bf16 / 16-byte f32 stores and
+//     vector loads of bias / gate in the epilogue.
+//   * One barrier per K tile; the DMA of tile k+1 is in flight while tile k is multiplied.
+//   * Grouped launch (img + txt streams of a double block in one grid) and an XCD-aware
+//     bijective block remap so tiles sharing a W panel sit on the same XCD's L2.
+//   * Epilogues fuse bias, GELU(tanh), gate*y + residual (f32 residual stream), per-column-range
+//     GELU (single-stream block's [q|k|v|mlp] fused projection), scale, bf16 residual add.
+//   * QUANT: nf4 / fp4 weight tiles are read packed (32 B per row per K tile), expanded with the
+//     16-entry LUT * absmax in registers and written to the same swizzled LDS image — the
+//     "dequant as an LDS stage" of BASELINE.json's north star.
+//   * CONV: the A-tile row is an output pixel, the K tile a (tap, 64-channel) slice of an NHWC
+//     image; padding taps read a zero line, a nearest-2x upsample is folded into the gather.
+#include "common.h"
+
+namespace fmi {
+
+constexpr int BM = 256, BK = 64;
+constexpr int GEMM_THREADS = 512;
+constexpr int A_TILE_BYTES = BM * BK * 2;  // 32 KiB
+constexpr int MAX_PROBLEMS = 8;
+
+struct GemmBatch {
+  GemmProblem p[MAX_PROBLEMS];
+  int tile_start[MAX_PROBLEMS + 1];
+  int nprob;
+};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __constant__ float kNF4[16] = {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
+                                          -0.28444138169288635f, -0.18477343022823334f, -0.09105003625154495f, 0.0f,
+                                          0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f, 0.33791524171829224f,
+                                          0.44070982933044434f, 0.5626170039176941f, 0.7229568362236023f, 1.0f};
+
+// fp4 tree of dequant.cu:12-37 as (value * absmax) * sign, same operation order
+__device__ __forceinline__ float dq_fp4(unsigned v, float am) {
+  const float tab[8] = {0.0f, 5.208333333e-03f, 0.66666667f, 1.0f, 0.33333333f, 0.5f, 0.16666667f, 0.25f};
+  float sign = (v & 8) ? -1.0f : 1.0f;
+  return tab[v & 7] * am * sign;
+}
+
+// Stage ROWS x 64 bf16 (rows r0.., cols k0..k0+63 of a row-major matrix with `ld`) into LDS.
+// Rows past `rmax` are clamped (duplicates of the last row; their results are never stored).
+template <int ROWS>
+__device__ __forceinline__ void stage_tile_dma(const bf16_t* __restrict g, int ld, int r0, int rmax, int k0, char* lds_tile, int wave, int lane) {
+  const int r8 = lane >> 3, cs = lane & 7;
+  constexpr int CPW = ROWS / 64;  // 1-KiB chunks (8 rows) per wave
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int chunk = wave * CPW + i;
+    const int row = chunk * 8 + r8;  // tile-local row
+    const int src_slot = cs ^ ((row >> 1) & 7);
+    int grow = r0 + row;
+    grow = grow > rmax ? rmax : grow;
+    const bf16_t* src = g + (int64_t)grow * ld + k0 + src_slot * 8;
+    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds_tile + chunk * 1024), 16, 0, 0);
+  }
+}
+
+// 4-bit weight tile: ROWS x 64 k = 32 packed bytes per row; thread t expands half a row.
+template <int ROWS>
+__device__ __forceinline__ void stage_tile_q4(const GemmProblem& P, int n0, int k0, char* lds_tile, int tid) {
+  const int row = tid >> 1, half = tid & 1;
+  if (row >= ROWS) return;
+  int n = n0 + row;
+  n = n > P.N - 1 ? P.N - 1 : n;
+  const int64_t e0 = (int64_t)n * P.K + k0 + half * 32;  // first element index of this thread's 32 weights
+  const uint4 pk = *reinterpret_cast<const uint4*>(P.Wq + (e0 >> 1));
+  const float am = P.absmax[e0 / P.q_blocksize];
+  const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+  const int sw = (row >> 1) & 7;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {  // 4 chunks of 8 weights (4 bytes each)
+    uint32_t out[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const unsigned byte = (w[c] >> (8 * b)) & 0xffu;
+      float hi, lo;  // high nibble first (dequant.cu:142-151)
+      if (P.q_type == 2) {
+        hi = kNF4[byte >> 4] * am;
+        lo = kNF4[byte & 15] * am;
+      } else {
+        hi = dq_fp4(byte >> 4, am);
+        lo = dq_fp4(byte & 15, am);
+      }
+      out[b] = pack_bf16x2(hi, lo);
+    }
+    const int slot = (half * 4 + c) ^ sw;
+    *reinterpret_cast<uint4*>(lds_tile + row * 128 + slot * 16) = make_uint4(out[0], out[1], out[2], out[3]);
+  }
+}
+
+// MODE 0: dense GEMM, 1: 4-bit weights, 2: implicit-GEMM convolution (NHWC)
+template <int MODE, int NJ>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBatch batch) {
+  constexpr int BN = 128 * NJ;
+  constexpr int W_TILE_BYTES = BN * BK * 2;
+  constexpr int BUF_BYTES = A_TILE_BYTES + W_TILE_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- which problem / tile
+  const int total = batch.tile_start[batch.nprob];
+  const int lid = xcd_remap(blockIdx.x, total);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_PROBLEMS; ++i)
+    if (i < batch.nprob && lid >= batch.tile_start[i]) pi = i;
+  const GemmProblem& P = batch.p[pi];
+  const int t = lid - batch.tile_start[pi];
+  const int tiles_m = (P.M + BM - 1) / BM;
+  const int tm = t % tiles_m, tn = t / tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = P.K / BK;
+
+  auto bufA = [&](int b) -> char* { return smem + b * BUF_BYTES; };
+  auto bufW = [&](int b) -> char* { return smem + b * BUF_BYTES + A_TILE_BYTES; };
+
+  f32x16 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane swizzled column-slot byte offsets for the 4 k-steps of a tile
+  const int sw = ((lane & 31) >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + (lane >> 5)) ^ sw) << 4;
+  const int a_row_off = (wm * 128 + (lane & 31)) * 128;
+  const int w_row_off = (wn * 32 * NJ + (lane & 31)) * 128;
+
+  // CONV: this lane stages rows chunk*8 + (lane>>3), chunk = wave*4 + i; precompute their pixels
+  int cv_y[4], cv_x[4];
+  int64_t cv_base[4];
+  if (MODE == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = m0 + (wave * 4 + i) * 8 + (lane >> 3);
+      m = m > P.M - 1 ? P.M - 1 : m;
+      const int ow = P.cv_w << P.cv_up, oh = P.cv_h << P.cv_up;
+      const int x = m % ow, y = (m / ow) % oh, b = m / (ow * oh);
+      cv_x[i] = x;
+      cv_y[i] = y;
+      cv_base[i] = (int64_t)b * P.cv_h * P.cv_w;
+    }
+  }
+  auto stage_a = [&](int kt, char* dst) {
+    if (MODE == 2) {
+      const int cpt = P.cv_cin >> 6;  // 64-channel slices per tap
+      const int tap = kt / cpt, c0 = (kt - tap * cpt) << 6;
+      const int half = P.cv_ks >> 1;
+      const int dy = tap / P.cv_ks - half, dx = tap % P.cv_ks - half;
+      const int ow = P.cv_w << P.cv_up, oh = P.cv_h << P.cv_up;
+      const int cs = lane & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int chunk = wave * 4 + i;
+        const int row = chunk * 8 + (lane >> 3);
+        const int src_slot = cs ^ ((row >> 1) & 7);
+        const int yy = cv_y[i] + dy, xx = cv_x[i] + dx;
+        const bf16_t* src;
+        if (yy >= 0 && yy < oh && xx >= 0 && xx < ow)
+          src = P.A + (cv_base[i] + (int64_t)(yy >> P.cv_up) * P.cv_w + (xx >> P.cv_up)) * P.cv_cin + c0 + src_slot * 8;
+        else
+          src = P.cv_zero + src_slot * 8;  // zero padding (conv2d pad = k/2)
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + chunk * 1024), 16, 0, 0);
+      }
+    } else {
+      stage_tile_dma<BM>(P.A, P.lda, m0, P.M - 1, kt * BK, dst, wave, lane);
+    }
+  };
+  auto stage_w = [&](int kt, char* dst) {
+    if (MODE == 1)
+      stage_tile_q4<BN>(P, n0, kt * BK, dst, tid);
+    else
+      stage_tile_dma<BN>(P.W, P.ldw, n0, P.N - 1, kt * BK, dst, wave, lane);
+  };
+
+  stage_a(0, bufA(0));
+  stage_w(0, bufW(0));
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    __syncthreads();  // tile kt landed for every wave; everyone finished reading buf[cur^1]
+    if (kt + 1 < nk) {
+      stage_a(kt + 1, bufA(cur ^ 1));
+      stage_w(kt + 1, bufW(cur ^ 1));
+    }
+    const char* la = bufA(cur) + a_row_off;
+    const char* lw = bufW(cur) + w_row_off;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8_t xf[4], wf[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(lw + j * 32 * 128 + koff[s]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(la + i * 32 * 128 + koff[s]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds row m = ..+(lane&31), columns n = ..+8q+4(lane>>5)+{0..3}
+  const int epi = P.epi;
+  const float alpha = P.alpha;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 128 + i * 32 + (lane & 31);
+    if (m >= P.M) continue;
+    const float* gate = P.gate;
+    if (epi == EPI_RESID_GATE_F32 && P.rows_per_batch > 0) gate += (int64_t)(m / P.rows_per_batch) * P.gate_bstride;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 32 * NJ + j * 32 + q * 8 + 4 * (lane >> 5);
+        if (n >= P.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+        const bool full = (n + 3 < P.N);
+        if (epi == EPI_STORE_F32 || epi == EPI_SCALE_BF16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= alpha;
+        }
+        if (P.bias) {
+          if (full) {
+            const uint2 b = *reinterpret_cast<const uint2*>(P.bias + n);
+            v[0] += bf16_to_f32((bf16_t)(b.x & 0xffff));
+            v[1] += bf16_to_f32((bf16_t)(b.x >> 16));
+            v[2] += bf16_to_f32((bf16_t)(b.y & 0xffff));
+            v[3] += bf16_to_f32((bf16_t)(b.y >> 16));
+          } else {
+            for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(P.bias[n + e]);
+          }
+        }
+        if (epi == EPI_GELU_BF16 || (epi == EPI_GELU_FROM_COL && n >= P.gelu_from)) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+        } else if (epi == EPI_SILU_BF16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
+        }
+        if (epi == EPI_RESID_GATE_F32) {
+          float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
+          if (full) {
+            const float4 g = *reinterpret_cast<const float4*>(gate + n);
+            float4 x = *reinterpret_cast<float4*>(o);
+            x.x += g.x * v[0];
+            x.y += g.y * v[1];
+            x.z += g.z * v[2];
+            x.w += g.w * v[3];
+            *reinterpret_cast<float4*>(o) = x;
+          } else {
+            for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] += gate[n + e] * v[e];
+          }
+        } else if (epi == EPI_STORE_F32) {
+          float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
+          if (full) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = v[e];
+          }
+        } else {
+          bf16_t* o = reinterpret_cast<bf16_t*>(P.out) + (int64_t)m * P.ldo + n;
+          if (epi == EPI_RESID_ADD_BF16) {
+            const bf16_t* r = reinterpret_cast<const bf16_t*>(P.resid) + (int64_t)m * P.ldo + n;
+            for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(r[e]);
+          }
+          if (full && (P.ldo & 3) == 0) {
+            *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          } else {
+            for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = f32_to_bf16(v[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
+  if (nprob <= 0) return FMI_OK;
+  if (nprob > MAX_PROBLEMS) return fail(FMI_ERR_INVALID, "launch_gemm: too many grouped problems");
+  GemmBatch b;
+  b.nprob = nprob;
+  int total = 0;
+  const bool quant = probs[0].q_type != 0;
+  const bool conv = probs[0].cv_ks != 0;
+  int max_n = 0;
+  for (int i = 0; i < nprob; ++i) max_n = std::max(max_n, probs[i].N);
+  const int bn = max_n <= 128 ? 128 : 256;
+  for (int i = 0; i < nprob; ++i) {
+    const GemmProblem& p = probs[i];
+    if (p.M <= 0 || p.N <= 0) return fail(FMI_ERR_INVALID, "launch_gemm: empty problem");
+    if (p.K <= 0 || p.K % BK != 0) return fail(FMI_ERR_INVALID, "launch_gemm: K must be a positive multiple of 64, got " + std::to_string(p.K));
+    if ((p.q_type != 0) != quant || (p.cv_ks != 0) != conv) return fail(FMI_ERR_INVALID, "launch_gemm: cannot mix dense / 4-bit / conv problems in one group");
+    if (quant && conv) return fail(FMI_ERR_UNSUPPORTED, "launch_gemm: quantised convolution");
+    if ((!conv && p.lda % 8) || (!quant && p.ldw % 8)) return fail(FMI_ERR_INVALID, "launch_gemm: lda/ldw must be multiples of 8 elements (16-byte rows)");
+    if (conv && (p.cv_cin % 64 || p.K != p.cv_ks * p.cv_ks * p.cv_cin || !p.cv_zero)) return fail(FMI_ERR_INVALID, "launch_gemm: bad conv descriptor (Cin % 64, K = k*k*Cin)");
+    if (p.epi != EPI_STORE_BF16 && p.epi != EPI_GELU_BF16 && p.epi != EPI_GELU_FROM_COL && p.epi != EPI_SCALE_BF16 && p.epi != EPI_RESID_ADD_BF16 &&
+        p.epi != EPI_SILU_BF16 && p.ldo % 4)
+      return fail(FMI_ERR_INVALID, "launch_gemm: f32 outputs need ldo % 4 == 0");
+    if (quant && (p.q_blocksize % 64 != 0 || p.q_blocksize <= 0)) return fail(FMI_ERR_INVALID, "launch_gemm: 4-bit blocksize must be a multiple of 64");
+    b.p[i] = p;
+    b.tile_start[i] = total;
+    total += cdiv(p.M, BM) * cdiv(p.N, bn);
+  }
+  for (int i = nprob; i <= MAX_PROBLEMS; ++i) b.tile_start[i] = total;
+  const dim3 grid(total), blk(GEMM_THREADS);
+#define FMI_GEMM_LAUNCH(MODE)                                                               \
+  do {                                                                                      \
+    if (bn == 128)                                                                          \
+      hipLaunchKernelGGL((gemm_bf16_kernel<MODE, 1>), grid, blk, 0, stream, b);             \
+    else                                                                                    \
+      hipLaunchKernelGGL((gemm_bf16_kernel<MODE, 2>), grid, blk, 0, stream, b);             \
+  } while (0)
+  if (conv)
+    FMI_GEMM_LAUNCH(2);
+  else if (quant)
+    FMI_GEMM_LAUNCH(1);
+  else
+    FMI_GEMM_LAUNCH(0);
+#undef FMI_GEMM_LAUNCH
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
+}  // namespace fmi

@@ -1,0 +1,248 @@
+"""Host-side mirrors of the reference's model objects over the C-ABI.
+
+  FluxModel      <-> diffusion_rs_core::models::flux::Flux            (model.rs:709-838)
+  AutoEncoderKl  <-> diffusion_rs_core::models::vaes::AutoEncoderKl   (autoencoder_kl.rs:52-128)
+  FlowMatchEuler <-> pipelines::sampling::Sampler + SchedulerConfig   (sampling.rs, scheduler.rs)
+
+torch is used only as the device-memory / stream plumbing (tensors own the buffers whose raw
+pointers cross the C-ABI); every FLOP runs in libflux_mi355x.so.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+FLUX_DEV = dict(in_channels=64, pooled_projection_dim=768, joint_attention_dim=4096, num_attention_heads=24, num_layers=19,
+                num_single_layers=38, guidance_embeds=True, axes_dim=[16, 56, 56], theta=10000)
+FLUX_SCHNELL = dict(FLUX_DEV, guidance_embeds=False)
+VAE_FLUX = dict(in_channels=3, out_channels=3, block_out_channels=[128, 256, 512, 512], layers_per_block=2, latent_channels=16,
+                norm_num_groups=32, mid_block_add_attention=True, use_post_quant_conv=False, scaling_factor=0.3611, shift_factor=0.1159)
+
+_TORCH_DT = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16, torch.uint8: L.U8, torch.int8: L.I8}
+_NP_DT = {np.dtype(np.float32): L.F32, np.dtype(np.float16): L.F16}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _tensor_arg(t):
+    """(pointer, fmi_dtype, shape, keepalive) for a torch tensor (any device) or numpy array."""
+    if isinstance(t, np.ndarray):
+        a = np.ascontiguousarray(t)
+        if a.dtype not in _NP_DT:
+            a = a.astype(np.float32)
+        return C.c_void_p(a.ctypes.data), _NP_DT[a.dtype], a.shape, a
+    t = t.contiguous()
+    return C.c_void_p(t.data_ptr()), _TORCH_DT[t.dtype], tuple(t.shape), t
+
+
+@dataclass
+class SchedulerConfig:
+    """pipelines/scheduler.rs:4-20 (public FLUX.1 values as defaults)."""
+    base_image_seq_len: int = 256
+    base_shift: float = 0.5
+    max_image_seq_len: int = 4096
+    max_shift: float = 1.15
+    shift: float = 3.0
+    use_dynamic_shifting: bool = True
+
+    def get_timesteps(self, num_steps: int, mu: Optional[float]) -> List[float]:
+        if self.use_dynamic_shifting and mu is None:
+            raise ValueError("`mu` is required for dynamic shifting")  # scheduler.rs:34
+        c = L.SchedulerConfigC(self.base_image_seq_len, self.base_shift, self.max_image_seq_len, self.max_shift, self.shift,
+                               int(self.use_dynamic_shifting))
+        out = (C.c_double * (num_steps + 1))()
+        L.check(L.load().fmi_get_timesteps(C.byref(c), num_steps, C.c_double(mu or 0.0), out))
+        return list(out)
+
+    def calculate_shift(self, image_seq_len: int) -> float:
+        return L.load().fmi_calculate_shift(image_seq_len, self.base_image_seq_len, self.max_image_seq_len, self.base_shift, self.max_shift)
+
+
+class FluxModel:
+    def __init__(self, cfg: dict, device: int = 0):
+        self.lib = L.load()
+        self.cfg = dict(cfg)
+        L.check(self.lib.fmi_init(device))
+        c = L.FluxConfig(cfg["in_channels"], cfg["pooled_projection_dim"], cfg["joint_attention_dim"], cfg["num_attention_heads"],
+                         cfg["num_layers"], cfg["num_single_layers"], int(cfg["guidance_embeds"]), (C.c_int * 3)(*cfg["axes_dim"]), cfg["theta"])
+        h = C.c_void_p()
+        L.check(self.lib.fmi_flux_create(C.byref(c), L.MODEL_BF16, C.byref(h)))
+        self.h = h
+        self.hidden = cfg["num_attention_heads"] * 128
+        self.device = torch.device("cuda", device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fmi_flux_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def is_guidance(self) -> bool:  # Flux::is_guidance, model.rs:835-837
+        return bool(self.cfg["guidance_embeds"])
+
+    def set_tensor(self, name: str, t):
+        p, dt, shape, keep = _tensor_arg(t)
+        sh = (C.c_int64 * len(shape))(*shape)
+        L.check(self.lib.fmi_flux_set_tensor(self.h, name.encode(), p, dt, sh, len(shape)))
+
+    def load_state_dict(self, tensors: dict):
+        for k, v in tensors.items():
+            self.set_tensor(k, v)
+        self.assert_complete()
+
+    def set_linear_bnb4(self, prefix: str, packed, absmax, blocksize: int, quant_type: str, out_features: int, in_features: int):
+        pk = np.ascontiguousarray(packed, np.uint8)
+        am = np.ascontiguousarray(absmax, np.float32)
+        q = {"fp4": 1, "nf4": 2}[quant_type]
+        L.check(self.lib.fmi_flux_set_linear_bnb4(self.h, prefix.encode(), C.c_void_p(pk.ctypes.data), C.c_void_p(am.ctypes.data), blocksize, q,
+                                                  out_features, in_features))
+
+    def missing(self) -> List[str]:
+        n = self.lib.fmi_flux_missing_count(self.h)
+        return [self.lib.fmi_flux_missing_name(self.h, i).decode() for i in range(n)]
+
+    def assert_complete(self):
+        m = self.missing()
+        if m:
+            raise L.FmiError(f"{len(m)} tensors missing, e.g. {m[:4]}")
+
+    def size_in_bytes(self) -> int:
+        return self.lib.fmi_flux_size_in_bytes(self.h)
+
+    def _inputs(self, img, img_ids, txt, txt_ids, timesteps, y, guidance):
+        B, S = int(img_ids.shape[0]), int(img_ids.shape[1])
+        T = int(txt.shape[1])
+        keep = [t.contiguous() if t is not None else None for t in (img, img_ids, txt, txt_ids, timesteps, y, guidance)]
+        img, img_ids, txt, txt_ids, timesteps, y, guidance = keep
+        for t, nm in ((img_ids, "img_ids"), (txt_ids, "txt_ids"), (timesteps, "timesteps"), (guidance, "guidance")):
+            if t is not None and t.dtype != torch.float32:
+                raise TypeError(f"{nm} must be float32")
+        inp = L.FluxInputs(_ptr(img), _TORCH_DT[img.dtype] if img is not None else 0, _ptr(img_ids), _ptr(txt), _TORCH_DT[txt.dtype], _ptr(txt_ids),
+                           _ptr(timesteps), _ptr(y), _TORCH_DT[y.dtype], _ptr(guidance), B, S, T, 0)
+        return inp, keep
+
+    def forward(self, img, img_ids, txt, txt_ids, timesteps, y, guidance=None):
+        """== Flux::forward (model.rs:790-833).  Returns the velocity (B,S,C) f32."""
+        inp, keep = self._inputs(img, img_ids, txt, txt_ids, timesteps, y, guidance)
+        pred = torch.empty(img.shape, dtype=torch.float32, device=img.device)
+        L.check(self.lib.fmi_flux_forward(self.h, C.byref(inp), _ptr(pred), _stream()))
+        return pred
+
+    def denoise(self, img, img_ids, txt, txt_ids, y, guidance, timesteps: List[float]):
+        """== Sampler::sample around Flux::forward (sampling.rs:25-48). `img` f32 (B,S,C), updated copy returned."""
+        img = img.to(torch.float32).clone().contiguous()
+        inp, keep = self._inputs(None, img_ids, txt, txt_ids, None, y, guidance)
+        ts = (C.c_double * len(timesteps))(*timesteps)
+        L.check(self.lib.fmi_flux_denoise(self.h, C.byref(inp), _ptr(img), ts, len(timesteps) - 1, _stream()))
+        return img
+
+    def set_profiling(self, on: bool):
+        L.check(self.lib.fmi_flux_set_profiling(self.h, int(on)))
+
+    def phase_ms(self) -> dict:
+        n = self.lib.fmi_flux_phase_count()
+        out = (C.c_float * n)()
+        L.check(self.lib.fmi_flux_phase_ms(self.h, out))
+        return {self.lib.fmi_flux_phase_name(i).decode(): out[i] for i in range(n)}
+
+
+class AutoEncoderKl:
+    def __init__(self, cfg: dict, device: int = 0):
+        self.lib = L.load()
+        self.cfg = dict(cfg)
+        L.check(self.lib.fmi_init(device))
+        boc = list(cfg["block_out_channels"])
+        if len(boc) != 4:
+            raise L.FmiError("block_out_channels must have 4 entries (the reference hard-codes i_level != 3, vae.rs:412)")
+        c = L.VaeConfig(cfg["in_channels"], cfg["out_channels"], (C.c_int * 4)(*boc), 4, cfg["layers_per_block"], cfg["latent_channels"],
+                        cfg["norm_num_groups"], int(cfg["mid_block_add_attention"]), int(cfg.get("use_post_quant_conv", False)),
+                        cfg["scaling_factor"], cfg["shift_factor"])
+        h = C.c_void_p()
+        L.check(self.lib.fmi_vae_create(C.byref(c), L.MODEL_BF16, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fmi_vae_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_tensor(self, name, t):
+        p, dt, shape, keep = _tensor_arg(t)
+        sh = (C.c_int64 * len(shape))(*shape)
+        L.check(self.lib.fmi_vae_set_tensor(self.h, name.encode(), p, dt, sh, len(shape)))
+
+    def load_state_dict(self, tensors: dict):
+        for k, v in tensors.items():
+            self.set_tensor(k, v)
+        n = self.lib.fmi_vae_missing_count(self.h)
+        if n:
+            raise L.FmiError(f"{n} VAE tensors missing, e.g. {self.lib.fmi_vae_missing_name(self.h, 0).decode()}")
+
+    def scale_factor(self) -> float:
+        return self.lib.fmi_vae_scale_factor(self.h)
+
+    def shift_factor(self) -> float:
+        return self.lib.fmi_vae_shift_factor(self.h)
+
+    def decode(self, z):
+        """== VAEModel::decode (vaes/mod.rs:15-28): z (B,16,h,w) f32 -> (B,3,8h,8w) f32."""
+        z = z.to(torch.float32).contiguous()
+        B, _, h, w = z.shape
+        out = torch.empty((B, self.cfg["out_channels"], 8 * h, 8 * w), dtype=torch.float32, device=z.device)
+        L.check(self.lib.fmi_vae_decode(self.h, _ptr(z), B, h, w, _ptr(out), _stream()))
+        return out
+
+
+# ---- tensor glue of FluxPipeline::forward (pipelines/flux/mod.rs:270-332), on device
+def pack_latents(latent):
+    """State::new patchify (flux/sampling.rs:131-148): (B,C,h,w) f32 -> img (B,hw/4,4C), img_ids (B,hw/4,3)."""
+    latent = latent.to(torch.float32).contiguous()
+    B, Cc, h, w = latent.shape
+    img = torch.empty((B, (h // 2) * (w // 2), Cc * 4), dtype=torch.float32, device=latent.device)
+    ids = torch.empty((B, (h // 2) * (w // 2), 3), dtype=torch.float32, device=latent.device)
+    L.check(L.load().fmi_pack_latents(_ptr(latent), B, Cc, h, w, _ptr(img), _ptr(ids), _stream()))
+    return img, ids
+
+
+def unpack_latents(img, Cc, h, w, scale_factor, shift_factor):
+    img = img.to(torch.float32).contiguous()
+    B = img.shape[0]
+    z = torch.empty((B, Cc, h, w), dtype=torch.float32, device=img.device)
+    L.check(L.load().fmi_unpack_latents(_ptr(img), B, Cc, h, w, scale_factor, shift_factor, _ptr(z), _stream()))
+    return z
+
+
+def postprocess_u8(image, interleave=False):
+    image = image.to(torch.float32).contiguous()
+    B, Cc, H, W = image.shape
+    out = torch.empty((B, H, W, Cc) if interleave else (B, Cc, H, W), dtype=torch.uint8, device=image.device)
+    L.check(L.load().fmi_postprocess_u8(_ptr(image), B, Cc, H, W, int(interleave), _ptr(out), _stream()))
+    return out
+
+
+def randn_latents(B, Cc, h, w, seed, first_sample=0, device="cuda"):
+    """Seedable get_noise (flux/sampling.rs:5-14): Philox4x32-10, sample index = first_sample + b."""
+    out = torch.empty((B, Cc, h, w), dtype=torch.float32, device=device)
+    L.check(L.load().fmi_randn(_ptr(out), Cc * h * w, B, seed, first_sample, _stream()))
+    return out

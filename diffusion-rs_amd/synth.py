@@ -1,0 +1,182 @@
+"""Synthetic FLUX / VAE weights (there are no checkpoints offline).
+
+`flux_tensor_shapes` / `vae_tensor_shapes` enumerate exactly the diffusers tensor names the
+reference's VarBuilder reads (model.rs:165-772, vae.rs:371-433) with their shapes, so the same
+dictionaries drive the HIP library, the CPU oracle and the independent torch re-derivation.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+
+def flux_tensor_shapes(cfg) -> "OrderedDict[str, tuple]":
+    D = cfg["num_attention_heads"] * sum(cfg["axes_dim"])
+    M = 4 * D
+    C = cfg["in_channels"]
+    hd = sum(cfg["axes_dim"])
+    t = OrderedDict()
+
+    def lin(p, o, i):
+        t[p + ".weight"] = (o, i)
+        t[p + ".bias"] = (o,)
+
+    lin("x_embedder", D, C)
+    lin("context_embedder", D, cfg["joint_attention_dim"])
+    lin("time_text_embed.timestep_embedder.linear_1", D, 256)
+    lin("time_text_embed.timestep_embedder.linear_2", D, D)
+    if cfg["guidance_embeds"]:
+        lin("time_text_embed.guidance_embedder.linear_1", D, 256)
+        lin("time_text_embed.guidance_embedder.linear_2", D, D)
+    lin("time_text_embed.text_embedder.linear_1", D, cfg["pooled_projection_dim"])
+    lin("time_text_embed.text_embedder.linear_2", D, D)
+    for i in range(cfg["num_layers"]):
+        p = f"transformer_blocks.{i}."
+        lin(p + "norm1.linear", 6 * D, D)
+        lin(p + "norm1_context.linear", 6 * D, D)
+        for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+            lin(p + "attn." + n, D, D)
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            t[p + "attn." + n + ".weight"] = (hd,)
+        lin(p + "ff.net.0.proj", M, D)
+        lin(p + "ff.net.2", D, M)
+        lin(p + "ff_context.net.0.proj", M, D)
+        lin(p + "ff_context.net.2", D, M)
+    for i in range(cfg["num_single_layers"]):
+        p = f"single_transformer_blocks.{i}."
+        lin(p + "norm.linear", 3 * D, D)
+        for n in ("to_q", "to_k", "to_v"):
+            lin(p + "attn." + n, D, D)
+        t[p + "attn.norm_q.weight"] = (hd,)
+        t[p + "attn.norm_k.weight"] = (hd,)
+        lin(p + "proj_mlp", M, D)
+        lin(p + "proj_out", D, D + M)
+    lin("norm_out.linear", 2 * D, D)
+    lin("proj_out", C, D)
+    return t
+
+
+def _std_for(name, w_std, mod_std):
+    if "norm1.linear" in name or "norm1_context.linear" in name or ".norm.linear" in name or name.startswith("norm_out.linear"):
+        return mod_std
+    return w_std
+
+
+def flux_state_dict_numpy(cfg, seed=0, w_std=0.02, mod_std=0.01, bias_std=0.02, norm_jitter=0.1, round_bf16=True):
+    """Small-config weights for parity tests: Linear W~N(0,w_std^2) (modulation linears mod_std so
+    1+scale stays near 1 and gates small), biases N(0,bias_std^2), QkNorm weights 1+N(0,norm_jitter^2).
+    Values are rounded to bf16-representable f32 so oracle and GPU see identical weights."""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, shape in flux_tensor_shapes(cfg).items():
+        if name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or name.endswith("norm_added_q.weight") or name.endswith("norm_added_k.weight"):
+            a = 1.0 + norm_jitter * rng.standard_normal(shape)
+        elif name.endswith(".bias"):
+            a = bias_std * rng.standard_normal(shape)
+        else:
+            a = _std_for(name, w_std, mod_std) * rng.standard_normal(shape)
+        a = a.astype(np.float32)
+        out[name] = to_bf16_f32(a) if round_bf16 else a
+    return out
+
+
+def to_bf16_f32(a):
+    """Round f32 to the nearest bf16 (RNE) and return as f32."""
+    a = np.ascontiguousarray(a, np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).reshape(a.shape)
+
+
+def fill_flux_random_device(model, seed=0, w_std=0.02, mod_std=0.01, bias_std=0.0, device="cuda"):
+    """Full-size random weights generated on the GPU (bench): torch.randn is only the RNG here."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    for name, shape in flux_tensor_shapes(model.cfg).items():
+        if "norm_q.weight" in name or "norm_k.weight" in name or "norm_added" in name:
+            t = torch.ones(shape, dtype=torch.bfloat16, device=device)
+        elif name.endswith(".bias"):
+            t = (torch.randn(shape, generator=g, device=device, dtype=torch.float32) * bias_std).to(torch.bfloat16) if bias_std else torch.zeros(
+                shape, dtype=torch.bfloat16, device=device)
+        else:
+            t = torch.randn(shape, generator=g, device=device, dtype=torch.bfloat16)
+            t.mul_(_std_for(name, w_std, mod_std))
+        model.set_tensor(name, t)
+        del t
+    model.assert_complete()
+
+
+def vae_tensor_shapes(cfg) -> "OrderedDict[str, tuple]":
+    boc = list(cfg["block_out_channels"])
+    t = OrderedDict()
+
+    def conv(p, o, i, k):
+        t[p + ".weight"] = (o, i, k, k)
+        t[p + ".bias"] = (o,)
+
+    def gn(p, c):
+        t[p + ".weight"] = (c,)
+        t[p + ".bias"] = (c,)
+
+    def resnet(p, i, o):
+        gn(p + ".norm1", i)
+        conv(p + ".conv1", o, i, 3)
+        gn(p + ".norm2", o)
+        conv(p + ".conv2", o, o, 3)
+        if i != o:
+            conv(p + ".conv_shortcut", o, i, 1)
+
+    block_in = boc[-1]
+    conv("decoder.conv_in", block_in, cfg["latent_channels"], 3)
+    resnet("decoder.mid_block.resnets.0", block_in, block_in)
+    if cfg["mid_block_add_attention"]:
+        p = "decoder.mid_block.attentions.0"
+        gn(p + ".group_norm", block_in)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            t[f"{p}.{n}.weight"] = (block_in, block_in)
+            t[f"{p}.{n}.bias"] = (block_in,)
+    resnet("decoder.mid_block.resnets.1", block_in, block_in)
+    for lvl, block_out in enumerate(reversed(boc)):
+        for i in range(cfg["layers_per_block"] + 1):
+            resnet(f"decoder.up_blocks.{lvl}.resnets.{i}", block_in, block_out)
+            block_in = block_out
+        if lvl != 3:
+            conv(f"decoder.up_blocks.{lvl}.upsamplers.0.conv", block_in, block_in, 3)
+    gn("decoder.conv_norm_out", boc[0])
+    conv("decoder.conv_out", cfg["out_channels"], boc[0], 3)
+    return t
+
+
+def vae_state_dict_numpy(cfg, seed=0, round_bf16=True):
+    """Conv W~N(0, 1/fan_in), small biases, GroupNorm w = 1+0.1N, b = 0.1N."""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, shape in vae_tensor_shapes(cfg).items():
+        if len(shape) == 4 or len(shape) == 2:
+            fan_in = int(np.prod(shape[1:]))
+            a = rng.standard_normal(shape) / np.sqrt(fan_in)
+        elif "norm" in name and name.endswith(".weight"):
+            a = 1.0 + 0.1 * rng.standard_normal(shape)
+        else:
+            a = 0.1 * rng.standard_normal(shape) if "norm" in name else 0.02 * rng.standard_normal(shape)
+        a = a.astype(np.float32)
+        out[name] = to_bf16_f32(a) if round_bf16 else a
+    return out
+
+
+def fill_vae_random_device(vae, seed=0, device="cuda"):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    for name, shape in vae_tensor_shapes(vae.cfg).items():
+        if len(shape) in (2, 4):
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = torch.randn(shape, generator=g, device=device, dtype=torch.float32) / (fan_in ** 0.5)
+        elif "norm" in name and name.endswith(".weight"):
+            t = torch.ones(shape, device=device, dtype=torch.float32)
+        else:
+            t = torch.zeros(shape, device=device, dtype=torch.float32)
+        vae.set_tensor(name, t)
+    return vae

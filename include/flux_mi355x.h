@@ -271,11 +271,12 @@ int fmi_layernorm_mod(const float* x, const float* scale, const float* shift, vo
  * (nn/group_norm.rs:39-74): x (B,HW,C). */
 int fmi_groupnorm_nhwc(const void* x_bf16, const float* weight, const float* bias, void* out_bf16,
                        int B, int HW, int C, int groups, float eps, int fuse_silu, void* stream);
-/* 3x3/1x1 stride-1 conv, zero pad k/2, NHWC bf16, weights (Cout,kh,kw,Cin) bf16, bias f32;
+/* 3x3/1x1 stride-1 conv, zero pad k/2, NHWC bf16, weights (Cout,kh,kw,Cin) bf16, bias bf16 (Cout)
+ * or NULL; Cin % 64 == 0 (zero-pad the channels);
  * optional nearest-2x upsample folded into the input gather (Upsample::forward vae.rs:223-229)
  * and optional residual add (ResnetBlock::forward vae.rs:157-172). (in_h,in_w) is the stored
  * input size; output is (in_h*(up?2:1), in_w*(up?2:1)). */
-int fmi_conv2d_nhwc(const void* x_bf16, const void* w_bf16, const float* bias,
+int fmi_conv2d_nhwc(const void* x_bf16, const void* w_bf16, const void* bias_bf16,
                     const void* residual_bf16, void* out_bf16, int B, int in_h, int in_w, int Cin,
                     int Cout, int ksize, int upsample2x, void* stream);
 
