@@ -1,0 +1,290 @@
+#!/usr/bin/env python
+"""bench.py — images/sec + ms/denoise-step, FLUX.1-dev 1024x1024 50-step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE IMAGE: the full hot path over one batch of synthetic input — 50 denoise
+steps (Flux::forward + Euler update), unpack, VAE decode, u8 post-process — with inputs
+(embeddings, latents) already resident in HBM.  Weights are random-init FLUX.1-dev / FLUX VAE
+of the real architecture (no checkpoints offline), data is synthetic.  Batch sharding: every
+rank generates its own image (weak scaling, no data-path collective); weights are generated on
+rank 0 and broadcast over RCCL/xGMI, the decoded u8 images are gathered to rank 0 after the
+timed region.
+
+One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
+  roofline     — the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / device time from
+                 hipEvents on the launch stream, measured in a profiled pass of the same step
+                 right after the timed region (the per-phase event pairs serialise phases, so
+                 they are kept out of the timed region itself);
+  cpu_baseline — the CPU oracle ("port" of the reference CPU semantics, f32) timed on this
+                 host's cores on a bounded sample (one single-stream block at the full C2 shape),
+                 extrapolated to images/s by algorithmic FLOPs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D_HID, N_HEADS, MLP = 3072, 24, 12288
+N_DOUBLE, N_SINGLE = 19, 38
+
+
+def step_flops(S, T, B=1, cfg=None):
+    """Algorithmic FLOPs of one denoise step, split by kernel class."""
+    D, M = D_HID, MLP
+    L = S + T
+    nd, ns = N_DOUBLE, N_SINGLE
+    if cfg is not None:
+        D = cfg["num_attention_heads"] * 128
+        M = 4 * D
+        nd, ns = cfg["num_layers"], cfg["num_single_layers"]
+    gemm = 0
+    # double blocks: per stream qkv (3D), proj (D), mlp1 (M), mlp2 (M) : tokens * 2 * D * (3D + D + M + M)
+    gemm += nd * 2 * L * D * (3 * D + D + 2 * M)
+    # single blocks: fused (3D+M) and proj_out (D+M -> D)
+    gemm += ns * 2 * L * (D * (3 * D + M) + (D + M) * D)
+    # img_in, txt_in, final proj
+    gemm += 2 * S * 64 * D + 2 * T * 4096 * D + 2 * S * D * 64
+    attn = (nd + ns) * 4 * L * L * D
+    mod = 2 * (nd * 12 + ns * 3 + 2) * D * D + 2 * (3 * D * D + 2 * 256 * D + 768 * D)
+    return dict(gemm=B * gemm, attn=B * attn, gemv=B * mod, total=B * (gemm + attn + mod))
+
+
+def vae_flops(h8, w8):
+    """Algorithmic conv+attention FLOPs of one VAE decode at latent (h8,w8) (public FLUX VAE config)."""
+    boc = [128, 256, 512, 512]
+    px = h8 * w8
+    f = 2 * px * 9 * 16 * 512
+    res = lambda cin, cout, p: 2 * p * 9 * (cin * cout + cout * cout) + (2 * p * cin * cout if cin != cout else 0)
+    f += 2 * res(512, 512, px) + 2 * px * 512 * 512 * 4 + 4 * px * px * 512
+    cin = 512
+    for lvl, cout in enumerate(reversed(boc)):
+        for _ in range(3):
+            f += res(cin, cout, px)
+            cin = cout
+        if lvl != 3:
+            px *= 4
+            f += 2 * px * 9 * cin * cin
+    f += 2 * px * 9 * 128 * 3
+    return f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="images to time (one step = one 50-step image)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--txt-tokens", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--cpu-baseline-tokens", type=int, default=0, help="override L of the CPU sample (debug)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import diffusion_rs_amd as d
+    from diffusion_rs_amd import _lib as L
+    from diffusion_rs_amd import synth
+    lib = L.load()
+    dev = torch.device("cuda", local_rank)
+
+    # ---------------- model: random-init FLUX.1-dev + FLUX VAE; rank 0 generates, RCCL broadcasts
+    t_load = time.time()
+    flux = d.FluxModel(d.FLUX_DEV, local_rank)
+    vae = d.AutoEncoderKl(d.VAE_FLUX, local_rank)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    for name, shape in synth.flux_tensor_shapes(d.FLUX_DEV).items():
+        if rank == 0:
+            if "norm_q" in name or "norm_k" in name or "norm_added" in name:
+                t = torch.ones(shape, dtype=torch.bfloat16, device=dev)
+            elif name.endswith(".bias"):
+                t = torch.zeros(shape, dtype=torch.bfloat16, device=dev)
+            else:
+                t = torch.randn(shape, generator=g, device=dev, dtype=torch.bfloat16)
+                t.mul_(synth._std_for(name, 0.02, 0.01))
+        else:
+            t = torch.empty(shape, dtype=torch.bfloat16, device=dev)
+        if world > 1:
+            dist.broadcast(t, src=0)
+        flux.set_tensor(name, t)
+        del t
+    flux.assert_complete()
+    if world > 1:
+        vsd = {}
+        for name, shape in synth.vae_tensor_shapes(d.VAE_FLUX).items():
+            if len(shape) in (2, 4):
+                fan = int(np.prod(shape[1:]))
+                t = (torch.randn(shape, generator=g, device=dev) / fan ** 0.5) if rank == 0 else torch.empty(shape, device=dev)
+            elif "norm" in name and name.endswith(".weight"):
+                t = torch.ones(shape, device=dev)
+            else:
+                t = torch.zeros(shape, device=dev)
+            dist.broadcast(t, src=0)
+            vae.set_tensor(name, t)
+    else:
+        synth.fill_vae_random_device(vae, seed=1, device=dev)
+    torch.cuda.synchronize()
+    load_s = time.time() - t_load
+
+    # ---------------- synthetic inputs resident in HBM (per rank: its own prompt / seed)
+    H, W, NS, T = args.height, args.width, args.denoise_steps, args.txt_tokens
+    h, w = (H + 15) // 16 * 2, (W + 15) // 16 * 2
+    S = (h // 2) * (w // 2)
+    B = 1
+    gi = torch.Generator(device=dev)
+    gi.manual_seed(1234 + rank)
+    txt = torch.randn((B, T, 4096), generator=gi, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    y = torch.randn((B, 768), generator=gi, device=dev, dtype=torch.float32)
+    guidance = torch.full((B,), 3.5, dtype=torch.float32, device=dev)
+    txt_ids = torch.zeros((B, T, 3), dtype=torch.float32, device=dev)
+    sched = d.SchedulerConfig()
+    timesteps = sched.get_timesteps(NS, sched.calculate_shift(S))
+
+    def one_image(i):
+        lat = d.randn_latents(B, 16, h, w, seed=1234, first_sample=rank + world * i, device=dev)
+        img, img_ids = d.pack_latents(lat)
+        img = flux.denoise(img, img_ids, txt, txt_ids, y, guidance, timesteps)
+        z = d.unpack_latents(img, 16, h, w, vae.scale_factor(), vae.shift_factor())
+        return d.postprocess_u8(vae.decode(z))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        u8 = one_image(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        u8 = one_image(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    finite = bool(torch.isfinite(u8.float()).all().item()) and int(u8.max()) > int(u8.min())
+
+    # gather the decoded images to rank 0 (outside the timed region; 3 MB/sample over xGMI)
+    if world > 1:
+        gl = [torch.empty_like(u8) for _ in range(world)] if rank == 0 else None
+        dist.gather(u8, gl, dst=0)
+
+    # ---------------- profiled pass: per-phase hipEvent timing on the launch stream
+    roof = None
+    extra = {}
+    if rank == 0 and not args.no_profile_pass:
+        nprof = min(NS, 4)
+        fl = step_flops(S, T, B)
+        lat = d.randn_latents(B, 16, h, w, seed=99, device=dev)
+        img, img_ids = d.pack_latents(lat)
+        flux.set_profiling(True)
+        flux.denoise(img, img_ids, txt, txt_ids, y, guidance, timesteps[:nprof + 1])
+        torch.cuda.synchronize()
+        ph = {k: v / nprof for k, v in flux.phase_ms().items()}
+        flux.set_profiling(False)
+        gemm_ms = ph["gemm_qkv"] + ph["gemm_proj"] + ph["gemm_mlp"]
+        gemm_launches = N_DOUBLE * 4 + N_SINGLE * 2
+        gemm_fl = fl["gemm"] - (2 * S * 64 * D_HID + 2 * T * 4096 * D_HID + 2 * S * D_HID * 64)
+        ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<0,2> (bf16 MFMA GEMM, all block linears)", "achieved": round(ach, 1), "peak": 2500.0,
+                "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
+                "launches_per_step": gemm_launches, "avg_launch_ms": round(gemm_ms / gemm_launches, 4),
+                "flop_per_launch_avg": gemm_fl / gemm_launches, "measured_on": f"profiled pass, {nprof} denoise steps, hipEvents on the launch stream"}
+        attn_ach = fl["attn"] / (ph["attention"] * 1e-3) / 1e12
+        extra["phase_ms_per_denoise_step"] = {k: round(v, 3) for k, v in ph.items()}
+        extra["attention_tflops"] = round(attn_ach, 1)
+        extra["step_flops"] = fl
+        # VAE decode timing
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        z = d.unpack_latents(img, 16, h, w, vae.scale_factor(), vae.shift_factor())
+        torch.cuda.synchronize()
+        e0.record()
+        vae.decode(z)
+        e1.record()
+        torch.cuda.synchronize()
+        extra["vae_decode_ms"] = round(e0.elapsed_time(e1), 2)
+        extra["vae_tflops"] = round(vae_flops(h, w) / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+
+    # ---------------- CPU baseline (rank 0, N=1 only): oracle = port of the reference CPU semantics
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        Lc = args.cpu_baseline_tokens or (S + T)
+        cfg1 = dict(d.FLUX_DEV, num_layers=0, num_single_layers=1)
+        om = orc.Flux(cfg1)
+        rng = np.random.default_rng(0)
+        Dh = D_HID
+        p = "single_transformer_blocks.0."
+        for name, shape in synth.flux_tensor_shapes(cfg1).items():
+            if name.startswith(p):
+                a = rng.standard_normal(shape, dtype=np.float32) * (0.01 if "norm.linear" in name else 0.02)
+                if "norm_q" in name or "norm_k" in name:
+                    a = np.ones(shape, np.float32)
+                om.set_tensor(name, a)
+        x = rng.standard_normal((1, Lc, Dh), dtype=np.float32)
+        vec = rng.standard_normal((1, Dh), dtype=np.float32)
+        ids = np.zeros((Lc, 3), np.float32)
+        ids[T:, 1] = np.arange(Lc - T) // max(1, (w // 2)) if Lc > T else 0
+        pe = orc.rope_table(ids, [16, 56, 56], 10000)[None]
+        tc = time.perf_counter()
+        om.single_block(0, x, vec, pe)
+        cpu_s = time.perf_counter() - tc
+        blk_fl = 24 * Dh * Dh * Lc + 4 * Lc * Lc * Dh
+        img_fl = step_flops(S, T)["total"] * NS + vae_flops(h, w)
+        cpu_ips = 1.0 / (cpu_s * img_fl / blk_fl)
+        cpu = {"value": cpu_ips, "unit": "images/s", "cores": orc.get_threads(), "kind": "port",
+               "gflops": round(blk_fl / cpu_s / 1e9, 1),
+               "sample": f"one SingleStreamBlock at the full shape (L={Lc}, D=3072, f32, {blk_fl / 1e12:.2f} TFLOP) timed in {cpu_s:.1f} s on "
+                         f"{orc.get_threads()} host threads, extrapolated to one image ({img_fl / 1e15:.2f} PFLOP) by algorithmic FLOPs; "
+                         "restatement of the reference CPU semantics (oracle/), not the reference binary"}
+
+    if rank == 0:
+        ms_per_image = elapsed / args.steps * 1e3
+        total_images = args.steps * world * B
+        out = {
+            "metric": "images/sec, FLUX.1-dev 1024x1024 50-step" if (H, W, NS) == (1024, 1024, 50) else f"images/sec, FLUX.1-dev {W}x{H} {NS}-step",
+            "value": total_images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (random-init FLUX.1-dev + FLUX VAE weights, N(0,1) embeddings, Philox latents)",
+            "config": {"workload": f"FLUX.1-dev bf16 {W}x{H} {NS}-step, batch=1 per GPU, S={S} img + T={T} txt tokens, step = one image "
+                                   "(50x Flux::forward + Euler, unpack, VAE decode, u8)",
+                       "global_batch": world * B, "parallelism": f"batch-sharded x{world}" if world > 1 else "single GPU"},
+            "ms_per_denoise_step": round((ms_per_image - extra.get("vae_decode_ms", 0.0)) / NS, 2),
+            "ms_per_image": round(ms_per_image, 1),
+            "output_ok": finite, "load_s": round(load_s, 1),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,10 @@ struct bf16_bits {
 };
 template <>
 __device__ __forceinline__ half_bits cvt_out<half_bits>(float v) {
+  // The reference rounds the f32 product to f32 and THEN to f16 (two roundings, dequant.cu:136-151).
+  // Without this barrier the backend folds fmul+fptrunc into v_fma_mixlo_f16 (one rounding) and
+  // 1 value in ~20k differs by an f16 ulp.
+  asm volatile("" : "+v"(v));
   return half_bits{f32_to_f16(v)};
 }
 template <>
