@@ -27,6 +27,8 @@
 //     "dequant as an LDS stage" of BASELINE.json's north star.
 //   * CONV: the A-tile row is an output pixel, the K tile a (tap, 64-channel) slice of an NHWC
 //     image; padding taps read a zero line, a nearest-2x upsample is folded into the gather.
+#include <type_traits>
+
 #include "common.h"
 
 namespace fmi {
@@ -131,7 +133,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   const GemmProblem& P = batch.p[pi];
   const int t = lid - batch.tile_start[pi];
   const int tiles_m = (P.M + BM - 1) / BM;
-  const int tm = t % tiles_m, tn = t / tiles_m;
+  const int tiles_n = (P.N + BN - 1) / BN;
+  // Logical ids walk bands of GH tile-rows column by column, so the ~32 tiles an XCD runs at any
+  // time form a compact GH x 4 patch: 12 distinct A/W panels per K step instead of 20 (L2 hits).
+  constexpr int GH = 8;
+  const int band = t / (GH * tiles_n);
+  const int band_h = min(GH, tiles_m - band * GH);
+  const int tin = t - band * GH * tiles_n;
+  const int tn = tin / band_h, tm = band * GH + tin % band_h;
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = P.K / BK;
 
@@ -169,6 +178,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
       cv_base[i] = (int64_t)b * P.cv_h * P.cv_w;
     }
   }
+  // per-lane DMA source pointers, hoisted out of the K loop: this lane stages tile rows
+  // chunk*8 + (lane>>3) (1-KiB chunk = 8 rows), 16-B slot (lane&7) ^ ((row>>1)&7) of each row
+  constexpr int CPWN = BN / 64;
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[CPWN];
+  if (MODE != 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 8 + (lane >> 3);
+      const int g = min(m0 + row, P.M - 1);
+      a_src[i] = P.A + (int64_t)g * P.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    }
+  }
+  if (MODE != 1) {
+#pragma unroll
+    for (int i = 0; i < CPWN; ++i) {
+      const int row = (wave * CPWN + i) * 8 + (lane >> 3);
+      const int g = min(n0 + row, P.N - 1);
+      w_src[i] = P.W + (int64_t)g * P.ldw + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    }
+  }
   auto stage_a = [&](int kt, char* dst) {
     if (MODE == 2) {
       const int cpt = P.cv_cin >> 6;  // 64-channel slices per tap
@@ -191,28 +221,49 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + chunk * 1024), 16, 0, 0);
       }
     } else {
-      stage_tile_dma<BM>(P.A, P.lda, m0, P.M - 1, kt * BK, dst, wave, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void*)(a_src[i] + kt * BK), (lds_void*)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
     }
   };
   auto stage_w = [&](int kt, char* dst) {
-    if (MODE == 1)
+    if (MODE == 1) {
       stage_tile_q4<BN>(P, n0, kt * BK, dst, tid);
-    else
-      stage_tile_dma<BN>(P.W, P.ldw, n0, P.N - 1, kt * BK, dst, wave, lane);
+    } else {
+#pragma unroll
+      for (int i = 0; i < CPWN; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void*)(w_src[i] + kt * BK), (lds_void*)(dst + (wave * CPWN + i) * 1024), 16, 0, 0);
+    }
   };
 
   stage_a(0, bufA(0));
   stage_w(0, bufW(0));
 
-  for (int kt = 0; kt < nk; ++kt) {
+  // One 1-KiB piece (8 rows) of tile `kt` into buffer `buf`: pieces 0..3 are A, the rest W.
+  auto dma_piece = [&](int kt, int d, int buf) {
+    if (d < 4)
+      __builtin_amdgcn_global_load_lds((glb_void*)(a_src[d] + kt * BK), (lds_void*)(bufA(buf) + (wave * 4 + d) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((glb_void*)(w_src[d - 4] + kt * BK), (lds_void*)(bufW(buf) + (wave * CPWN + d - 4) * 1024), 16, 0, 0);
+  };
+  // Dense GEMM: the DMA pieces of tile kt+1 are issued one at a time BETWEEN the MFMAs of the
+  // first two k-steps of tile kt (an LDS-DMA costs ~60 cycles among MFMAs but 100-185 in a burst,
+  // and a burst leaves the matrix pipe of the SIMD idle because both of its waves burst together);
+  // the last two k-steps give the pieces time to land before the next barrier.
+  constexpr bool INTERLEAVE = (MODE == 0);
+  auto ktile = [&](int kt, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
     const int cur = kt & 1;
     __syncthreads();  // tile kt landed for every wave; everyone finished reading buf[cur^1]
-    if (kt + 1 < nk) {
+#ifndef FMI_ABLATE_NO_LOAD
+    if (MORE && !INTERLEAVE) {
       stage_a(kt + 1, bufA(cur ^ 1));
       stage_w(kt + 1, bufW(cur ^ 1));
     }
+#endif
     const char* la = bufA(cur) + a_row_off;
     const char* lw = bufW(cur) + w_row_off;
+#ifndef FMI_ABLATE_NO_MFMA
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       bf16x8_t xf[4], wf[NJ];
@@ -221,18 +272,152 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
 #pragma unroll
       for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(la + i * 32 * 128 + koff[s]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+#ifndef FMI_ABLATE_NO_LOAD
+#ifdef FMI_ABLATE_HALF_LOAD
+        if (MORE && INTERLEAVE && s * 4 + i < 4) dma_piece(kt + 1, s * 4 + i, cur ^ 1);  // A pieces only
+#else
+        if (MORE && INTERLEAVE && s * 4 + i < 4 + CPWN) dma_piece(kt + 1, s * 4 + i, cur ^ 1);
+#endif
+#endif
+      }
     }
-  }
+#else
+    acc[0][0][0] += *reinterpret_cast<const float*>(la + koff[0]);  // keep the tile "used"
+#ifndef FMI_ABLATE_NO_LOAD
+    if (MORE && INTERLEAVE) {
+      stage_a(kt + 1, bufA(cur ^ 1));
+      stage_w(kt + 1, bufW(cur ^ 1));
+    }
+#endif
+#endif
+  };
+  for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
+  ktile(nk - 1, std::false_type{});
 
   // ---- epilogue: lane holds row m = ..+(lane&31), columns n = ..+8q+4(lane>>5)+{0..3}
   const int epi = P.epi;
   const float alpha = P.alpha;
+  const int hl = lane >> 5, l31 = lane & 31;
+  // alpha, bias, activation on 4 consecutive columns starting at n
+  auto finish = [&](int n, float (&v)[4], bool full) {
+    if (epi == EPI_STORE_F32 || epi == EPI_SCALE_BF16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= alpha;
+    }
+    if (P.bias) {
+      if (full) {
+        const uint2 b = *reinterpret_cast<const uint2*>(P.bias + n);
+        v[0] += bf16_to_f32((bf16_t)(b.x & 0xffff));
+        v[1] += bf16_to_f32((bf16_t)(b.x >> 16));
+        v[2] += bf16_to_f32((bf16_t)(b.y & 0xffff));
+        v[3] += bf16_to_f32((bf16_t)(b.y >> 16));
+      } else {
+        for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(P.bias[n + e]);
+      }
+    }
+    if (epi == EPI_GELU_BF16 || (epi == EPI_GELU_FROM_COL && n >= P.gelu_from)) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+    } else if (epi == EPI_SILU_BF16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
+    }
+  };
+  const bool f32_out = (epi == EPI_RESID_GATE_F32 || epi == EPI_STORE_F32);
+#ifdef FMI_ABLATE_NO_EPI
+  if (alpha != 12345.f) return;  // ablation: skip the stores but keep the accumulators live
+#endif
+  // Staged path: the C tile goes through LDS (free after the K loop) and leaves as whole 128-B
+  // (bf16) / 256-B (f32) row segments with 16-B stores.  Direct per-lane stores touch 32 partial
+  // cache lines per instruction and cost ~30 us per tile with nothing else resident on the CU.
+  const bool staged = (P.ldo % 8 == 0) && (n0 + BN <= P.N) && ((reinterpret_cast<uintptr_t>(P.out) & 15) == 0) && epi != EPI_RESID_ADD_BF16 &&
+                      (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias) & 7) == 0);
+  if (staged) {
+    __syncthreads();  // every wave is done with the operand tiles
+    char* cw = smem + wave * (8192 * NJ);  // wave-private staging region
+    const int ncol0 = n0 + wn * 32 * NJ;
+    if (!f32_out) {
+      constexpr int RB = 64 * NJ;   // bytes per staged row (32*NJ bf16)
+      constexpr int NS8 = 8 * NJ;   // 8-byte slots per row
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+            finish(ncol0 + j * 32 + q * 8 + 4 * hl, v, true);
+            const int r = i * 32 + l31, c = j * 8 + q * 2 + hl;
+            *reinterpret_cast<uint2*>(cw + r * RB + ((c ^ (r & (NS8 - 1))) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int LPR = RB / 16, RPI = 64 / LPR;  // lanes per row, rows per wave-instruction
+      bf16_t* ob = reinterpret_cast<bf16_t*>(P.out);
+#pragma unroll
+      for (int it = 0; it < 128 / RPI; ++it) {
+        const int r = it * RPI + lane / LPR, ch = lane % LPR;
+        const int sp = ((2 * ch) ^ (r & (NS8 - 1))) & ~1;
+        uint4 d = *reinterpret_cast<const uint4*>(cw + r * RB + (sp << 3));
+        if (r & 1) d = make_uint4(d.z, d.w, d.x, d.y);  // odd rows hold the slot pair swapped
+        const int m = m0 + wm * 128 + r;
+        if (m < P.M) *reinterpret_cast<uint4*>(ob + (int64_t)m * P.ldo + ncol0 + ch * 8) = d;
+      }
+    } else {
+      constexpr int RBF = 128 * NJ;  // bytes per staged row (32*NJ f32)
+      constexpr int NS16 = 8 * NJ;   // 16-byte slots per row
+      constexpr int LPR = RBF / 16, RPI = 64 / LPR;
+      float* of = reinterpret_cast<float*>(P.out);
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[pass * 2 + ii][j][q * 4 + e];
+              finish(ncol0 + j * 32 + q * 8 + 4 * hl, v, true);
+              const int r = ii * 32 + l31, c = j * 8 + q * 2 + hl;
+              *reinterpret_cast<float4*>(cw + r * RBF + ((c ^ (r & (NS16 - 1))) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 64 / RPI; ++it) {
+          const int r = it * RPI + lane / LPR, ch = lane % LPR;
+          const float4 v = *reinterpret_cast<const float4*>(cw + r * RBF + ((ch ^ (r & (NS16 - 1))) << 4));
+          const int m = m0 + wm * 128 + pass * 64 + r, n = ncol0 + ch * 4;
+          if (m < P.M) {
+            float* o = of + (int64_t)m * P.ldo + n;
+            if (epi == EPI_RESID_GATE_F32) {
+              const float* gate = P.gate + (P.rows_per_batch > 0 ? (int64_t)(m / P.rows_per_batch) * P.gate_bstride : 0);
+              const float4 g = *reinterpret_cast<const float4*>(gate + n);
+              float4 x = *reinterpret_cast<float4*>(o);
+              x.x += g.x * v.x;
+              x.y += g.y * v.y;
+              x.z += g.z * v.z;
+              x.w += g.w * v.w;
+              *reinterpret_cast<float4*>(o) = x;
+            } else {
+              *reinterpret_cast<float4*>(o) = v;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+  // ---- direct path (ragged N tile, unaligned output, bf16 residual add)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 128 + i * 32 + (lane & 31);
+    const int m = m0 + wm * 128 + i * 32 + l31;
     if (m >= P.M) continue;
     const float* gate = P.gate;
     if (epi == EPI_RESID_GATE_F32 && P.rows_per_batch > 0) gate += (int64_t)(m / P.rows_per_batch) * P.gate_bstride;
@@ -240,65 +425,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 32 * NJ + j * 32 + q * 8 + 4 * (lane >> 5);
+        const int n = n0 + wn * 32 * NJ + j * 32 + q * 8 + 4 * hl;
         if (n >= P.N) continue;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-        const bool full = (n + 3 < P.N);
-        if (epi == EPI_STORE_F32 || epi == EPI_SCALE_BF16) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= alpha;
-        }
-        if (P.bias) {
-          if (full) {
-            const uint2 b = *reinterpret_cast<const uint2*>(P.bias + n);
-            v[0] += bf16_to_f32((bf16_t)(b.x & 0xffff));
-            v[1] += bf16_to_f32((bf16_t)(b.x >> 16));
-            v[2] += bf16_to_f32((bf16_t)(b.y & 0xffff));
-            v[3] += bf16_to_f32((bf16_t)(b.y >> 16));
-          } else {
-            for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(P.bias[n + e]);
-          }
-        }
-        if (epi == EPI_GELU_BF16 || (epi == EPI_GELU_FROM_COL && n >= P.gelu_from)) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-        } else if (epi == EPI_SILU_BF16) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
-        }
+        const bool full = (n + 3 < P.N) && (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias + n) & 7) == 0);
+        finish(n, v, full);
         if (epi == EPI_RESID_GATE_F32) {
           float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
-          if (full) {
-            const float4 g = *reinterpret_cast<const float4*>(gate + n);
-            float4 x = *reinterpret_cast<float4*>(o);
-            x.x += g.x * v[0];
-            x.y += g.y * v[1];
-            x.z += g.z * v[2];
-            x.w += g.w * v[3];
-            *reinterpret_cast<float4*>(o) = x;
-          } else {
-            for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] += gate[n + e] * v[e];
-          }
+          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] += gate[n + e] * v[e];
         } else if (epi == EPI_STORE_F32) {
           float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
-          if (full) {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = v[e];
-          }
+          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = v[e];
         } else {
           bf16_t* o = reinterpret_cast<bf16_t*>(P.out) + (int64_t)m * P.ldo + n;
           if (epi == EPI_RESID_ADD_BF16) {
             const bf16_t* r = reinterpret_cast<const bf16_t*>(P.resid) + (int64_t)m * P.ldo + n;
             for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(r[e]);
           }
-          if (full && (P.ldo & 3) == 0) {
-            *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-          } else {
-            for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = f32_to_bf16(v[e]);
-          }
+          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = f32_to_bf16(v[e]);
         }
       }
     }
@@ -324,9 +470,6 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
     if (quant && conv) return fail(FMI_ERR_UNSUPPORTED, "launch_gemm: quantised convolution");
     if ((!conv && p.lda % 8) || (!quant && p.ldw % 8)) return fail(FMI_ERR_INVALID, "launch_gemm: lda/ldw must be multiples of 8 elements (16-byte rows)");
     if (conv && (p.cv_cin % 64 || p.K != p.cv_ks * p.cv_ks * p.cv_cin || !p.cv_zero)) return fail(FMI_ERR_INVALID, "launch_gemm: bad conv descriptor (Cin % 64, K = k*k*Cin)");
-    if (p.epi != EPI_STORE_BF16 && p.epi != EPI_GELU_BF16 && p.epi != EPI_GELU_FROM_COL && p.epi != EPI_SCALE_BF16 && p.epi != EPI_RESID_ADD_BF16 &&
-        p.epi != EPI_SILU_BF16 && p.ldo % 4)
-      return fail(FMI_ERR_INVALID, "launch_gemm: f32 outputs need ldo % 4 == 0");
     if (quant && (p.q_blocksize % 64 != 0 || p.q_blocksize <= 0)) return fail(FMI_ERR_INVALID, "launch_gemm: 4-bit blocksize must be a multiple of 64");
     b.p[i] = p;
     b.tile_start[i] = total;

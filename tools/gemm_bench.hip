@@ -1,0 +1,68 @@
+// tools/gemm_bench.hip — standalone micro-benchmark / ablation harness for the bf16 GEMM.
+// Build variants with -DFMI_ABLATE_NO_LOAD / -DFMI_ABLATE_NO_MFMA (see tools/run_gemm_bench.sh).
+// Prints TFLOP/s per FLUX shape on random bf16 data (never zero-filled: DVFS, cdna guide rule 25).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../diffusion-rs_amd/csrc/gemm_bf16.hip"
+
+namespace fmi {
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+int fail(fmi_status st, const std::string& m) {
+  g_err = m;
+  fprintf(stderr, "error: %s\n", m.c_str());
+  return (int)st;
+}
+}  // namespace fmi
+using namespace fmi;
+
+__global__ void fill_kernel(bf16_t* p, size_t n, uint32_t seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+    float f = ((float)(x & 0xffff) / 32768.0f - 1.0f);  // uniform [-1,1)
+    p[i] = f32_to_bf16(f);
+  }
+}
+
+int main(int argc, char** argv) {
+  struct Shape { int M, N, K; const char* name; };
+  std::vector<Shape> shapes = {{4608, 21504, 3072, "single qkv+mlp"}, {4608, 3072, 15360, "single proj_out"}, {4096, 9216, 3072, "double qkv img"},
+                               {4096, 12288, 3072, "double mlp1 img"}, {4096, 3072, 12288, "double mlp2 img"}, {4096, 3072, 3072, "double proj img"},
+                               {512, 9216, 3072, "double qkv txt"}, {8192, 8192, 8192, "8k cube"}};
+  int iters = argc > 1 ? atoi(argv[1]) : 10;
+  size_t maxA = 0, maxW = 0, maxO = 0;
+  for (auto& s : shapes) {
+    maxA = std::max(maxA, (size_t)s.M * s.K);
+    maxW = std::max(maxW, (size_t)s.N * s.K);
+    maxO = std::max(maxO, (size_t)s.M * s.N);
+  }
+  bf16_t *A, *W, *O;
+  hipMalloc((void**)&A, maxA * 2);
+  hipMalloc((void**)&W, maxW * 2);
+  hipMalloc((void**)&O, maxO * 2);
+  fill_kernel<<<2048, 256>>>(A, maxA, 1u);
+  fill_kernel<<<2048, 256>>>(W, maxW, 2u);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (auto& s : shapes) {
+    GemmProblem p{};
+    p.A = A, p.W = W, p.out = O, p.M = s.M, p.N = s.N, p.K = s.K, p.lda = s.K, p.ldw = s.K, p.ldo = s.N, p.epi = EPI_STORE_BF16, p.alpha = 1.f;
+    for (int i = 0; i < 2; ++i) launch_gemm(&p, 1, nullptr);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) launch_gemm(&p, 1, nullptr);
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= iters;
+    double tf = 2.0 * s.M * s.N * s.K / (ms * 1e-3) / 1e12;
+    printf("%-18s M=%5d N=%5d K=%5d  %8.3f ms  %7.1f TF\n", s.name, s.M, s.N, s.K, ms, tf);
+  }
+  return 0;
+}
