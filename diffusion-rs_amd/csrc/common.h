@@ -30,16 +30,19 @@ int fail(fmi_status st, const std::string& msg);
 typedef uint16_t bf16_t;  // raw bits
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, NaN preserved (same rule as half::bf16::from_f32)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even (same rule as half::bf16::from_f32) on the hardware converter:
+// the fptrunc selects v_cvt_pk_bf16_f32 on gfx950 (a software RNE + NaN branch costs ~10
+// instructions and an exec-mask diamond per element — it was 2/3 of the attention loop's VALU work).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  uint32_t u;
+  __builtin_memcpy(&u, &r, 4);
+  return u;
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float f16_to_f32(uint16_t h) {
   _Float16 v;
   __builtin_memcpy(&v, &h, 2);
