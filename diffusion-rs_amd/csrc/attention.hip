@@ -81,9 +81,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
 #pragma unroll
   for (int c = 0; c < 8; ++c) v_off[c] = l31 * 128 + ((c ^ ((l31 >> 1) & 7)) << 4);
 
-  auto stage = [&](int tile, int buf) {
-    char* kd = smem + buf * 32768;
-    char* vd = kd + 16384;
+  // LDS: K ring [2][64x128] at 0 / 16K, Vt ring [2][128x64] at 32K / 48K
+  auto stage_k = [&](int tile, int buf) {
+    char* kd = smem + buf * 16384;
     const int kv0 = tile * ATT_KV;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -94,6 +94,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
       const bf16_t* src = Kb + (int64_t)kr * HD + (((lane & 15) ^ (row & 15)) << 3);
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(kd + chunk * 1024), 16, 0, 0);
     }
+  };
+  auto stage_v = [&](int tile, int buf) {
+    char* vd = smem + 32768 + buf * 16384;
+    const int kv0 = tile * ATT_KV;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int chunk = wave * 2 + i;  // 16 chunks of 8 Vt rows
@@ -102,18 +106,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
       __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(vd + chunk * 1024), 16, 0, 0);
     }
   };
-
-  const int ntiles = (Lk + ATT_KV - 1) / ATT_KV;
-  stage(0, 0);
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    __syncthreads();
-    if (t + 1 < ntiles) stage(t + 1, cur ^ 1);
-    const char* kl = smem + cur * 32768;
-    const char* vl = kl + 16384;
-
-    // ---- Sᵀ = K Qᵀ : two 32-kv sub-tiles
-    f32x16 st[2];
+  // Sᵀ = K Qᵀ for one 64-kv tile: two 32-kv sub-tiles, 16 MFMAs
+  auto qk = [&](f32x16 (&st)[2], int buf) {
+    const char* kl = smem + buf * 16384;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -124,6 +119,19 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
         st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[u], 0, 0, 0);
       }
     }
+  };
+
+  const int ntiles = (Lk + ATT_KV - 1) / ATT_KV;
+  // Software pipeline: iteration t issues the 16 QKᵀ MFMAs of tile t+1 BEFORE the softmax of tile t,
+  // so the matrix pipe works through them while this wave's VALU does max/exp2/sum/convert (MFMA
+  // and VALU are separate pipes; in the straight-line order every wave of the workgroup did its
+  // softmax at the same time with the matrix pipe idle).  K and Vt therefore run on separate
+  // double-buffered rings: at iteration t the K ring holds tiles t+1 / t+2, the Vt ring t / t+1.
+  auto body = [&](int t, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
+    __syncthreads();  // K(t+1), Vt(t) landed; every wave finished iteration t-1
+    if (t + 2 < ntiles) stage_k(t + 2, t & 1);
+    if (t + 1 < ntiles) stage_v(t + 1, (t + 1) & 1);
+    if (t + 1 < ntiles) qk(sn, (t + 1) & 1);
     // ---- mask the ragged tail (kv >= Lk); kv_local = 32u + (r&3) + 8(r>>2) + 4hl
     if ((t + 1) * ATT_KV > Lk) {
       const int kvb = t * ATT_KV + 4 * hl;
@@ -131,14 +139,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kvb + 32 * u + (r & 3) + 8 * (r >> 2) >= Lk) st[u][r] = -1e30f;
+          if (kvb + 32 * u + (r & 3) + 8 * (r >> 2) >= Lk) sc[u][r] = -1e30f;
     }
     // ---- online softmax (exp2 domain), lane-local row
-    float pmax = st[0][0];
+    float pmax = sc[0][0];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pmax = fmaxf(pmax, st[u][r]);
+      for (int r = 0; r < 16; ++r) pmax = fmaxf(pmax, sc[u][r]);
     pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
     const float ps = pmax * scale_log2e;
     if (__any(ps - m_run > (float)THR_X16 * 0.0625f)) {
@@ -158,8 +166,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
       uint32_t pk[8];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float p0 = fast_exp2(st[u][r] * scale_log2e - m_run);
-        const float p1 = fast_exp2(st[u][r + 1] * scale_log2e - m_run);
+        const float p0 = fast_exp2(sc[u][r] * scale_log2e - m_run);
+        const float p1 = fast_exp2(sc[u][r + 1] * scale_log2e - m_run);
         lsum += p0 + p1;
         pk[r >> 1] = pack_bf16x2(p0, p1);
       }
@@ -170,6 +178,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
     }
     l_run += lsum;
     // ---- Oᵀ += Vᵀ Pᵀ : k-slot (hl,e) of step (u,w) <-> Vt position 32u + 16w + 8hl + e
+    const char* vl = smem + 32768 + (t & 1) * 16384;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
@@ -178,6 +187,17 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
         ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c], ot[dt], 0, 0, 0);
       }
     }
+  };
+
+  f32x16 sa[2], sb[2];
+  stage_k(0, 0);
+  stage_v(0, 0);
+  if (ntiles > 1) stage_k(1, 1);
+  __syncthreads();
+  qk(sa, 0);
+  for (int t = 0; t < ntiles; t += 2) {
+    body(t, sa, sb);
+    if (t + 1 < ntiles) body(t + 1, sb, sa);
   }
 
   // ---- epilogue: O[q][d] = Oᵀ / l ; d = 32dt + (r&3) + 8(r>>2) + 4hl
