@@ -33,6 +33,13 @@
 
 namespace fmi {
 
+// cache-policy bits of the A / W LDS-DMA streams (0 = default, 2 = nt); tuning knobs
+#ifndef FMI_AUX_A
+#define FMI_AUX_A 0
+#endif
+#ifndef FMI_AUX_W
+#define FMI_AUX_W 0
+#endif
 constexpr int BM = 256, BK = 64;
 constexpr int GEMM_THREADS = 512;
 constexpr int A_TILE_BYTES = BM * BK * 2;  // 32 KiB
@@ -136,7 +143,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   const int tiles_n = (P.N + BN - 1) / BN;
   // Logical ids walk bands of GH tile-rows column by column, so the ~32 tiles an XCD runs at any
   // time form a compact GH x 4 patch: 12 distinct A/W panels per K step instead of 20 (L2 hits).
-  constexpr int GH = 8;
+#ifndef FMI_GH
+#define FMI_GH 8
+#endif
+  constexpr int GH = FMI_GH;
   const int band = t / (GH * tiles_n);
   const int band_h = min(GH, tiles_m - band * GH);
   const int tin = t - band * GH * tiles_n;
@@ -242,9 +252,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   // One 1-KiB piece (8 rows) of tile `kt` into buffer `buf`: pieces 0..3 are A, the rest W.
   auto dma_piece = [&](int kt, int d, int buf) {
     if (d < 4)
-      __builtin_amdgcn_global_load_lds((glb_void*)(a_src[d] + kt * BK), (lds_void*)(bufA(buf) + (wave * 4 + d) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(a_src[d] + kt * BK), (lds_void*)(bufA(buf) + (wave * 4 + d) * 1024), 16, 0, FMI_AUX_A);
     else
-      __builtin_amdgcn_global_load_lds((glb_void*)(w_src[d - 4] + kt * BK), (lds_void*)(bufW(buf) + (wave * CPWN + d - 4) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(w_src[d - 4] + kt * BK), (lds_void*)(bufW(buf) + (wave * CPWN + d - 4) * 1024), 16, 0, FMI_AUX_W);
   };
   // Dense GEMM: the DMA pieces of tile kt+1 are issued one at a time BETWEEN the MFMAs of the
   // first two k-steps of tile kt (an LDS-DMA costs ~60 cycles among MFMAs but 100-185 in a burst,

@@ -52,17 +52,16 @@ __global__ void conv_weight_relayout_kernel(const bf16_t* __restrict w, bf16_t* 
 constexpr int GN_PIX_PER_BLOCK = 1024;
 // partial[(b*nchunks + chunk)*G + g] = {sum, sumsq} over the chunk's pixels; requires C%8==0, cpg%4==0
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict x, float2* __restrict partial, int HW, int C, int G) {
-  extern __shared__ float lds[];  // [G][2]
+  __shared__ float4 part[256];  // per-thread {sum_lo, sumsq_lo, sum_hi, sumsq_hi} (channels 0-3 / 4-7 of its 8)
   const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
-  for (int i = threadIdx.x; i < 2 * G; i += 256) lds[i] = 0.f;
-  __syncthreads();
   const int tpp = C >> 3;  // threads per pixel
   const int cpg = C / G;
   const int c8 = threadIdx.x % tpp;
   const int pstep = 256 / tpp;
+  const int nact = tpp * pstep;
   const int p0 = chunk * GN_PIX_PER_BLOCK, p1 = min(HW, p0 + GN_PIX_PER_BLOCK);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-  if (threadIdx.x < tpp * pstep) {
+  if ((int)threadIdx.x < nact) {
     for (int p = p0 + threadIdx.x / tpp; p < p1; p += pstep) {
       const uint4 raw = *reinterpret_cast<const uint4*>(x + ((int64_t)b * HW + p) * C + c8 * 8);
       const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw);
@@ -79,14 +78,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict 
         q1 += v * v;
       }
     }
-    const int g0 = (c8 * 8) / cpg, g1 = (c8 * 8 + 4) / cpg;
-    atomicAdd(&lds[2 * g0], s0);
-    atomicAdd(&lds[2 * g0 + 1], q0);
-    atomicAdd(&lds[2 * g1], s1);
-    atomicAdd(&lds[2 * g1 + 1], q1);
   }
+  part[threadIdx.x] = make_float4(s0, q0, s1, q1);
   __syncthreads();
-  for (int g = threadIdx.x; g < G; g += 256) partial[((int64_t)b * nchunks + chunk) * G + g] = make_float2(lds[2 * g], lds[2 * g + 1]);
+  // fixed-order combine (no atomics: results are bit-reproducible run to run)
+  for (int g = threadIdx.x; g < G; g += 256) {
+    float s = 0.f, q = 0.f;
+    for (int t = 0; t < nact; ++t) {
+      const int tc = (t % tpp) * 8;
+      const float4 v = part[t];
+      if (tc / cpg == g) {
+        s += v.x;
+        q += v.y;
+      }
+      if ((tc + 4) / cpg == g) {
+        s += v.z;
+        q += v.w;
+      }
+    }
+    partial[((int64_t)b * nchunks + chunk) * G + g] = make_float2(s, q);
+  }
 }
 // stats[b*G+g] = {mean, 1/sqrt(var+eps)}; f64 combine of the f32 partials
 __global__ void gn_finalize_kernel(const float2* __restrict partial, float2* __restrict stats, int nchunks, int G, double count, float eps) {
@@ -135,7 +146,7 @@ int launch_groupnorm_nhwc(const bf16_t* x, const float* w, const float* b, bf16_
   if (C % 8 || C % G || (C / G) % 4) return fail(FMI_ERR_UNSUPPORTED, "groupnorm: needs C % 8 == 0 and (C/groups) % 4 == 0");
   if (C / 8 > 256) return fail(FMI_ERR_UNSUPPORTED, "groupnorm: C > 2048 not supported");
   const int nchunks = cdiv(HW, GN_PIX_PER_BLOCK);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 2 * G * sizeof(float), s, x, partial, HW, C, G);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, x, partial, HW, C, G);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, partial, stats, nchunks, G, (double)HW * (C / G), eps);
   const int64_t nvec = (int64_t)B * HW * (C / 8);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(nvec, 256), 256 * 16)), dim3(256), 0, s, x, stats, w, b, out, HW, C, G,
