@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--txt-tokens", type=int, default=512)
+    ap.add_argument("--quant", choices=["none", "nf4"], default="none", help="nf4: block linears stored bitsandbytes-nf4, fused dequant-GEMM (config C3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--cpu-baseline-tokens", type=int, default=0, help="override L of the CPU sample (debug)")
@@ -129,7 +130,12 @@ def main():
             t = torch.empty(shape, dtype=torch.bfloat16, device=dev)
         if world > 1:
             dist.broadcast(t, src=0)
-        flux.set_tensor(name, t)
+        if args.quant == "nf4" and synth.is_block_linear(name):
+            packed, absmax = synth.quantize_nf4_device(t, 64)
+            flux.set_linear_bnb4(name[:-len(".weight")], packed, absmax, 64, "nf4", shape[0], shape[1])
+            del packed, absmax
+        else:
+            flux.set_tensor(name, t)
         del t
     flux.assert_complete()
     if world > 1:
@@ -212,8 +218,15 @@ def main():
         gemm_launches = N_DOUBLE * 4 + N_SINGLE * 2
         gemm_fl = fl["gemm"] - (2 * S * 64 * D_HID + 2 * T * 4096 * D_HID + 2 * S * D_HID * 64)
         ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_summary_latest.json")) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch")
+        except Exception:
+            pass
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<0,2> (bf16 MFMA GEMM, all block linears)", "achieved": round(ach, 1), "peak": 2500.0,
-                "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
+                "traffic_note": "HBM-side bytes per launch = FETCH_SIZE*2 + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/), not re-measured in this run",
                 "launches_per_step": gemm_launches, "avg_launch_ms": round(gemm_ms / gemm_launches, 4),
                 "flop_per_launch_avg": gemm_fl / gemm_launches, "measured_on": f"profiled pass, {nprof} denoise steps, hipEvents on the launch stream"}
         attn_ach = fl["attn"] / (ph["attention"] * 1e-3) / 1e12
@@ -270,7 +283,7 @@ def main():
         out = {
             "metric": "images/sec, FLUX.1-dev 1024x1024 50-step" if (H, W, NS) == (1024, 1024, 50) else f"images/sec, FLUX.1-dev {W}x{H} {NS}-step",
             "value": total_images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.quant == "none" else "bf16 (nf4 weights, fused dequant-GEMM)",
             "data": "synthetic (random-init FLUX.1-dev + FLUX VAE weights, N(0,1) embeddings, Philox latents)",
             "config": {"workload": f"FLUX.1-dev bf16 {W}x{H} {NS}-step, batch=1 per GPU, S={S} img + T={T} txt tokens, step = one image "
                                    "(50x Flux::forward + Euler, unpack, VAE decode, u8)",

@@ -82,6 +82,10 @@ struct fmi_flux {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float phase_ms[PH_COUNT] = {0};
   int attn_thr = 96;
+  // 4-bit weights, large-M regime: per-layer streaming dequant into a reusable bf16 scratch
+  bf16_t* wscratch[2] = {nullptr, nullptr};
+  size_t wscratch_elems = 0;
+  int q_fused_max_rows = 512;  // M below this keeps the fused dequant-GEMM (weight-bandwidth-bound regime)
 };
 
 namespace {
@@ -294,8 +298,39 @@ void with_gate(GemmProblem& p, const float* gate, int rows_per_batch, int bstrid
   p.rows_per_batch = rows_per_batch;
   p.gate_bstride = bstride;
 }
+// 4-bit weights: the fused dequant-GEMM re-expands a weight tile once per M tile, which wins while
+// the GEMM is weight-bandwidth-bound (few M tiles) and loses when it is MFMA-bound (at M = 4608 the
+// fused kernel ran at 456 TFLOP/s vs ~1000 dense).  Above `q_fused_max_rows` rows the weight is
+// dequantised ONCE per call into a reusable bf16 scratch (0.5 B read + 2 B written per weight,
+// HBM-streaming) and the dense MFMA kernel runs — BnbLinear::forward's "dequantize_w then matmul"
+// (bitsandbytes/mod.rs:301-312) without allocating or leaving the device.
+int densify(fmi_flux* m, GemmProblem* p, int n, hipStream_t s) {
+  for (int i = 0; i < n && i < 2; ++i) {
+    if (!p[i].q_type || p[i].M < m->q_fused_max_rows) continue;
+    const size_t elems = (size_t)p[i].N * p[i].K;
+    if (elems > m->wscratch_elems || !m->wscratch[0]) {
+      const size_t want = std::max(elems, (size_t)(3 * m->D + m->M) * (size_t)m->D);  // largest fused weight of the model
+      FMI_HIP_TRY(hipDeviceSynchronize());
+      for (int k = 0; k < 2; ++k) {
+        if (m->wscratch[k]) FMI_HIP_TRY(hipFree(m->wscratch[k]));
+        FMI_HIP_TRY(hipMalloc((void**)&m->wscratch[k], want * sizeof(bf16_t)));
+      }
+      m->wscratch_elems = want;
+    }
+    if (elems >= (1ull << 31)) return fail(FMI_ERR_UNSUPPORTED, "densify: weight too large");
+    if (p[i].q_type == 2)
+      dequantize_blockwise_bf16_nf4(nullptr, p[i].Wq, p[i].absmax, m->wscratch[i], p[i].q_blocksize, (int)elems, s);
+    else
+      dequantize_blockwise_bf16_fp4(nullptr, p[i].Wq, p[i].absmax, m->wscratch[i], p[i].q_blocksize, (int)elems, s);
+    p[i].W = m->wscratch[i];
+    p[i].ldw = p[i].K;
+    p[i].Wq = nullptr, p[i].absmax = nullptr, p[i].q_type = 0, p[i].q_blocksize = 0;
+  }
+  return FMI_OK;
+}
 // launch 1 or 2 problems; quantised and dense problems cannot share a grid
-int gemm2(GemmProblem* p, int n, hipStream_t s) {
+int gemm2(fmi_flux* m, GemmProblem* p, int n, hipStream_t s) {
+  FMI_TRY(densify(m, p, n, s));
   if (n == 2 && (p[0].q_type != 0) != (p[1].q_type != 0)) {
     FMI_TRY(launch_gemm(p, 1, s));
     return launch_gemm(p + 1, 1, s);
@@ -368,7 +403,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     GemmProblem p[2];
     p[0] = make_problem(m->img_in, w.img_bf, C, B * S, w.x_img, D, EPI_STORE_F32);
     p[1] = make_problem(m->txt_in, w.txt_bf, c.joint_attention_dim, B * T, w.x_txt, D, EPI_STORE_F32);
-    FMI_TRY(gemm2(p, 2, s));
+    FMI_TRY(gemm2(m, p, 2, s));
   }
   {
     // every Modulation1/2 + LastLayer.ada_ln of the model in one GEMV: lin(silu(vec)) (model.rs:244-299,695-698)
@@ -393,7 +428,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       GemmProblem p[2];
       p[0] = make_problem(bw.qkv[0], xm_img, D, B * S, w.qkv_img, 3 * D, EPI_STORE_BF16);
       p[1] = make_problem(bw.qkv[1], xm_txt, D, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16);
-      FMI_TRY(gemm2(p, 2, s));
+      FMI_TRY(gemm2(m, p, 2, s));
     }
     {
       PhaseTimer pt(m, s, PH_RELAYOUT);
@@ -417,7 +452,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       with_gate(p[0], mi + 2 * D, S, nmod);
       p[1] = make_problem(bw.proj[1], w.attn_txt, D, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
       with_gate(p[1], mt + 2 * D, T, nmod);
-      FMI_TRY(gemm2(p, 2, s));
+      FMI_TRY(gemm2(m, p, 2, s));
     }
     {
       PhaseTimer pt(m, s, PH_LN);
@@ -431,12 +466,12 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       GemmProblem p[2];
       p[0] = make_problem(bw.mlp1[0], xm_img, D, B * S, hid_img, Mh, EPI_GELU_BF16);
       p[1] = make_problem(bw.mlp1[1], xm_txt, D, B * T, hid_txt, Mh, EPI_GELU_BF16);
-      FMI_TRY(gemm2(p, 2, s));
+      FMI_TRY(gemm2(m, p, 2, s));
       p[0] = make_problem(bw.mlp2[0], hid_img, Mh, B * S, w.x_img, D, EPI_RESID_GATE_F32);
       with_gate(p[0], mi + 5 * D, S, nmod);
       p[1] = make_problem(bw.mlp2[1], hid_txt, Mh, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
       with_gate(p[1], mt + 5 * D, T, nmod);
-      FMI_TRY(gemm2(p, 2, s));
+      FMI_TRY(gemm2(m, p, 2, s));
     }
   }
 
@@ -458,7 +493,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       // [q|k|v|gelu(proj_mlp)] in one GEMM; the concat of model.rs:660 is never materialised
       GemmProblem p = make_problem(bw.w1, w.xm, D, B * L, w.big, ldbig, EPI_GELU_FROM_COL);
       p.gelu_from = 3 * D;
-      FMI_TRY(launch_gemm(&p, 1, s));
+      FMI_TRY(gemm2(m, &p, 1, s));
     }
     {
       PhaseTimer pt(m, s, PH_RELAYOUT);
@@ -478,7 +513,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
       GemmProblem p = make_problem(bw.w2, w.big + 2 * D, ldbig, B * L, w.x, D, EPI_RESID_GATE_F32);
       with_gate(p, mo + 2 * D, L, nmod);
-      FMI_TRY(launch_gemm(&p, 1, s));
+      FMI_TRY(gemm2(m, &p, 1, s));
     }
   }
 
@@ -490,7 +525,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       FMI_TRY(launch_layernorm_mod(w.x + ((size_t)b * L + T) * D, mf + (size_t)b * nmod, mf + (size_t)b * nmod + D, 0, 0,
                                    w.xm + (size_t)b * S * D, S, D, 1e-6f, s));
     GemmProblem p = make_problem(m->final_proj, w.xm, D, B * S, pred, C, EPI_STORE_F32);
-    FMI_TRY(launch_gemm(&p, 1, s));
+    FMI_TRY(gemm2(m, &p, 1, s));
   }
   return FMI_OK;
 }
@@ -553,6 +588,8 @@ extern "C" void fmi_flux_destroy(fmi_flux* m) {
   hipDeviceSynchronize();
   if (m->ws.base) hipFree(m->ws.base);
   if (m->arena) hipFree(m->arena);
+  for (int k = 0; k < 2; ++k)
+    if (m->wscratch[k]) hipFree(m->wscratch[k]);
   for (auto& b : m->dbl)
     for (int s = 0; s < 2; ++s)
       for (Dense* d : {&b.qkv[s], &b.proj[s], &b.mlp1[s], &b.mlp2[s]}) {
@@ -762,6 +799,12 @@ extern "C" const char* fmi_flux_phase_name(int i) { return (i >= 0 && i < PH_COU
 extern "C" int fmi_flux_phase_ms(fmi_flux* m, float* ms_out) {
   if (!m || !ms_out) return fail(FMI_ERR_INVALID, "null argument");
   for (int i = 0; i < PH_COUNT; ++i) ms_out[i] = m->phase_ms[i];
+  return FMI_OK;
+}
+// 4-bit dispatch threshold (rows): below it the fused dequant-GEMM runs, at or above it dequant-once + dense
+extern "C" int fmi_flux_set_bnb4_fused_max_rows(fmi_flux* m, int rows) {
+  if (!m) return fail(FMI_ERR_INVALID, "null handle");
+  m->q_fused_max_rows = rows;
   return FMI_OK;
 }
 // test hook: 0 = rescale every tile, else deferred-rescale threshold (default)

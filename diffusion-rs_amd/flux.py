@@ -106,11 +106,16 @@ class FluxModel:
         self.assert_complete()
 
     def set_linear_bnb4(self, prefix: str, packed, absmax, blocksize: int, quant_type: str, out_features: int, in_features: int):
-        pk = np.ascontiguousarray(packed, np.uint8)
-        am = np.ascontiguousarray(absmax, np.float32)
         q = {"fp4": 1, "nf4": 2}[quant_type]
-        L.check(self.lib.fmi_flux_set_linear_bnb4(self.h, prefix.encode(), C.c_void_p(pk.ctypes.data), C.c_void_p(am.ctypes.data), blocksize, q,
-                                                  out_features, in_features))
+        if isinstance(packed, torch.Tensor):  # host or device tensors: the C side copies with hipMemcpyDefault
+            pk, am = packed.contiguous(), absmax.to(torch.float32).contiguous()
+            assert pk.dtype == torch.uint8
+            pp, ap = C.c_void_p(pk.data_ptr()), C.c_void_p(am.data_ptr())
+        else:
+            pk = np.ascontiguousarray(packed, np.uint8)
+            am = np.ascontiguousarray(absmax, np.float32)
+            pp, ap = C.c_void_p(pk.ctypes.data), C.c_void_p(am.ctypes.data)
+        L.check(self.lib.fmi_flux_set_linear_bnb4(self.h, prefix.encode(), pp, ap, blocksize, q, out_features, in_features))
 
     def missing(self) -> List[str]:
         n = self.lib.fmi_flux_missing_count(self.h)

@@ -180,3 +180,28 @@ def fill_vae_random_device(vae, seed=0, device="cuda"):
             t = torch.zeros(shape, device=device, dtype=torch.float32)
         vae.set_tensor(name, t)
     return vae
+
+
+NF4_CODE = [-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635, -0.18477343022823334,
+            -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725, 0.24611230194568634, 0.33791524171829224,
+            0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0]
+
+
+def quantize_nf4_device(w, blocksize=64):
+    """bitsandbytes-rule nf4 quantisation on the GPU (synthetic C3 weights): absmax per block, nearest
+    code, high nibble first.  Returns (packed u8 (n/2), absmax f32 (n/blocksize))."""
+    import torch
+    flat = w.reshape(-1, blocksize).float()
+    absmax = flat.abs().amax(1)
+    xn = flat / absmax.clamp_min(1e-30)[:, None]
+    code = torch.tensor(NF4_CODE, device=w.device)
+    mid = (code[1:] + code[:-1]) / 2
+    idx = torch.bucketize(xn, mid).to(torch.uint8).reshape(-1)
+    packed = (idx[0::2] << 4) | idx[1::2]
+    return packed.contiguous(), absmax.contiguous()
+
+
+def is_block_linear(name):
+    """Linears of the DiT blocks that take the fused 4-bit GEMM path (everything a bnb checkpoint
+    quantises inside transformer_blocks / single_transformer_blocks except the modulation linears)."""
+    return name.endswith(".weight") and "transformer_blocks." in name and "norm" not in name
