@@ -7,9 +7,9 @@
 // cargo/rustc), so this file is the checker; see flux_oracle.h for pin status.
 //
 // Numerics choices where the reference leaves freedom (all f32 unless noted):
-//  * GEMM accumulation order: 8-lane partial sums per 256-deep K chunk, then a horizontal
-//    sum — the reference's order lives in the un-vendored `gemm` 0.17.1 crate and is
-//    unpinned.
+//  * GEMM accumulation order: one k-ordered f32 FMA chain per output and 256-deep K block,
+//    blocks added in order — the reference's order lives in the un-vendored `gemm` 0.17.1
+//    crate and is unpinned.
 //  * LayerNorm: sequential f32 sum / sum2, var = E[x^2]-mean^2 — exactly nn/ops.rs:1020-1041.
 //  * GroupNorm / RMS-norm slow path / softmax: two-pass f32 with sequential accumulation
 //    (the reference accumulates with SIMD-lane partial sums, core/cpu/kernels.rs; the
@@ -77,73 +77,70 @@ static inline float round_out(float v, int out_dtype) {
 // Linear: y = x W^T + b.  UnquantLinear::forward (diffusion_rs_backend/src/unquantized/
 // mod.rs:34-77, CPU branch `a.matmul(&w.t()?)?.broadcast_add(&b)`); W is (N,K) row-major.
 // ---------------------------------------------------------------------------------------
-static inline float hsum(v8f v) {
-  return ((v[0] + v[4]) + (v[1] + v[5])) + ((v[2] + v[6]) + (v[3] + v[7]));
-}
-
+// Register-blocked kernel in the BLIS shape: W is packed once per call into K-major 16-column
+// panels (Wt[panel][k][16]); the micro-kernel holds a 6x16 block of y in 12 YMM accumulators and,
+// per k, broadcasts 6 x values against two 8-float loads of the panel row (12 FMAs per 2 loads).
+// Every y[m][n] is therefore a k-ordered f32 FMA chain per 256-deep K block, blocks added in
+// order — the same class of ordering as the reference's `gemm` 0.17.1 micro-kernels (unpinned).
 static void gemm_nt(const float* __restrict x, int64_t ldx, const float* __restrict w, int64_t ldw,
                     const float* bias, int M, int N, int K, float* __restrict y, int64_t ldy, float alpha) {
-  const int MB = 48, NB = 64, KB = 256;
-  const int mt = (M + MB - 1) / MB, nt = (N + NB - 1) / NB;
+  const int NR = 16, MR = 6, KC = 256, MC = 96, NC = 256;
+  const int npan = (N + NR - 1) / NR;
+  std::vector<float> wt((size_t)npan * K * NR);
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < npan; ++p) {
+    float* dst = wt.data() + (size_t)p * K * NR;
+    for (int j = 0; j < NR; ++j) {
+      const int n = p * NR + j;
+      if (n < N) {
+        const float* src = w + (int64_t)n * ldw;
+        for (int k = 0; k < K; ++k) dst[(size_t)k * NR + j] = src[k];
+      } else {
+        for (int k = 0; k < K; ++k) dst[(size_t)k * NR + j] = 0.f;
+      }
+    }
+  }
+  const int mt = (M + MC - 1) / MC, nt = (N + NC - 1) / NC;
 #pragma omp parallel for collapse(2) schedule(dynamic, 1)
   for (int tm = 0; tm < mt; ++tm) {
     for (int tn = 0; tn < nt; ++tn) {
-      const int m0 = tm * MB, n0 = tn * NB;
-      const int mb = std::min(MB, M - m0), nb = std::min(NB, N - n0);
-      float acc[MB][NB];
+      const int m0 = tm * MC, mb = std::min(MC, M - m0);
+      const int n0 = tn * NC, nb = std::min(NC, N - n0);
+      float cblk[MC][NC];
       for (int i = 0; i < mb; ++i)
-        for (int j = 0; j < nb; ++j) acc[i][j] = 0.f;
-      for (int k0 = 0; k0 < K; k0 += KB) {
-        const int kb = std::min(KB, K - k0);
-        const int kv = kb & ~7;
-        for (int i = 0; i < mb; i += 4) {
-          const int ib = std::min(4, mb - i);
-          for (int j = 0; j < nb; j += 4) {
-            const int jb = std::min(4, nb - j);
-            if (ib == 4 && jb == 4) {
-              v8f c[4][4];
-              for (int a = 0; a < 4; ++a)
-                for (int b = 0; b < 4; ++b) c[a][b] = (v8f){0, 0, 0, 0, 0, 0, 0, 0};
-              const float* xp[4];
-              const float* wp[4];
-              for (int a = 0; a < 4; ++a) xp[a] = x + (int64_t)(m0 + i + a) * ldx + k0;
-              for (int b = 0; b < 4; ++b) wp[b] = w + (int64_t)(n0 + j + b) * ldw + k0;
-              for (int k = 0; k < kv; k += 8) {
-                v8f xv[4], wv[4];
-                for (int a = 0; a < 4; ++a) memcpy(&xv[a], xp[a] + k, 32);
-                for (int b = 0; b < 4; ++b) memcpy(&wv[b], wp[b] + k, 32);
-                for (int a = 0; a < 4; ++a)
-                  for (int b = 0; b < 4; ++b) c[a][b] += xv[a] * wv[b];
+        for (int j = 0; j < NC; ++j) cblk[i][j] = 0.f;
+      for (int k0 = 0; k0 < K; k0 += KC) {
+        const int kb = std::min(KC, K - k0);
+        for (int jr = 0; jr < nb; jr += NR) {
+          const float* bp = wt.data() + ((size_t)((n0 + jr) / NR) * K + k0) * NR;
+          for (int ir = 0; ir < mb; ir += MR) {
+            const int ib = std::min(MR, mb - ir);
+            v8f c[MR][2];
+            for (int a = 0; a < MR; ++a) c[a][0] = c[a][1] = (v8f){0, 0, 0, 0, 0, 0, 0, 0};
+            const float* xr[MR];
+            for (int a = 0; a < MR; ++a) xr[a] = x + (int64_t)(m0 + ir + std::min(a, ib - 1)) * ldx + k0;
+            for (int k = 0; k < kb; ++k) {
+              v8f b0, b1;
+              memcpy(&b0, bp + (size_t)k * NR, 32);
+              memcpy(&b1, bp + (size_t)k * NR + 8, 32);
+              for (int a = 0; a < MR; ++a) {
+                const float s = xr[a][k];
+                const v8f av = {s, s, s, s, s, s, s, s};
+                c[a][0] += av * b0;
+                c[a][1] += av * b1;
               }
-              for (int a = 0; a < 4; ++a)
-                for (int b = 0; b < 4; ++b) {
-                  float s = hsum(c[a][b]);
-                  for (int k = kv; k < kb; ++k) s += xp[a][k] * wp[b][k];
-                  acc[i + a][j + b] += s;
-                }
-            } else {
-              for (int a = 0; a < ib; ++a)
-                for (int b = 0; b < jb; ++b) {
-                  const float* xr = x + (int64_t)(m0 + i + a) * ldx + k0;
-                  const float* wr = w + (int64_t)(n0 + j + b) * ldw + k0;
-                  v8f c = (v8f){0, 0, 0, 0, 0, 0, 0, 0};
-                  for (int k = 0; k < kv; k += 8) {
-                    v8f xv, wv;
-                    memcpy(&xv, xr + k, 32);
-                    memcpy(&wv, wr + k, 32);
-                    c += xv * wv;
-                  }
-                  float s = hsum(c);
-                  for (int k = kv; k < kb; ++k) s += xr[k] * wr[k];
-                  acc[i + a][j + b] += s;
-                }
             }
+            for (int a = 0; a < ib; ++a)
+              for (int e = 0; e < 8; ++e) {
+                cblk[ir + a][jr + e] += c[a][0][e];
+                cblk[ir + a][jr + 8 + e] += c[a][1][e];
+              }
           }
         }
       }
       for (int i = 0; i < mb; ++i)
         for (int j = 0; j < nb; ++j) {
-          float v = acc[i][j] * alpha;
+          float v = cblk[i][j] * alpha;
           if (bias) v += bias[n0 + j];
           y[(int64_t)(m0 + i) * ldy + n0 + j] = v;
         }
