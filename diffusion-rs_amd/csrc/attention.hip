@@ -45,9 +45,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bh = blockIdx.y;
+  // 1-D grid, XCD-aware: block b runs on XCD b % 8, so give each XCD a contiguous range of
+  // (head, q-block) ids — all q-blocks of a head then share that head's K / Vt in ONE L2 instead
+  // of pulling it into all eight.
+  const int nqb = (Lq + ATT_QBLK - 1) / ATT_QBLK;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lid / nqb;
   const int b = bh / H, h = bh % H;
-  const int q0 = blockIdx.x * ATT_QBLK + wave * 32;
+  const int q0 = (lid % nqb) * ATT_QBLK + wave * 32;
   const int hl = lane >> 5;   // half of the wave
   const int l31 = lane & 31;  // query row within the wave / operand row
 
@@ -128,10 +133,22 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
   // softmax at the same time with the matrix pipe idle).  K and Vt therefore run on separate
   // double-buffered rings: at iteration t the K ring holds tiles t+1 / t+2, the Vt ring t / t+1.
   auto body = [&](int t, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
-    __syncthreads();  // K(t+1), Vt(t) landed; every wave finished iteration t-1
+    dma_barrier();  // K(t+1), Vt(t) landed; every wave finished iteration t-1
+#ifndef FMI_ATT_DMA_AFTER_QK
     if (t + 2 < ntiles) stage_k(t + 2, t & 1);
     if (t + 1 < ntiles) stage_v(t + 1, (t + 1) & 1);
+#endif
+#ifdef FMI_ATT_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
     if (t + 1 < ntiles) qk(sn, (t + 1) & 1);
+#ifdef FMI_ATT_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef FMI_ATT_DMA_AFTER_QK
+    if (t + 2 < ntiles) stage_k(t + 2, t & 1);
+    if (t + 1 < ntiles) stage_v(t + 1, (t + 1) & 1);
+#endif
     // ---- mask the ragged tail (kv >= Lk); kv_local = 32u + (r&3) + 8(r>>2) + 4hl
     if ((t + 1) * ATT_KV > Lk) {
       const int kvb = t * ATT_KV + 4 * hl;
@@ -179,6 +196,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
     l_run += lsum;
     // ---- Oᵀ += Vᵀ Pᵀ : k-slot (hl,e) of step (u,w) <-> Vt position 32u + 16w + 8hl + e
     const char* vl = smem + 32768 + (t & 1) * 16384;
+#ifdef FMI_ATT_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
@@ -187,13 +207,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
         ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c], ot[dt], 0, 0, 0);
       }
     }
+#ifdef FMI_ATT_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   f32x16 sa[2], sb[2];
   stage_k(0, 0);
   stage_v(0, 0);
   if (ntiles > 1) stage_k(1, 1);
-  __syncthreads();
+  dma_barrier();
   qk(sa, 0);
   for (int t = 0; t < ntiles; t += 2) {
     body(t, sa, sb);
@@ -228,7 +251,7 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
                         int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream) {
   if (Lq <= 0 || Lk <= 0) return fail(FMI_ERR_INVALID, "attention: empty sequence");
   if (Lkpad % ATT_KV != 0 || Lkpad < Lk) return fail(FMI_ERR_INVALID, "attention: Lkpad must be a multiple of 64 and >= Lk");
-  dim3 grid(cdiv(Lq, ATT_QBLK), B * H);
+  dim3 grid(cdiv(Lq, ATT_QBLK) * B * H);
   const float sl = scale * 1.4426950408889634f;
   if (rescale_thr_x16 == 0)
     hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);

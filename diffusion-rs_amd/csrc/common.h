@@ -81,6 +81,15 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Barrier that guards LDS-DMA data.  hipcc does not reliably drain global_load_lds before a
+// __syncthreads() (in the 2x-unrolled attention loop it emitted only lgkmcnt(0) before one of the
+// two barriers -> rare stale tiles, caught by the determinism property test), so the wait is explicit:
+// every wave first retires ITS OWN DMA pieces, then the barrier makes all pieces visible to all.
+__device__ __forceinline__ void dma_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 constexpr int NUM_XCD = 8;
 // Bijective XCD-aware remap: consecutive logical tiles land on the same XCD (= same L2).
 // (block b is dispatched to XCD b % 8; cdna guide T1 "XCD swizzle must be bijective")

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   auto ktile = [&](int kt, auto more_tag) {
     constexpr bool MORE = decltype(more_tag)::value;
     const int cur = kt & 1;
-    __syncthreads();  // tile kt landed for every wave; everyone finished reading buf[cur^1]
+    dma_barrier();  // tile kt landed for every wave; everyone finished reading buf[cur^1]
 #ifndef FMI_ABLATE_NO_LOAD
     if (MORE && !INTERLEAVE) {
       stage_a(kt + 1, bufA(cur ^ 1));

@@ -33,11 +33,13 @@ int main(int argc, char** argv) {
                                {4096, 12288, 3072, "double mlp1 img"}, {4096, 3072, 12288, "double mlp2 img"}, {4096, 3072, 3072, "double proj img"},
                                {512, 9216, 3072, "double qkv txt"}, {8192, 8192, 8192, "8k cube"}};
   int iters = argc > 1 ? atoi(argv[1]) : 10;
+  const int pad_a = argc > 2 ? atoi(argv[2]) : 0, pad_w = argc > 3 ? atoi(argv[3]) : 0, pad_o = argc > 4 ? atoi(argv[4]) : 0;  // row-stride padding (elements)
+  printf("pads: lda +%d, ldw +%d, ldo +%d elements\n", pad_a, pad_w, pad_o);
   size_t maxA = 0, maxW = 0, maxO = 0;
   for (auto& s : shapes) {
-    maxA = std::max(maxA, (size_t)s.M * s.K);
-    maxW = std::max(maxW, (size_t)s.N * s.K);
-    maxO = std::max(maxO, (size_t)s.M * s.N);
+    maxA = std::max(maxA, (size_t)s.M * (s.K + 512));
+    maxW = std::max(maxW, (size_t)s.N * (s.K + 512));
+    maxO = std::max(maxO, (size_t)s.M * (s.N + 512));
   }
   bf16_t *A, *W, *O;
   hipMalloc((void**)&A, maxA * 2);
@@ -51,7 +53,7 @@ int main(int argc, char** argv) {
   hipEventCreate(&e1);
   for (auto& s : shapes) {
     GemmProblem p{};
-    p.A = A, p.W = W, p.out = O, p.M = s.M, p.N = s.N, p.K = s.K, p.lda = s.K, p.ldw = s.K, p.ldo = s.N, p.epi = EPI_STORE_BF16, p.alpha = 1.f;
+    p.A = A, p.W = W, p.out = O, p.M = s.M, p.N = s.N, p.K = s.K, p.lda = s.K + pad_a, p.ldw = s.K + pad_w, p.ldo = s.N + pad_o, p.epi = EPI_STORE_BF16, p.alpha = 1.f;
     for (int i = 0; i < 2; ++i) launch_gemm(&p, 1, nullptr);
     hipDeviceSynchronize();
     hipEventRecord(e0, nullptr);
