@@ -1,0 +1,161 @@
+"""Weight ingestion: diffusers directories, DDUF archives and HF-bitsandbytes
+tensor naming, feeding the C-ABI's fmi_flux_set_tensor / fmi_flux_set_linear_bnb4 / fmi_vae_set_tensor.
+
+  FileLoader      <-> diffusion_rs_common::model_source::FileLoader (model_source.rs:87-259):
+                      a local directory, or a DDUF file = a zip whose entries are STORED
+                      (uncompressed) so tensors can be sliced straight out of the mmap
+                      (model_source.rs:225-232, varbuilder_loading.rs:111-117).
+  load_flux       <-> FluxModel::new over a VarBuilder (model.rs:722-787) + the bnb detection of
+                      diffusion_rs_backend::linear_b (lib.rs:197-266): a linear whose prefix has
+                      `weight.absmax` / `weight.quant_state.bitsandbytes__{nf4,fp4}` is 4-bit
+                      (bitsandbytes/mod.rs:137-222), nested absmax resolved as mod.rs:230-239.
+There is no network here: hub model ids must already be local directories.
+"""
+import io
+import json
+import warnings
+import mmap
+import os
+import struct
+import zipfile
+from typing import Dict, Iterator, List, Tuple
+
+import numpy as np
+import torch
+
+from . import synth
+
+_ST_DTYPES = {"F32": (torch.float32, 4), "F16": (torch.float16, 2), "BF16": (torch.bfloat16, 2), "U8": (torch.uint8, 1), "I8": (torch.int8, 1),
+              "I32": (torch.int32, 4), "I64": (torch.int64, 8), "F64": (torch.float64, 8)}
+
+
+def _safetensors_from_buffer(buf) -> Iterator[Tuple[str, torch.Tensor]]:
+    """Zero-copy views of every tensor in a safetensors image held in `buf` (mmap / memoryview)."""
+    n = struct.unpack("<Q", bytes(buf[:8]))[0]
+    header = json.loads(bytes(buf[8:8 + n]))
+    base = 8 + n
+    for name, meta in header.items():
+        if name == "__metadata__":
+            continue
+        dt, _ = _ST_DTYPES[meta["dtype"]]
+        a, b = meta["data_offsets"]
+        with warnings.catch_warnings():  # read-only mmap views are intended: tensors are only copied to the device
+            warnings.simplefilter("ignore", UserWarning)
+            t = torch.frombuffer(buf, dtype=dt, count=(b - a) // _ST_DTYPES[meta["dtype"]][1], offset=base + a) if b > a else torch.empty(0, dtype=dt)
+        yield name, t.reshape(meta["shape"])
+
+
+class FileLoader:
+    """Directory or DDUF view of a diffusers checkpoint: list_files / read_json / tensors(component)."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self._mm = None
+        if os.path.isdir(path):
+            self.kind = "dir"
+            self.files = sorted(os.path.relpath(os.path.join(r, f), path) for r, _, fs in os.walk(path) for f in fs)
+        elif zipfile.is_zipfile(path):
+            self.kind = "dduf"
+            self._f = open(path, "rb")
+            self._mm = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
+            self._zip = zipfile.ZipFile(path)
+            self._info = {i.filename: i for i in self._zip.infolist() if not i.is_dir()}
+            for i in self._info.values():
+                if i.compress_type != zipfile.ZIP_STORED:
+                    raise ValueError(f"{path}: DDUF entries must be stored uncompressed ({i.filename} is compressed)")
+            self.files = sorted(self._info)
+        else:
+            raise FileNotFoundError(f"{path}: not a directory or DDUF (zip) file; hub ids need network access, which this build does not have")
+
+    def list_files(self) -> List[str]:
+        return self.files
+
+    def _entry_view(self, name: str) -> memoryview:
+        """Slice of the mmap holding a stored zip entry (data_start()..+size, model_source.rs:225-232)."""
+        i = self._info[name]
+        hdr = self._mm[i.header_offset:i.header_offset + 30]
+        nlen, elen = struct.unpack("<HH", hdr[26:30])
+        start = i.header_offset + 30 + nlen + elen
+        return memoryview(self._mm)[start:start + i.file_size]
+
+    def read_json(self, name: str) -> dict:
+        if self.kind == "dir":
+            with open(os.path.join(self.path, name)) as f:
+                return json.load(f)
+        return json.loads(bytes(self._entry_view(name)))
+
+    def tensors(self, component: str) -> Iterator[Tuple[str, torch.Tensor]]:
+        """All tensors of every *.safetensors shard under `component/` (shards in name order)."""
+        for fn in self.files:
+            if not (fn.startswith(component + "/") and fn.endswith(".safetensors")):
+                continue
+            if self.kind == "dir":
+                with open(os.path.join(self.path, fn), "rb") as f:
+                    mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+                yield from _safetensors_from_buffer(memoryview(mm))
+            else:
+                yield from _safetensors_from_buffer(self._entry_view(fn))
+
+
+def _resolve_absmax(lib, group: Dict[str, torch.Tensor], state: dict, device) -> torch.Tensor:
+    """f32 absmax of a 4-bit weight; nested (double-quantised) absmax per bitsandbytes/mod.rs:230-239:
+    absmax = dequantize_int8(absmax_u8, nested_quant_map, nested_absmax, nested_blocksize) + nested_offset."""
+    import ctypes as C
+    absmax = group["weight.absmax"]
+    if "weight.nested_absmax" not in group:
+        return absmax.to(torch.float32)
+    a8 = absmax.to(device=device, dtype=torch.uint8).contiguous()
+    code = group["weight.nested_quant_map"].to(device=device, dtype=torch.float32).contiguous()
+    nabs = group["weight.nested_absmax"].to(device=device, dtype=torch.float32).contiguous()
+    out = torch.empty(a8.numel(), dtype=torch.float32, device=device)
+    lib.dequantize_blockwise_f32_int8(C.c_void_p(code.data_ptr()), C.c_void_p(a8.data_ptr()), C.c_void_p(nabs.data_ptr()), C.c_void_p(out.data_ptr()),
+                                      int(state["nested_blocksize"]), a8.numel(), None)
+    torch.cuda.synchronize()
+    return out + float(state["nested_offset"])
+
+
+def load_flux(flux, tensors: Iterator[Tuple[str, torch.Tensor]]) -> dict:
+    """Feed a FluxModel from (name, tensor) pairs; returns {"dense": n, "bnb4": n, "skipped": [...]}."""
+    from . import _lib as L
+    lib = L.load()
+    want = synth.flux_tensor_shapes(flux.cfg)
+    stats = {"dense": 0, "bnb4": 0, "skipped": []}
+    pending: Dict[str, Dict[str, torch.Tensor]] = {}
+    for name, t in tensors:
+        # bnb side tensors: "<prefix>.weight.absmax", ".weight.quant_map", ".weight.quant_state.bitsandbytes__nf4", ...
+        if ".weight." in name:
+            prefix, rest = name.split(".weight.", 1)
+            pending.setdefault(prefix, {})["weight." + rest] = t
+            continue
+        if name.endswith(".weight") and t.dtype == torch.uint8:  # packed 4-bit weight of a bnb linear
+            pending.setdefault(name[:-len(".weight")], {})["weight"] = t
+            continue
+        if name in want:
+            flux.set_tensor(name, t)
+            stats["dense"] += 1
+        else:
+            stats["skipped"].append(name)
+    for prefix, group in pending.items():
+        qkey = next((k for k in group if k.startswith("weight.quant_state.bitsandbytes__")), None)
+        if qkey is None or "weight" not in group or "weight.absmax" not in group:
+            raise ValueError(f"`BnbLinear` expects fp4/nf4 layers: incomplete tensors for {prefix}: {sorted(group)}")  # bitsandbytes/mod.rs:120
+        qt = qkey.rsplit("__", 1)[1]
+        state = json.loads(bytes(group[qkey].numpy().tobytes()))
+        out_f, in_f = want[prefix + ".weight"]
+        if list(state["shape"]) != [out_f, in_f]:
+            raise ValueError(f"{prefix}: quant_state shape {state['shape']} != expected {(out_f, in_f)}")
+        absmax = _resolve_absmax(lib, group, state, flux.device)
+        flux.set_linear_bnb4(prefix, group["weight"].reshape(-1), absmax, int(state["blocksize"]), qt, out_f, in_f)
+        stats["bnb4"] += 1
+    flux.assert_complete()
+    return stats
+
+
+def load_vae(vae, tensors: Iterator[Tuple[str, torch.Tensor]]) -> int:
+    want = synth.vae_tensor_shapes(vae.cfg)
+    n = 0
+    for name, t in tensors:
+        if name in want:
+            vae.set_tensor(name, t)
+            n += 1
+    return n

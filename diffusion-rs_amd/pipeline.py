@@ -138,47 +138,31 @@ class Pipeline:
             if source.variant != "dev":
                 self.scheduler = F.SchedulerConfig(shift=1.0, use_dynamic_shifting=False)
         elif source.kind == "model_id":
-            self._load_directory(source.model_id, getattr(source, "transformer_model_id", None))
+            self._load_checkpoint(source.model_id, getattr(source, "transformer_model_id", None))
         else:
-            raise NotImplementedError("DDUF ingestion is a SURVEY §8(f) 'next' row (zip + safetensors); load a diffusers directory instead")
+            self._load_checkpoint(source.file, None)
 
-    # Pipeline::load for a local diffusers directory (model_index.json, transformer/, vae/, scheduler/)
-    def _load_directory(self, path: str, transformer_path: Optional[str]):
-        from safetensors import safe_open
-        if not os.path.isdir(path):
-            raise FileNotFoundError(f"{path}: only local diffusers directories can be loaded (no network)")
-        with open(os.path.join(path, "model_index.json")) as f:
-            if json.load(f).get("_class_name") != "FluxPipeline":  # pipelines/mod.rs:146-149
-                raise ValueError("Only FluxPipeline is supported")
-        with open(os.path.join(path, "scheduler", "scheduler_config.json")) as f:
-            sc = json.load(f)
+    # Pipeline::load (pipelines/mod.rs:120-236) for a local diffusers directory or a DDUF file:
+    # model_index.json -> FluxPipeline only; scheduler / transformer / vae components
+    # (text_encoder*, tokenizer* are listed by the reference loader but out of scope here).
+    def _load_checkpoint(self, path: str, transformer_path: Optional[str]):
+        from . import loader
+        fl = loader.FileLoader(path)
+        if fl.read_json("model_index.json").get("_class_name") != "FluxPipeline":  # pipelines/mod.rs:146-149
+            raise ValueError("Only FluxPipeline is supported")
+        sc = fl.read_json("scheduler/scheduler_config.json")
         self.scheduler = F.SchedulerConfig(sc["base_image_seq_len"], sc["base_shift"], sc["max_image_seq_len"], sc["max_shift"], sc["shift"],
                                            sc["use_dynamic_shifting"])
-        tdir = os.path.join(transformer_path or path, "transformer") if not (transformer_path and os.path.isfile(os.path.join(transformer_path, "config.json"))) else transformer_path
-        with open(os.path.join(tdir, "config.json")) as f:
-            tc = json.load(f)
+        tl = loader.FileLoader(transformer_path) if transformer_path else fl  # ModelIdWithTransformer (model_source.rs:22-25)
+        tc = tl.read_json("transformer/config.json")
         fcfg = dict(F.FLUX_DEV, **{k: tc[k] for k in ("in_channels", "pooled_projection_dim", "joint_attention_dim", "num_attention_heads", "num_layers",
                                                      "num_single_layers", "guidance_embeds") if k in tc})
         self.flux = F.FluxModel(fcfg, self.device_index)
-        for fn in sorted(os.listdir(tdir)):
-            if fn.endswith(".safetensors"):
-                with safe_open(os.path.join(tdir, fn), framework="pt", device="cpu") as sf:
-                    for k in sf.keys():
-                        if k in synth.flux_tensor_shapes(fcfg):
-                            self.flux.set_tensor(k, sf.get_tensor(k))
-        self.flux.assert_complete()
-        vdir = os.path.join(path, "vae")
-        with open(os.path.join(vdir, "config.json")) as f:
-            vc = json.load(f)
+        self.load_stats = loader.load_flux(self.flux, tl.tensors("transformer"))
+        vc = fl.read_json("vae/config.json")
         vcfg = dict(F.VAE_FLUX, **{k: vc[k] for k in F.VAE_FLUX if k in vc})
         self.vae = F.AutoEncoderKl(vcfg, self.device_index)
-        want = synth.vae_tensor_shapes(vcfg)
-        for fn in sorted(os.listdir(vdir)):
-            if fn.endswith(".safetensors"):
-                with safe_open(os.path.join(vdir, fn), framework="pt", device="cpu") as sf:
-                    for k in sf.keys():
-                        if k in want:
-                            self.vae.set_tensor(k, sf.get_tensor(k))
+        loader.load_vae(self.vae, fl.tensors("vae"))
 
     @classmethod
     def load(cls, source, silent=False, token=None, revision=None, offloading_type=None, dtype=ModelDType.Auto, **kw):

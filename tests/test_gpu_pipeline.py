@@ -89,3 +89,73 @@ def test_pipeline_rejects_non_flux_and_f32(tmp_path):
         d.Pipeline(d.ModelSource.ModelId(str(root)))
     with pytest.raises(ValueError):
         d.Pipeline(d.ModelSource.Synthetic(), dtype=d.ModelDType.F32)
+
+
+def test_dduf_with_bnb_nf4_nested_absmax(tmp_path):
+    """§8(f) rank 1: a DDUF (stored zip) FLUX checkpoint whose block linears are HF-bitsandbytes nf4 with
+    double-quantised (nested) absmax loads through the FileLoader + bnb name detection and matches the
+    oracle run on the dequantised weights (BnbLinear::dequantize_4bit, bitsandbytes/mod.rs:225-261)."""
+    import io
+    import zipfile
+    import torch
+    from safetensors.torch import save
+    import diffusion_rs_amd as d
+    from oracle import oracle as orc
+    from tests.util import flux_inputs
+    sd = d.synth.flux_state_dict_numpy(SMALL_FLUX, seed=2)
+    vsd = d.synth.vae_state_dict_numpy(SMALL_VAE, seed=2)
+    code256 = np.linspace(-1.0, 1.0, 256).astype(np.float32)
+    nf4_map = np.array(d.synth.NF4_CODE, np.float32)
+    tens, dense_for_oracle = {}, {}
+    nq = 0
+    for name, w in sd.items():
+        if d.synth.is_block_linear(name):
+            prefix = name[:-len(".weight")]
+            packed, absmax = orc.quantize_blockwise_4bit(w.ravel(), 64, "nf4")
+            off = float(absmax.mean())
+            a = absmax - np.float32(off)
+            nb = (a.size + 255) // 256
+            nabs = np.array([np.abs(a[i * 256:(i + 1) * 256]).max() for i in range(nb)], np.float32)
+            idx = np.array([np.abs(code256 - (a[i] / max(nabs[i // 256], 1e-30))).argmin() for i in range(a.size)], np.uint8)
+            eff = (code256[idx] * nabs[np.arange(a.size) // 256]).astype(np.float32) + np.float32(off)
+            state = {"blocksize": 64, "shape": list(w.shape), "dtype": "bfloat16", "nested_blocksize": 256, "nested_offset": off,
+                     "nested_dtype": "float32", "quant_type": "nf4"}
+            tens[name] = torch.from_numpy(packed.reshape(-1, 1))
+            tens[prefix + ".weight.absmax"] = torch.from_numpy(idx)
+            tens[prefix + ".weight.quant_map"] = torch.from_numpy(nf4_map.copy())
+            tens[prefix + ".weight.nested_absmax"] = torch.from_numpy(nabs)
+            tens[prefix + ".weight.nested_quant_map"] = torch.from_numpy(code256.copy())
+            tens[prefix + ".weight.quant_state.bitsandbytes__nf4"] = torch.from_numpy(np.frombuffer(json.dumps(state).encode(), np.uint8).copy())
+            dense_for_oracle[name] = orc.dequantize_blockwise(None, packed, eff, 64, w.size, "nf4", "bf16").reshape(w.shape)
+            nq += 1
+        else:
+            tens[name] = torch.from_numpy(w).to(torch.bfloat16)
+            dense_for_oracle[name] = w
+    path = str(tmp_path / "tiny-flux-Q4-bnb.dduf")
+    with zipfile.ZipFile(path, "w", compression=zipfile.ZIP_STORED) as z:
+        z.writestr("model_index.json", json.dumps({"_class_name": "FluxPipeline"}))
+        z.writestr("scheduler/scheduler_config.json", json.dumps({"_class_name": "FlowMatchEulerDiscreteScheduler", "base_image_seq_len": 256,
+                   "base_shift": 0.5, "max_image_seq_len": 4096, "max_shift": 1.15, "shift": 3.0, "use_dynamic_shifting": True}))
+        z.writestr("transformer/config.json", json.dumps({k: SMALL_FLUX[k] for k in ("in_channels", "pooled_projection_dim", "joint_attention_dim",
+                   "num_attention_heads", "num_layers", "num_single_layers", "guidance_embeds")}))
+        z.writestr("transformer/diffusion_pytorch_model.safetensors", save(tens))
+        z.writestr("vae/config.json", json.dumps(dict(SMALL_VAE)))
+        z.writestr("vae/diffusion_pytorch_model.safetensors", save({k: torch.from_numpy(v) for k, v in vsd.items()}))
+    pipe = d.Pipeline(d.ModelSource.DdufFile(path))
+    assert pipe.load_stats["bnb4"] == nq and nq > 0
+    om = orc.Flux(SMALL_FLUX)
+    om.load(dense_for_oracle)
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, 1, (8, 8), 32, seed=4)
+    t = np.array([0.7], np.float32)
+    g = np.array([3.5], np.float32)
+    ref = om.forward(img, ids, txt, txt_ids, t, y, g)
+    got = host(pipe.flux.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
+    err = rel_l2(got, ref)
+    print(f"DDUF + bnb-nf4 (nested absmax): {nq} quantised linears, rel-L2 {err:.3e}")
+    assert err <= 1e-2
+    # a compressed entry is rejected (DDUF entries must be stored: tensors are sliced from the mmap)
+    bad = str(tmp_path / "bad.dduf")
+    with zipfile.ZipFile(bad, "w", compression=zipfile.ZIP_DEFLATED) as z:
+        z.writestr("model_index.json", json.dumps({"_class_name": "FluxPipeline"}) * 50)
+    with pytest.raises(ValueError):
+        d.Pipeline(d.ModelSource.DdufFile(bad))
