@@ -141,6 +141,7 @@ struct GemmProblem {
   const bf16_t* cv_zero;  // >= 128 B of zeros for padding taps
 };
 int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream);
+void set_gemm_pingpong(bool on);  // dense N>128 launches: ping-pong kernel (default) or the double-buffered one
 
 // attention output routing: query rows [0,rows0) -> p0, the rest -> p1 (token-major, head h at
 // column h*128); or head-major (B,H,Lq,128) in p1.

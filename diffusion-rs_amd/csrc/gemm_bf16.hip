@@ -40,6 +40,9 @@ namespace fmi {
 #ifndef FMI_AUX_W
 #define FMI_AUX_W 0
 #endif
+#ifndef FMI_GH
+#define FMI_GH 8  // tile-rows per band of the tile order (see the kernel)
+#endif
 constexpr int BM = 256, BK = 64;
 constexpr int GEMM_THREADS = 512;
 constexpr int A_TILE_BYTES = BM * BK * 2;  // 32 KiB
@@ -118,6 +121,167 @@ __device__ __forceinline__ void stage_tile_q4(const GemmProblem& P, int n0, int 
   }
 }
 
+// Shared epilogue.  Lane holds, for accumulator (i, j): row m = m0 + wm*128 + i*32 + (lane&31) and
+// columns n = n0 + wn*32*NJ + j*32 + 8q + 4(lane>>5) + {0..3} in registers 4q..4q+3.
+// `smem` (>= 8 * 8192*NJ bytes) is free for staging once every wave has passed the leading barrier.
+template <int NJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc)[4][NJ], char* smem, int m0, int n0, int wave, int lane) {
+  constexpr int BN = 128 * NJ;
+  const int wm = wave >> 2, wn = wave & 3;
+  // ---- epilogue: lane holds row m = ..+(lane&31), columns n = ..+8q+4(lane>>5)+{0..3}
+  const int epi = P.epi;
+  const float alpha = P.alpha;
+  const int hl = lane >> 5, l31 = lane & 31;
+  // alpha, bias, activation on 4 consecutive columns starting at n
+  auto finish = [&](int n, float (&v)[4], bool full) {
+    if (epi == EPI_STORE_F32 || epi == EPI_SCALE_BF16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= alpha;
+    }
+    if (P.bias) {
+      if (full) {
+        const uint2 b = *reinterpret_cast<const uint2*>(P.bias + n);
+        v[0] += bf16_to_f32((bf16_t)(b.x & 0xffff));
+        v[1] += bf16_to_f32((bf16_t)(b.x >> 16));
+        v[2] += bf16_to_f32((bf16_t)(b.y & 0xffff));
+        v[3] += bf16_to_f32((bf16_t)(b.y >> 16));
+      } else {
+        for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(P.bias[n + e]);
+      }
+    }
+    if (epi == EPI_GELU_BF16 || (epi == EPI_GELU_FROM_COL && n >= P.gelu_from)) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+    } else if (epi == EPI_SILU_BF16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
+    }
+  };
+  const bool f32_out = (epi == EPI_RESID_GATE_F32 || epi == EPI_STORE_F32);
+#ifdef FMI_ABLATE_NO_EPI
+  if (alpha != 12345.f) return;  // ablation: skip the stores but keep the accumulators live
+#endif
+  // Staged path: the C tile goes through LDS (free after the K loop) and leaves as whole 128-B
+  // (bf16) / 256-B (f32) row segments with 16-B stores.  Direct per-lane stores touch 32 partial
+  // cache lines per instruction and cost ~30 us per tile with nothing else resident on the CU.
+  const bool staged = (P.ldo % 8 == 0) && (n0 + BN <= P.N) && ((reinterpret_cast<uintptr_t>(P.out) & 15) == 0) && epi != EPI_RESID_ADD_BF16 &&
+                      (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias) & 7) == 0);
+  if (staged) {
+    __syncthreads();  // every wave is done with the operand tiles
+    char* cw = smem + wave * (8192 * NJ);  // wave-private staging region
+    const int ncol0 = n0 + wn * 32 * NJ;
+    if (!f32_out) {
+      constexpr int RB = 64 * NJ;   // bytes per staged row (32*NJ bf16)
+      constexpr int NS8 = 8 * NJ;   // 8-byte slots per row
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+            finish(ncol0 + j * 32 + q * 8 + 4 * hl, v, true);
+            const int r = i * 32 + l31, c = j * 8 + q * 2 + hl;
+            *reinterpret_cast<uint2*>(cw + r * RB + ((c ^ (r & (NS8 - 1))) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int LPR = RB / 16, RPI = 64 / LPR;  // lanes per row, rows per wave-instruction
+      bf16_t* ob = reinterpret_cast<bf16_t*>(P.out);
+#pragma unroll
+      for (int it = 0; it < 128 / RPI; ++it) {
+        const int r = it * RPI + lane / LPR, ch = lane % LPR;
+        const int sp = ((2 * ch) ^ (r & (NS8 - 1))) & ~1;
+        uint4 d = *reinterpret_cast<const uint4*>(cw + r * RB + (sp << 3));
+        if (r & 1) d = make_uint4(d.z, d.w, d.x, d.y);  // odd rows hold the slot pair swapped
+        const int m = m0 + wm * 128 + r;
+        if (m < P.M) *reinterpret_cast<uint4*>(ob + (int64_t)m * P.ldo + ncol0 + ch * 8) = d;
+      }
+    } else {
+      constexpr int RBF = 128 * NJ;  // bytes per staged row (32*NJ f32)
+      constexpr int NS16 = 8 * NJ;   // 16-byte slots per row
+      constexpr int LPR = RBF / 16, RPI = 64 / LPR;
+      float* of = reinterpret_cast<float*>(P.out);
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[pass * 2 + ii][j][q * 4 + e];
+              finish(ncol0 + j * 32 + q * 8 + 4 * hl, v, true);
+              const int r = ii * 32 + l31, c = j * 8 + q * 2 + hl;
+              *reinterpret_cast<float4*>(cw + r * RBF + ((c ^ (r & (NS16 - 1))) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 64 / RPI; ++it) {
+          const int r = it * RPI + lane / LPR, ch = lane % LPR;
+          const float4 v = *reinterpret_cast<const float4*>(cw + r * RBF + ((ch ^ (r & (NS16 - 1))) << 4));
+          const int m = m0 + wm * 128 + pass * 64 + r, n = ncol0 + ch * 4;
+          if (m < P.M) {
+            float* o = of + (int64_t)m * P.ldo + n;
+            if (epi == EPI_RESID_GATE_F32) {
+              const float* gate = P.gate + (P.rows_per_batch > 0 ? (int64_t)(m / P.rows_per_batch) * P.gate_bstride : 0);
+              const float4 g = *reinterpret_cast<const float4*>(gate + n);
+              float4 x = *reinterpret_cast<float4*>(o);
+              x.x += g.x * v.x;
+              x.y += g.y * v.y;
+              x.z += g.z * v.z;
+              x.w += g.w * v.w;
+              *reinterpret_cast<float4*>(o) = x;
+            } else {
+              *reinterpret_cast<float4*>(o) = v;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+  // ---- direct path (ragged N tile, unaligned output, bf16 residual add)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 128 + i * 32 + l31;
+    if (m >= P.M) continue;
+    const float* gate = P.gate;
+    if (epi == EPI_RESID_GATE_F32 && P.rows_per_batch > 0) gate += (int64_t)(m / P.rows_per_batch) * P.gate_bstride;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 32 * NJ + j * 32 + q * 8 + 4 * hl;
+        if (n >= P.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+        const bool full = (n + 3 < P.N) && (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias + n) & 7) == 0);
+        finish(n, v, full);
+        if (epi == EPI_RESID_GATE_F32) {
+          float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
+          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] += gate[n + e] * v[e];
+        } else if (epi == EPI_STORE_F32) {
+          float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
+          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = v[e];
+        } else {
+          bf16_t* o = reinterpret_cast<bf16_t*>(P.out) + (int64_t)m * P.ldo + n;
+          if (epi == EPI_RESID_ADD_BF16) {
+            const bf16_t* r = reinterpret_cast<const bf16_t*>(P.resid) + (int64_t)m * P.ldo + n;
+            for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(r[e]);
+          }
+          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = f32_to_bf16(v[e]);
+        }
+      }
+    }
+  }
+}
+
 // MODE 0: dense GEMM, 1: 4-bit weights, 2: implicit-GEMM convolution (NHWC)
 template <int MODE, int NJ>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBatch batch) {
@@ -143,9 +307,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   const int tiles_n = (P.N + BN - 1) / BN;
   // Logical ids walk bands of GH tile-rows column by column, so the ~32 tiles an XCD runs at any
   // time form a compact GH x 4 patch: 12 distinct A/W panels per K step instead of 20 (L2 hits).
-#ifndef FMI_GH
-#define FMI_GH 8
-#endif
   constexpr int GH = FMI_GH;
   const int band = t / (GH * tiles_n);
   const int band_h = min(GH, tiles_m - band * GH);
@@ -307,159 +468,220 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
   ktile(nk - 1, std::false_type{});
 
-  // ---- epilogue: lane holds row m = ..+(lane&31), columns n = ..+8q+4(lane>>5)+{0..3}
-  const int epi = P.epi;
-  const float alpha = P.alpha;
-  const int hl = lane >> 5, l31 = lane & 31;
-  // alpha, bias, activation on 4 consecutive columns starting at n
-  auto finish = [&](int n, float (&v)[4], bool full) {
-    if (epi == EPI_STORE_F32 || epi == EPI_SCALE_BF16) {
+  gemm_epilogue<NJ>(P, acc, smem, m0, n0, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense 256x256x64 kernel: ping-pong wave groups, register-resident fragments, 5-tile LDS ring.
+//
+// Why (ablations on the double-buffered kernel above and on this one, profiles/ + DESIGN.md):
+//   * an LDS-DMA piece needs ~1.1-1.3 us from issue to landed under load, but double buffering
+//     gives a tile only one K-tile period of lead: every K tile ends in a wait for data;
+//   * a CU retires at most one 1-KiB global_load_lds every ~45 clocks (64 KiB per 1.2 us) and a
+//     wave that issues one while that queue is full stalls IN ORDER — the MFMAs behind it wait too.
+// So: (1) all 160 KiB of LDS hold 5 operand tiles (A ring of 2, W ring of 3) and a tile's
+// fragments are copied to registers in one burst, so its slot is recycled after a fraction of a
+// period and every DMA piece has 3 slots (1.5 periods) to land; (2) the wave that issues DMA is
+// never the wave that feeds the matrix pipe.
+//
+// The 8 waves form two groups (waves 0-3 = rows 0..127, waves 4-7 = rows 128..255; one wave of
+// each group per SIMD).  Time is cut into barrier-delimited slots; in every slot one group LOADs
+// (24 ds_read_b128 per wave: its fragments of tile t -> VGPRs, then its 8 DMA pieces, then waits
+// for the pieces it issued one period ago) while the other COMPUTEs (32 back-to-back MFMAs out of
+// registers, nothing else).  Group 1 runs one slot behind group 0:
+//     slot      2t        2t+1        2t+2        2t+3
+//     group 0   LOAD(t)   COMPUTE(t)  LOAD(t+1)   COMPUTE(t+1)
+//     group 1   COMP(t-1) LOAD(t)     COMPUTE(t)  LOAD(t+1)
+// DMA issued by a wave of group g during LOAD(t) (its 1-KiB chunks wave*4 + i, i < 4):
+//     A rows of the OTHER group, tile t+1+g -> A slot (t+1+g)&1   (last read one slot earlier)
+//     W rows (its half),         tile t+2   -> W slot (t+2)%3     (last read by group 1 in slot 2t-1)
+// `s_waitcnt vmcnt(8)` at the end of LOAD(t) retires what the wave issued in LOAD(t-1); the
+// closing barrier publishes it to the group that LOADs next.  Barriers are raw s_barrier +
+// lgkmcnt(0): a __syncthreads() would make hipcc drain vmcnt as well and collapse the pipeline,
+// and sched_barrier(0) keeps the MFMAs (not memory operations) from being hoisted across slots.
+// Accumulation order per output element is identical to gemm_bf16_kernel: bit-identical results.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatch batch) {
+  constexpr int NJ = 2, BN = 256;
+  constexpr int A_RING = 0, W_RING = 2 * A_TILE_BYTES, TILE = A_TILE_BYTES;  // 2 x 32 KiB + 3 x 32 KiB
+  __shared__ __attribute__((aligned(16))) char smem[5 * TILE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wn = wave & 3;  // group = row half (wm)
+
+  const int total = batch.tile_start[batch.nprob];
+  const int lid = xcd_remap(blockIdx.x, total);
+  int pi = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= alpha;
+  for (int i = 1; i < MAX_PROBLEMS; ++i)
+    if (i < batch.nprob && lid >= batch.tile_start[i]) pi = i;
+  const GemmProblem& P = batch.p[pi];
+  const int t_in = lid - batch.tile_start[pi];
+  const int tiles_m = (P.M + BM - 1) / BM;
+  const int tiles_n = (P.N + BN - 1) / BN;
+  constexpr int GH = FMI_GH;  // same band/patch order as gemm_bf16_kernel
+  const int band = t_in / (GH * tiles_n);
+  const int band_h = min(GH, tiles_m - band * GH);
+  const int tin = t_in - band * GH * tiles_n;
+  const int tn = tin / band_h, tm = band * GH + tin % band_h;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = P.K / BK;
+
+  f32x16 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int sw = ((lane & 31) >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + (lane >> 5)) ^ sw) << 4;
+  const int a_row_off = (g * 128 + (lane & 31)) * 128;
+  const int w_row_off = (wn * 64 + (lane & 31)) * 128;
+
+  // chunks (8 rows, 1 KiB) this wave stages: A chunks of the other group's rows, W chunks wave*4+i
+  const int a_chunk0 = (wave ^ 4) * 4, w_chunk0 = wave * 4;
+  // per-lane BYTE offsets (32-bit: the operands are < 4 GiB) from the uniform tile base, so the DMA
+  // uses the saddr + voffset form: 8 VGPRs instead of 16 for pointers (the kernel sits at the
+  // 256-register limit and a spilled pointer costs a vmcnt(0) reload — a full pipeline drain)
+  uint32_t a_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = (a_chunk0 + i) * 8 + (lane >> 3), rw = (w_chunk0 + i) * 8 + (lane >> 3);
+    a_off[i] = (uint32_t)(((int64_t)min(m0 + ra, P.M - 1) * P.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3)) * 2);
+    w_off[i] = (uint32_t)(((int64_t)min(n0 + rw, P.N - 1) * P.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3)) * 2);
+  }
+  const char* const a_base = reinterpret_cast<const char*>(P.A);
+  const char* const w_base = reinterpret_cast<const char*>(P.W);
+  auto dma_a = [&](int kt, int i) {
+    const char* base = a_base + (int64_t)kt * (BK * 2);  // uniform
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + a_off[i]), (lds_void*)(smem + A_RING + (kt & 1) * TILE + (a_chunk0 + i) * 1024), 16, 0, FMI_AUX_A);
+  };
+  auto dma_w = [&](int kt, int slot, int i) {
+    const char* base = w_base + (int64_t)kt * (BK * 2);
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + w_off[i]), (lds_void*)(smem + W_RING + slot * TILE + (w_chunk0 + i) * 1024), 16, 0, FMI_AUX_W);
+  };
+  auto slot_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS reads are done: the slots I read may be refilled
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: what the steady-state rule would have issued before LOAD(0): A(0) (both
+  // halves), W(0), W(1), and the rows group 0 reads of A(1) (staged by group 1)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_a(0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_w(0, 0, i);
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_w(1, 1, i);
+    if (g == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_a(1, i);
     }
-    if (P.bias) {
-      if (full) {
-        const uint2 b = *reinterpret_cast<const uint2*>(P.bias + n);
-        v[0] += bf16_to_f32((bf16_t)(b.x & 0xffff));
-        v[1] += bf16_to_f32((bf16_t)(b.x >> 16));
-        v[2] += bf16_to_f32((bf16_t)(b.y & 0xffff));
-        v[3] += bf16_to_f32((bf16_t)(b.y >> 16));
-      } else {
-        for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(P.bias[n + e]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  slot_barrier();
+  if (g == 1) slot_barrier();  // group 1 starts one slot late
+
+  bf16x8_t xf[4][4], wf[4][NJ];
+  int wr = 0;  // W slot of tile t = t % 3
+  int wi = 2;  // W slot of tile t + 2
+  auto ktile = [&](int t, auto main_tag) {
+    constexpr bool MAIN = decltype(main_tag)::value;  // steady state: both issues are in range
+    // ---- LOAD(t): fragments -> registers, then this wave's DMA pieces (issuing them first was
+    // measured 8-10 % slower: the ds_reads queue up behind DMA instructions blocked on a full queue)
+    const bool a_ok = MAIN || (t + 1 + g < nk);
+    const bool w_ok = MAIN || (t + 2 < nk);
+    auto issue_dma = [&]() {
+#ifndef FMI_PP_NO_DMA
+      if (a_ok) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_a(t + 1 + g, i);
+      }
+      if (w_ok) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_w(t + 2, wi, i);
+      }
+#endif
+    };
+#ifdef FMI_PP_DMA_FIRST
+    issue_dma();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    {
+      const char* la = smem + A_RING + (t & 1) * TILE + a_row_off;
+      const char* lw = smem + W_RING + wr * TILE + w_row_off;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wf[s][j] = *reinterpret_cast<const bf16x8_t*>(lw + j * 32 * 128 + koff[s]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[s][i] = *reinterpret_cast<const bf16x8_t*>(la + i * 32 * 128 + koff[s]);
       }
     }
-    if (epi == EPI_GELU_BF16 || (epi == EPI_GELU_FROM_COL && n >= P.gelu_from)) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-    } else if (epi == EPI_SILU_BF16) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
-    }
-  };
-  const bool f32_out = (epi == EPI_RESID_GATE_F32 || epi == EPI_STORE_F32);
-#ifdef FMI_ABLATE_NO_EPI
-  if (alpha != 12345.f) return;  // ablation: skip the stores but keep the accumulators live
+#ifndef FMI_PP_DMA_FIRST
+    __builtin_amdgcn_sched_barrier(0);
+    issue_dma();
 #endif
-  // Staged path: the C tile goes through LDS (free after the K loop) and leaves as whole 128-B
-  // (bf16) / 256-B (f32) row segments with 16-B stores.  Direct per-lane stores touch 32 partial
-  // cache lines per instruction and cost ~30 us per tile with nothing else resident on the CU.
-  const bool staged = (P.ldo % 8 == 0) && (n0 + BN <= P.N) && ((reinterpret_cast<uintptr_t>(P.out) & 15) == 0) && epi != EPI_RESID_ADD_BF16 &&
-                      (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias) & 7) == 0);
-  if (staged) {
-    __syncthreads();  // every wave is done with the operand tiles
-    char* cw = smem + wave * (8192 * NJ);  // wave-private staging region
-    const int ncol0 = n0 + wn * 32 * NJ;
-    if (!f32_out) {
-      constexpr int RB = 64 * NJ;   // bytes per staged row (32*NJ bf16)
-      constexpr int NS8 = 8 * NJ;   // 8-byte slots per row
+    __builtin_amdgcn_sched_barrier(0);
+    if (MAIN) {
+#ifndef FMI_PP_NO_WAIT
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+    } else {  // tail: wait for everything but what was issued just now
+      if (a_ok && w_ok)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (a_ok || w_ok)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    slot_barrier();
+    // ---- COMPUTE(t): the matrix pipe only
+#ifdef FMI_PP_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-            finish(ncol0 + j * 32 + q * 8 + 4 * hl, v, true);
-            const int r = i * 32 + l31, c = j * 8 + q * 2 + hl;
-            *reinterpret_cast<uint2*>(cw + r * RB + ((c ^ (r & (NS8 - 1))) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-          }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      constexpr int LPR = RB / 16, RPI = 64 / LPR;  // lanes per row, rows per wave-instruction
-      bf16_t* ob = reinterpret_cast<bf16_t*>(P.out);
-#pragma unroll
-      for (int it = 0; it < 128 / RPI; ++it) {
-        const int r = it * RPI + lane / LPR, ch = lane % LPR;
-        const int sp = ((2 * ch) ^ (r & (NS8 - 1))) & ~1;
-        uint4 d = *reinterpret_cast<const uint4*>(cw + r * RB + (sp << 3));
-        if (r & 1) d = make_uint4(d.z, d.w, d.x, d.y);  // odd rows hold the slot pair swapped
-        const int m = m0 + wm * 128 + r;
-        if (m < P.M) *reinterpret_cast<uint4*>(ob + (int64_t)m * P.ldo + ncol0 + ch * 8) = d;
-      }
-    } else {
-      constexpr int RBF = 128 * NJ;  // bytes per staged row (32*NJ f32)
-      constexpr int NS16 = 8 * NJ;   // 16-byte slots per row
-      constexpr int LPR = RBF / 16, RPI = 64 / LPR;
-      float* of = reinterpret_cast<float*>(P.out);
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float v[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = acc[pass * 2 + ii][j][q * 4 + e];
-              finish(ncol0 + j * 32 + q * 8 + 4 * hl, v, true);
-              const int r = ii * 32 + l31, c = j * 8 + q * 2 + hl;
-              *reinterpret_cast<float4*>(cw + r * RBF + ((c ^ (r & (NS16 - 1))) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < 64 / RPI; ++it) {
-          const int r = it * RPI + lane / LPR, ch = lane % LPR;
-          const float4 v = *reinterpret_cast<const float4*>(cw + r * RBF + ((ch ^ (r & (NS16 - 1))) << 4));
-          const int m = m0 + wm * 128 + pass * 64 + r, n = ncol0 + ch * 4;
-          if (m < P.M) {
-            float* o = of + (int64_t)m * P.ldo + n;
-            if (epi == EPI_RESID_GATE_F32) {
-              const float* gate = P.gate + (P.rows_per_batch > 0 ? (int64_t)(m / P.rows_per_batch) * P.gate_bstride : 0);
-              const float4 g = *reinterpret_cast<const float4*>(gate + n);
-              float4 x = *reinterpret_cast<float4*>(o);
-              x.x += g.x * v.x;
-              x.y += g.y * v.y;
-              x.z += g.z * v.z;
-              x.w += g.w * v.w;
-              *reinterpret_cast<float4*>(o) = x;
-            } else {
-              *reinterpret_cast<float4*>(o) = v;
-            }
-          }
+        for (int j = 0; j < NJ; ++j) {
+#if defined(FMI_PP_HALF_MFMA)
+          if (s < 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][j], xf[s][i], acc[i][j], 0, 0, 0);
+          else acc[i][j][0] += __builtin_bit_cast(f32x4, wf[s][j])[0] + __builtin_bit_cast(f32x4, xf[s][i])[1];
+#elif !defined(FMI_PP_NO_MFMA)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][j], xf[s][i], acc[i][j], 0, 0, 0);
+#else
+          acc[i][j][0] += __builtin_bit_cast(f32x4, wf[s][j])[0] + __builtin_bit_cast(f32x4, xf[s][i])[1];
+#endif
         }
-      }
-    }
-    return;
-  }
-  // ---- direct path (ragged N tile, unaligned output, bf16 residual add)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 128 + i * 32 + l31;
-    if (m >= P.M) continue;
-    const float* gate = P.gate;
-    if (epi == EPI_RESID_GATE_F32 && P.rows_per_batch > 0) gate += (int64_t)(m / P.rows_per_batch) * P.gate_bstride;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 32 * NJ + j * 32 + q * 8 + 4 * hl;
-        if (n >= P.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-        const bool full = (n + 3 < P.N) && (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias + n) & 7) == 0);
-        finish(n, v, full);
-        if (epi == EPI_RESID_GATE_F32) {
-          float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
-          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] += gate[n + e] * v[e];
-        } else if (epi == EPI_STORE_F32) {
-          float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
-          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = v[e];
-        } else {
-          bf16_t* o = reinterpret_cast<bf16_t*>(P.out) + (int64_t)m * P.ldo + n;
-          if (epi == EPI_RESID_ADD_BF16) {
-            const bf16_t* r = reinterpret_cast<const bf16_t*>(P.resid) + (int64_t)m * P.ldo + n;
-            for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(r[e]);
-          }
-          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = f32_to_bf16(v[e]);
-        }
-      }
-    }
-  }
+#ifdef FMI_PP_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef FMI_PP_SLEEP
+    __builtin_amdgcn_s_sleep(FMI_PP_SLEEP);  // ablation: stand-in for the MFMA time (64 clocks per unit)
+#endif
+    slot_barrier();
+    wr = wr == 2 ? 0 : wr + 1;
+    wi = wi == 2 ? 0 : wi + 1;
+  };
+  const int nmain = nk > 2 ? nk - 2 : 0;  // t + 2 < nk  (and t + 1 + g < nk)
+  for (int t = 0; t < nmain; ++t) ktile(t, std::true_type{});
+  for (int t = nmain; t < nk; ++t) ktile(t, std::false_type{});
+  if (g == 0) slot_barrier();  // group 0 finished one slot early
+
+  gemm_epilogue<NJ>(P, acc, smem, m0, n0, wave, lane);
 }
+
+static bool g_pingpong = true;
+void set_gemm_pingpong(bool on) { g_pingpong = on; }
 
 int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   if (nprob <= 0) return FMI_OK;
@@ -498,6 +720,8 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
     FMI_GEMM_LAUNCH(2);
   else if (quant)
     FMI_GEMM_LAUNCH(1);
+  else if (bn == 256 && g_pingpong)
+    hipLaunchKernelGGL(gemm_pp_kernel, grid, blk, 0, stream, b);
   else
     FMI_GEMM_LAUNCH(0);
 #undef FMI_GEMM_LAUNCH

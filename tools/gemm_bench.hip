@@ -27,6 +27,12 @@ __global__ void fill_kernel(bf16_t* p, size_t n, uint32_t seed) {
   }
 }
 
+__global__ void count_mismatch(const bf16_t* a, const bf16_t* b, size_t n, unsigned long long* out) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+  if (c) atomicAdd(out, c);
+}
+
 int main(int argc, char** argv) {
   struct Shape { int M, N, K; const char* name; };
   std::vector<Shape> shapes = {{4608, 21504, 3072, "single qkv+mlp"}, {4608, 3072, 15360, "single proj_out"}, {4096, 9216, 3072, "double qkv img"},
@@ -51,20 +57,34 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
+  bf16_t* O2;
+  hipMalloc((void**)&O2, maxO * 2);
+  unsigned long long* d_mis;
+  hipMalloc((void**)&d_mis, 8);
   for (auto& s : shapes) {
     GemmProblem p{};
     p.A = A, p.W = W, p.out = O, p.M = s.M, p.N = s.N, p.K = s.K, p.lda = s.K + pad_a, p.ldw = s.K + pad_w, p.ldo = s.N + pad_o, p.epi = EPI_STORE_BF16, p.alpha = 1.f;
-    for (int i = 0; i < 2; ++i) launch_gemm(&p, 1, nullptr);
-    hipDeviceSynchronize();
-    hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; ++i) launch_gemm(&p, 1, nullptr);
-    hipEventRecord(e1, nullptr);
-    hipEventSynchronize(e1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    ms /= iters;
-    double tf = 2.0 * s.M * s.N * s.K / (ms * 1e-3) / 1e12;
-    printf("%-18s M=%5d N=%5d K=%5d  %8.3f ms  %7.1f TF\n", s.name, s.M, s.N, s.K, ms, tf);
+    double tf[2];
+    for (int pp = 0; pp < 2; ++pp) {  // double-buffered kernel, then the ping-pong kernel
+      set_gemm_pingpong(pp != 0);
+      p.out = pp ? O2 : O;
+      for (int i = 0; i < 2; ++i) launch_gemm(&p, 1, nullptr);
+      hipDeviceSynchronize();
+      hipEventRecord(e0, nullptr);
+      for (int i = 0; i < iters; ++i) launch_gemm(&p, 1, nullptr);
+      hipEventRecord(e1, nullptr);
+      hipEventSynchronize(e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      ms /= iters;
+      tf[pp] = 2.0 * s.M * s.N * s.K / (ms * 1e-3) / 1e12;
+    }
+    hipMemset(d_mis, 0, 8);
+    count_mismatch<<<1024, 256>>>(O, O2, (size_t)s.M * p.ldo, d_mis);
+    unsigned long long mis = 0;
+    hipMemcpy(&mis, d_mis, 8, hipMemcpyDeviceToHost);
+    printf("%-18s M=%5d N=%5d K=%5d  double-buffered %7.1f TF   ping-pong %7.1f TF   mismatching elements %llu%s\n", s.name, s.M, s.N, s.K, tf[0], tf[1], mis,
+           hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
   }
   return 0;
 }

@@ -1,0 +1,67 @@
+// tools/mfma_peak.hip — what the matrix pipes sustain with nothing else going on: back-to-back
+// v_mfma_f32_32x32x16_bf16 on register operands (random bf16, not zeros: DVFS), W waves per SIMD.
+// Usage: mfma_peak [ms_target]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int NACC>
+__global__ __launch_bounds__(512, 2) void mfma_loop(const uint4* in, float* out, int iters) {
+  const int tid = threadIdx.x;
+  uint4 ua = in[tid], ub = in[512 + tid];
+  bf16x8_t a = __builtin_bit_cast(bf16x8_t, ua), b = __builtin_bit_cast(bf16x8_t, ub);
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][7];
+  out[(size_t)blockIdx.x * blockDim.x + tid] = s;
+}
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 20000;
+  uint4* in;
+  float* out;
+  hipMalloc((void**)&in, 1024 * 16);
+  hipMalloc((void**)&out, 512 * 512 * 4);
+  uint32_t h[4096];
+  uint32_t x = 12345;
+  for (int i = 0; i < 4096; ++i) {
+    x = x * 1664525u + 1013904223u;
+    // two bf16 in [-1,1): sign + exponent 0x3f00..0x3f7f
+    uint32_t lo = 0x3f00 | ((x >> 8) & 0x7f) | ((x & 1) << 15), hi = 0x3f00 | ((x >> 16) & 0x7f) | ((x & 2) << 14);
+    h[i] = lo | (hi << 16);
+  }
+  hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int threads : {256, 512}) {
+    for (int blocks : {256, 512}) {
+      for (int rep = 0; rep < 2; ++rep) {
+        const int n = rep ? iters * 20 : iters;  // short (~ms) and long (~100 ms) runs: DVFS settles in the long one
+        mfma_loop<8><<<blocks, threads>>>(in, out, 100);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        mfma_loop<8><<<blocks, threads>>>(in, out, n);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flop = (double)blocks * (threads / 64) * (double)n * 8 * 2.0 * 32 * 32 * 16;
+        printf("blocks %3d x %d waves, %8d iters: %8.2f ms  %7.1f TFLOP/s\n", blocks, threads / 64, n, ms, flop / (ms * 1e-3) / 1e12);
+      }
+    }
+  }
+  return 0;
+}
