@@ -224,8 +224,9 @@ def main():
                 traffic = json.load(f).get("traffic_bytes_per_launch")
         except Exception:
             pass
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<0,2> (bf16 MFMA GEMM, all block linears)", "achieved": round(ach, 1), "peak": 2500.0,
+        roof = {"bound": "mfma", "kernel": "gemm_pp_kernel (bf16 MFMA GEMM, all block linears)", "achieved": round(ach, 1), "peak": 2500.0,
                 "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
+                "peak_note": "2500 = dense bf16 MFMA peak at 2.4 GHz; a register-only MFMA loop (tools/mfma_peak.hip) sustains 2020 on this part (power cap, ~1.95 GHz)",
                 "traffic_note": "HBM-side bytes per launch = FETCH_SIZE*2 + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/), not re-measured in this run",
                 "launches_per_step": gemm_launches, "avg_launch_ms": round(gemm_ms / gemm_launches, 4),
                 "flop_per_launch_avg": gemm_fl / gemm_launches, "measured_on": f"profiled pass, {nprof} denoise steps, hipEvents on the launch stream"}
