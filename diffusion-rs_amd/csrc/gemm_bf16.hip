@@ -40,6 +40,9 @@ namespace fmi {
 #ifndef FMI_AUX_W
 #define FMI_AUX_W 0
 #endif
+#ifndef FMI_PP_EARLY
+#define FMI_PP_EARLY 0  // ping-pong kernel: MFMA pairs issued after the slot-closing barrier (measured: 0 is best, 2-8 cost 4-6 %)
+#endif
 #ifndef FMI_GH
 #define FMI_GH 8  // tile-rows per band of the tile order (see the kernel)
 #endif
@@ -650,7 +653,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        // experiment knob: signal the slot-closing barrier FMI_PP_EARLY MFMA pairs before the end
+        if (s * 4 + i == 16 - FMI_PP_EARLY) slot_barrier();
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
 #if defined(FMI_PP_HALF_MFMA)
@@ -662,13 +667,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
           acc[i][j][0] += __builtin_bit_cast(f32x4, wf[s][j])[0] + __builtin_bit_cast(f32x4, xf[s][i])[1];
 #endif
         }
+      }
 #ifdef FMI_PP_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
 #ifdef FMI_PP_SLEEP
     __builtin_amdgcn_s_sleep(FMI_PP_SLEEP);  // ablation: stand-in for the MFMA time (64 clocks per unit)
 #endif
-    slot_barrier();
+    if (FMI_PP_EARLY == 0) slot_barrier();
     wr = wr == 2 ? 0 : wr + 1;
     wi = wi == 2 ? 0 : wi + 1;
   };
