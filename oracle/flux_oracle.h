@@ -71,6 +71,20 @@ void orc_vae_destroy(orc_vae*);
 int orc_vae_set_tensor(orc_vae*, const char* name, const float* data, int64_t numel);
 int orc_vae_decode(orc_vae*, const float* z, int B, int h, int w, float* out);
 
+/* ---- text encoders (oracle/text_oracle.cpp) ---- */
+typedef struct orc_t5 orc_t5;
+/* act: 0 = relu, ungated (T5DenseActDense); 1 = gated-gelu (NewGelu); 2 = gated-silu */
+orc_t5* orc_t5_create(int vocab_size, int d_model, int d_kv, int d_ff, int num_layers, int num_heads, int rel_buckets, int rel_max_distance, float eps, int act);
+void orc_t5_destroy(orc_t5*);
+int orc_t5_set_tensor(orc_t5*, const char* name, const float* data, int64_t numel);
+int orc_t5_bucket(int i, int j, int num_buckets_total, int max_distance);
+int orc_t5_forward(orc_t5*, const int32_t* ids, int B, int T, float* out /* (B,T,d_model) */);
+typedef struct orc_clip orc_clip;
+orc_clip* orc_clip_create(int vocab_size, int projection_dim, int intermediate_size, int max_position_embeddings, int num_hidden_layers, int num_attention_heads);
+void orc_clip_destroy(orc_clip*);
+int orc_clip_set_tensor(orc_clip*, const char* name, const float* data, int64_t numel);
+int orc_clip_forward(orc_clip*, const int32_t* ids, int B, int T, float* hidden_out /* (B,T,hidden) or NULL */, float* pooled /* (B,hidden) */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,9 @@ def lib():
         _lib.orc_round_f16.argtypes = [C.c_float]
         _lib.orc_flux_create.restype = C.c_void_p
         _lib.orc_vae_create.restype = C.c_void_p
+        _lib.orc_t5_create.restype = C.c_void_p
+        _lib.orc_t5_create.argtypes = [C.c_int] * 8 + [C.c_float, C.c_int]
+        _lib.orc_clip_create.restype = C.c_void_p
     return _lib
 
 
@@ -368,3 +371,71 @@ class Vae:
         if rc:
             raise RuntimeError("oracle vae_decode failed rc=%d" % rc)
         return out
+
+
+T5_ACT = {"relu": 0, "gated-gelu": 1, "gated-silu": 2}
+
+
+class T5:
+    """CPU oracle of t5::T5EncoderModel (t5/mod.rs:609-632), f32.  cfg keys = T5Config (t5/mod.rs:72-91)."""
+
+    def __init__(self, cfg):
+        self.cfg = dict(cfg)
+        self.h = C.c_void_p(lib().orc_t5_create(cfg["vocab_size"], cfg["d_model"], cfg["d_kv"], cfg["d_ff"], cfg["num_layers"], cfg["num_heads"],
+                                                cfg["relative_attention_num_buckets"], cfg.get("relative_attention_max_distance", 128),
+                                                C.c_float(cfg["layer_norm_epsilon"]), T5_ACT[cfg.get("feed_forward_proj", "relu")]))
+
+    def __del__(self):
+        try:
+            lib().orc_t5_destroy(self.h)
+        except Exception:
+            pass
+
+    def load(self, tensors):
+        for k, v in tensors.items():
+            a, ap = _f(v)
+            lib().orc_t5_set_tensor(self.h, k.encode(), ap, C.c_int64(a.size))
+
+    def forward(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        B, T = ids.shape
+        out = np.empty((B, T, self.cfg["d_model"]), np.float32)
+        rc = lib().orc_t5_forward(self.h, ids.ctypes.data_as(C.POINTER(C.c_int32)), B, T, out.ctypes.data_as(f32p))
+        if rc:
+            raise RuntimeError("oracle t5_forward failed rc=%d" % rc)
+        return out
+
+
+def t5_bucket(i, j, num_buckets=32, max_distance=128):
+    return lib().orc_t5_bucket(int(i), int(j), int(num_buckets), int(max_distance))
+
+
+class Clip:
+    """CPU oracle of clip::text::ClipTextTransformer (clip/text.rs:243-317), f32.  cfg keys = ClipTextConfig."""
+
+    def __init__(self, cfg):
+        self.cfg = dict(cfg)
+        self.h = C.c_void_p(lib().orc_clip_create(cfg["vocab_size"], cfg["projection_dim"], cfg["intermediate_size"], cfg["max_position_embeddings"],
+                                                  cfg["num_hidden_layers"], cfg["num_attention_heads"]))
+
+    def __del__(self):
+        try:
+            lib().orc_clip_destroy(self.h)
+        except Exception:
+            pass
+
+    def load(self, tensors):
+        for k, v in tensors.items():
+            a, ap = _f(v)
+            lib().orc_clip_set_tensor(self.h, k.encode(), ap, C.c_int64(a.size))
+
+    def forward(self, ids, return_hidden=False):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        B, T = ids.shape
+        D = self.cfg["projection_dim"]
+        hid = np.empty((B, T, D), np.float32)
+        pooled = np.empty((B, D), np.float32)
+        rc = lib().orc_clip_forward(self.h, ids.ctypes.data_as(C.POINTER(C.c_int32)), B, T, hid.ctypes.data_as(f32p), pooled.ctypes.data_as(f32p))
+        if rc:
+            raise RuntimeError("oracle clip_forward failed rc=%d" % rc)
+        return (pooled, hid) if return_hidden else pooled
