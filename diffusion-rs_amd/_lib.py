@@ -39,6 +39,19 @@ class SchedulerConfigC(C.Structure):
                 ("shift", C.c_double), ("use_dynamic_shifting", C.c_int)]
 
 
+class T5Config(C.Structure):
+    """fmi_t5_config == t5::T5Config (t5/mod.rs:72-91)."""
+    _fields_ = [("vocab_size", C.c_int), ("d_model", C.c_int), ("d_kv", C.c_int), ("d_ff", C.c_int), ("num_layers", C.c_int), ("num_heads", C.c_int),
+                ("relative_attention_num_buckets", C.c_int), ("relative_attention_max_distance", C.c_int), ("layer_norm_epsilon", C.c_float),
+                ("feed_forward_act", C.c_int)]
+
+
+class ClipConfig(C.Structure):
+    """fmi_clip_config == clip::text::ClipTextConfig (clip/text.rs:24-33)."""
+    _fields_ = [("vocab_size", C.c_int), ("projection_dim", C.c_int), ("intermediate_size", C.c_int), ("max_position_embeddings", C.c_int),
+                ("num_hidden_layers", C.c_int), ("num_attention_heads", C.c_int)]
+
+
 F32, F16, BF16, U8, I8 = 0, 1, 2, 3, 4
 MODEL_AUTO, MODEL_BF16, MODEL_F16, MODEL_F32 = 0, 1, 2, 3
 
@@ -78,6 +91,17 @@ def load():
     lib.fmi_vae_set_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
     lib.fmi_flux_set_linear_bnb4.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.fmi_flux_forward.argtypes = [C.c_void_p, C.POINTER(FluxInputs), C.c_void_p, C.c_void_p]
+    for enc in ("t5", "clip"):
+        getattr(lib, f"fmi_{enc}_set_tensor").argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
+        getattr(lib, f"fmi_{enc}_missing_name").restype = C.c_char_p
+        getattr(lib, f"fmi_{enc}_missing_name").argtypes = [C.c_void_p, C.c_int]
+        getattr(lib, f"fmi_{enc}_missing_count").argtypes = [C.c_void_p]
+        getattr(lib, f"fmi_{enc}_size_in_bytes").restype = C.c_size_t
+        getattr(lib, f"fmi_{enc}_size_in_bytes").argtypes = [C.c_void_p]
+        getattr(lib, f"fmi_{enc}_destroy").argtypes = [C.c_void_p]
+        getattr(lib, f"fmi_{enc}_destroy").restype = None
+    lib.fmi_t5_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.fmi_clip_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.fmi_flux_denoise.argtypes = [C.c_void_p, C.POINTER(FluxInputs), C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_void_p]
     lib.fmi_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.fmi_pack_latents.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -118,7 +142,10 @@ EXPORTED = [
     "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
     "fmi_flux_forward", "fmi_flux_denoise", "fmi_flux_set_profiling", "fmi_flux_phase_count", "fmi_flux_phase_name", "fmi_flux_phase_ms",
     "fmi_vae_default_config", "fmi_vae_create", "fmi_vae_destroy", "fmi_vae_set_tensor", "fmi_vae_missing_count", "fmi_vae_missing_name",
-    "fmi_vae_scale_factor", "fmi_vae_shift_factor", "fmi_vae_decode", "fmi_pack_latents", "fmi_unpack_latents", "fmi_postprocess_u8",
+    "fmi_vae_scale_factor", "fmi_vae_shift_factor", "fmi_vae_decode",
+    "fmi_t5_default_config", "fmi_t5_create", "fmi_t5_destroy", "fmi_t5_set_tensor", "fmi_t5_missing_count", "fmi_t5_missing_name",
+    "fmi_t5_size_in_bytes", "fmi_t5_forward", "fmi_clip_default_config", "fmi_clip_create", "fmi_clip_destroy", "fmi_clip_set_tensor",
+    "fmi_clip_missing_count", "fmi_clip_missing_name", "fmi_clip_size_in_bytes", "fmi_clip_forward", "fmi_pack_latents", "fmi_unpack_latents", "fmi_postprocess_u8",
     "fmi_randn", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_sdpa_bf16", "fmi_layernorm_mod",
     "fmi_groupnorm_nhwc", "fmi_conv2d_nhwc",
     "dequantize_blockwise_f32_int8", "dequantize_blockwise_f32_fp4", "dequantize_blockwise_f32_nf4", "dequantize_blockwise_f16_int8",

@@ -84,6 +84,15 @@ class FileLoader:
                 return json.load(f)
         return json.loads(bytes(self._entry_view(name)))
 
+    def read_text(self, name: str) -> str:
+        if self.kind == "dir":
+            with open(os.path.join(self.path, name), encoding="utf-8") as f:
+                return f.read()
+        return bytes(self._entry_view(name)).decode("utf-8")
+
+    def has(self, name: str) -> bool:
+        return name in self.files
+
     def tensors(self, component: str) -> Iterator[Tuple[str, torch.Tensor]]:
         """All tensors of every *.safetensors shard under `component/` (shards in name order)."""
         for fn in self.files:
@@ -158,4 +167,22 @@ def load_vae(vae, tensors: Iterator[Tuple[str, torch.Tensor]]) -> int:
         if name in want:
             vae.set_tensor(name, t)
             n += 1
+    return n
+
+
+def load_text_encoder(model, tensors: Iterator[Tuple[str, torch.Tensor]]) -> int:
+    """Feed a T5EncoderModel / ClipTextTransformer from (name, tensor) pairs; names the model does not
+    read (decoder-tied embeddings, position_ids buffers, CLIP's unused text_projection) are skipped."""
+    want = model.tensor_names()
+    n = 0
+    for name, t in tensors:
+        if name in want:
+            model.set_tensor(name, t)
+            n += 1
+        elif name == "encoder.embed_tokens.weight" and "shared.weight" in model.missing():
+            model.set_tensor("shared.weight", t)  # T5EncoderModel::new falls back to it (t5/mod.rs:615-621)
+            n += 1
+    m = model.missing()
+    if m:
+        raise ValueError(f"{len(m)} text-encoder tensors missing, e.g. {m[0]}")
     return n

@@ -7,11 +7,11 @@ diffusion_rs_core/src/pipelines/mod.rs:24-33,110-270) over the MI355X hot path.
     Pipeline(source, silent=False, token=None, revision=None, offloading=None, dtype=ModelDType.Auto)
     Pipeline.forward(prompts, params) -> list[bytes]   (PNG-encoded, as the pyo3 binding returns)
 
-Scope: the denoise loop and the VAE decode run on the GPU through the C-ABI.
-The T5/CLIP text encoders are §8(f) "next" rows and are NOT built: `forward` takes precomputed
-embeddings via `embeddings=(t5_emb, clip_emb)`; with plain string prompts it derives
-deterministic placeholder embeddings from the prompt text (documented stand-in, used by the
-benchmarks where only shapes matter).  Extensions over the reference, all keyword-only:
+Scope: text encoders (when the checkpoint ships them), the denoise loop and the VAE
+decode run on the GPU through the C-ABI.  Tokenisation needs the checkpoint's tokenizer files and
+the `tokenizers` package; without them pass `token_ids=(t5_ids, clip_ids)` or precomputed
+`embeddings=(t5_emb, clip_emb)`.  A pipeline built WITHOUT text encoders (the benchmark's synthetic
+source) derives deterministic placeholder embeddings from the prompt text — only shapes matter there.  Extensions over the reference, all keyword-only:
 `latents=` / `seed=` (the reference cannot be seeded), `embeddings=`, `output=`.
 """
 import enum
@@ -67,9 +67,12 @@ class ModelSource:
     dduf = DdufFile
 
     @staticmethod
-    def Synthetic(variant: str = "dev", seed: int = 0, flux_cfg: Optional[dict] = None, vae_cfg: Optional[dict] = None) -> "ModelSource":
-        """Random-init weights of the named architecture generated on the GPU (no checkpoints offline)."""
-        return ModelSource("synthetic", variant=variant, seed=seed, flux_cfg=flux_cfg, vae_cfg=vae_cfg)
+    def Synthetic(variant: str = "dev", seed: int = 0, flux_cfg: Optional[dict] = None, vae_cfg: Optional[dict] = None,
+                  text_encoders: bool = False, t5_cfg: Optional[dict] = None, clip_cfg: Optional[dict] = None) -> "ModelSource":
+        """Random-init weights of the named architecture generated on the GPU (no checkpoints offline).
+        text_encoders=True also builds T5 / CLIP (T5-XXL: 9 GiB of bf16 weights)."""
+        return ModelSource("synthetic", variant=variant, seed=seed, flux_cfg=flux_cfg, vae_cfg=vae_cfg, text_encoders=text_encoders,
+                           t5_cfg=t5_cfg, clip_cfg=clip_cfg)
 
     def __repr__(self):
         if self.kind == "model_id":
@@ -128,6 +131,7 @@ class Pipeline:
         self.device = torch.device("cuda", device)
         self._lock = threading.Lock()  # Arc<Mutex<dyn ModelPipeline>>, pipelines/mod.rs:110-113
         self.scheduler = F.SchedulerConfig()
+        self.t5 = self.clip = self.t5_tokenizer = self.clip_tokenizer = None
         if source.kind == "synthetic":
             fcfg = source.flux_cfg or (F.FLUX_DEV if source.variant == "dev" else F.FLUX_SCHNELL)
             vcfg = source.vae_cfg or F.VAE_FLUX
@@ -137,6 +141,12 @@ class Pipeline:
             synth.fill_vae_random_device(self.vae, seed=source.seed + 1, device=self.device)
             if source.variant != "dev":
                 self.scheduler = F.SchedulerConfig(shift=1.0, use_dynamic_shifting=False)
+            if getattr(source, "text_encoders", False):
+                from . import text
+                self.t5 = text.T5EncoderModel(source.t5_cfg, device)
+                synth.fill_text_random_device(self.t5, seed=source.seed + 2, device=self.device)
+                self.clip = text.ClipTextTransformer(source.clip_cfg, device)
+                synth.fill_text_random_device(self.clip, seed=source.seed + 3, device=self.device)
         elif source.kind == "model_id":
             self._load_checkpoint(source.model_id, getattr(source, "transformer_model_id", None))
         else:
@@ -163,6 +173,26 @@ class Pipeline:
         vcfg = dict(F.VAE_FLUX, **{k: vc[k] for k in F.VAE_FLUX if k in vc})
         self.vae = F.AutoEncoderKl(vcfg, self.device_index)
         loader.load_vae(self.vae, fl.tensors("vae"))
+        # text_encoder (CLIP) / text_encoder_2 (T5) + their tokenizers (flux/mod.rs:74-127), when the checkpoint ships them
+        if fl.has("text_encoder/config.json") and fl.has("text_encoder_2/config.json"):
+            from . import text
+            cc = fl.read_json("text_encoder/config.json")
+            # ClipTextConfig reads projection_dim as the hidden width (clip/text.rs:24-33); both are 768 for CLIP-L
+            self.clip = text.ClipTextTransformer({k: cc[k] for k in text.CLIP_L}, self.device_index)
+            loader.load_text_encoder(self.clip, fl.tensors("text_encoder"))
+            tc2 = fl.read_json("text_encoder_2/config.json")
+            t5cfg = {k: tc2[k] for k in text.T5_XXL if k in tc2}
+            t5cfg["quantization_config"] = tc2.get("quantization_config")
+            self.t5 = text.T5EncoderModel(t5cfg, self.device_index)
+            loader.load_text_encoder(self.t5, fl.tensors("text_encoder_2"))
+            try:
+                from tokenizers import Tokenizer
+                if fl.has("tokenizer/vocab.json") and fl.has("tokenizer/merges.txt"):
+                    self.clip_tokenizer = text.load_bpe_tokenizer(fl.read_text("tokenizer/vocab.json"), fl.read_text("tokenizer/merges.txt"))
+                if fl.has("tokenizer_2/tokenizer.json"):
+                    self.t5_tokenizer = Tokenizer.from_str(fl.read_text("tokenizer_2/tokenizer.json"))
+            except ImportError:
+                pass  # no `tokenizers` package: forward() then needs token_ids=
 
     @classmethod
     def load(cls, source, silent=False, token=None, revision=None, offloading_type=None, dtype=ModelDType.Auto, **kw):
@@ -170,14 +200,36 @@ class Pipeline:
         return cls(source, silent, token, revision, offloading_type, dtype, **kw)
 
     # ------------------------------------------------------------------------------------------
+    def encode_prompts(self, prompts: List[str], token_ids=None):
+        """Prompt -> (t5_emb (B,T,4096) bf16, clip_emb (B,768) f32): the first half of FluxPipeline::forward
+        (flux/mod.rs:237-262).  token_ids = (t5_ids, clip_ids) overrides tokenisation (no tokenizer files offline)."""
+        from . import text
+        if self.t5 is None or self.clip is None:
+            raise F.L.FmiError("this pipeline was built without text encoders")
+        if token_ids is not None:
+            t5_ids, clip_ids = token_ids
+        elif self.t5_tokenizer is not None and self.clip_tokenizer is not None:
+            t5_ids = text.tokenize_and_pad(prompts, self.t5_tokenizer)
+            clip_ids = text.tokenize_and_pad(prompts, self.clip_tokenizer)
+        else:
+            raise F.L.FmiError("no tokenizers loaded: pass token_ids=(t5_ids, clip_ids)")
+        t5_ids = torch.as_tensor(t5_ids, dtype=torch.int32)
+        if not self.flux.is_guidance():  # schnell: zero-pad the T5 ids to 256 (flux/mod.rs:243-255)
+            if t5_ids.shape[1] > 256:
+                raise ValueError("T5 embedding length greater than 256, please shrink the prompt or use the -dev (with guidance distillation) version.")
+            t5_ids = torch.nn.functional.pad(t5_ids, (0, 256 - t5_ids.shape[1]))
+        return self.t5.forward(t5_ids), self.clip.forward(torch.as_tensor(clip_ids, dtype=torch.int32))
+
     def generate_tensor(self, prompts: List[str], params: DiffusionGenerationParams, *, embeddings=None, latents=None,
-                        seed: Optional[int] = None, first_sample: int = 0) -> torch.Tensor:
+                        seed: Optional[int] = None, first_sample: int = 0, token_ids=None) -> torch.Tensor:
         """== ModelPipeline::forward for FluxPipeline (pipelines/flux/mod.rs:224-335) from the
         embeddings onward.  Returns (B,3,H,W) u8 on the device."""
         cfg = self.flux.cfg
         B = len(prompts)
         dev = self.device
-        if embeddings is None:
+        if embeddings is None and self.t5 is not None and (token_ids is not None or self.t5_tokenizer is not None):
+            t5_emb, clip_emb = self.encode_prompts(prompts, token_ids)
+        elif embeddings is None:
             # schnell pads T5 ids to 256 (flux/mod.rs:243-253); dev uses the prompt length — 512 here
             T = 256 if not self.flux.is_guidance() else 512
             t5_emb, clip_emb = placeholder_embeddings(prompts, T, cfg["joint_attention_dim"], cfg["pooled_projection_dim"], dev)

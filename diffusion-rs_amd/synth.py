@@ -205,3 +205,92 @@ def is_block_linear(name):
     """Linears of the DiT blocks that take the fused 4-bit GEMM path (everything a bnb checkpoint
     quantises inside transformer_blocks / single_transformer_blocks except the modulation linears)."""
     return name.endswith(".weight") and "transformer_blocks." in name and "norm" not in name
+
+
+# ------------------------------------------------------------------------------- text encoders
+def t5_tensor_shapes(cfg) -> "OrderedDict[str, tuple]":
+    """Tensor names/shapes T5EncoderModel::new reads (t5/mod.rs:614-627 and the loaders it calls)."""
+    D, I, F = cfg["d_model"], cfg["num_heads"] * cfg["d_kv"], cfg["d_ff"]
+    gated = cfg.get("feed_forward_proj", "relu") != "relu"
+    out = OrderedDict()
+    out["shared.weight"] = (cfg["vocab_size"], D)
+    out["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] = (cfg["relative_attention_num_buckets"], cfg["num_heads"])
+    for l in range(cfg["num_layers"]):
+        p = f"encoder.block.{l}.layer."
+        out[p + "0.layer_norm.weight"] = (D,)
+        for n in "qkv":
+            out[p + f"0.SelfAttention.{n}.weight"] = (I, D)
+        out[p + "0.SelfAttention.o.weight"] = (D, I)
+        out[p + "1.layer_norm.weight"] = (D,)
+        if gated:
+            out[p + "1.DenseReluDense.wi_0.weight"] = (F, D)
+            out[p + "1.DenseReluDense.wi_1.weight"] = (F, D)
+        else:
+            out[p + "1.DenseReluDense.wi.weight"] = (F, D)
+        out[p + "1.DenseReluDense.wo.weight"] = (D, F)
+    out["encoder.final_layer_norm.weight"] = (D,)
+    return out
+
+
+def clip_tensor_shapes(cfg) -> "OrderedDict[str, tuple]":
+    """Tensor names/shapes ClipTextTransformer::new reads under vb.pp("text_model") (clip/text.rs:251-262)."""
+    D, F = cfg["projection_dim"], cfg["intermediate_size"]
+    out = OrderedDict()
+    tm = "text_model."
+    out[tm + "embeddings.token_embedding.weight"] = (cfg["vocab_size"], D)
+    out[tm + "embeddings.position_embedding.weight"] = (cfg["max_position_embeddings"], D)
+    for l in range(cfg["num_hidden_layers"]):
+        p = tm + f"encoder.layers.{l}."
+        for ln in ("layer_norm1", "layer_norm2"):
+            out[p + ln + ".weight"] = (D,)
+            out[p + ln + ".bias"] = (D,)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            out[p + f"self_attn.{n}.weight"] = (D, D)
+            out[p + f"self_attn.{n}.bias"] = (D,)
+        out[p + "mlp.fc1.weight"] = (F, D)
+        out[p + "mlp.fc1.bias"] = (F,)
+        out[p + "mlp.fc2.weight"] = (D, F)
+        out[p + "mlp.fc2.bias"] = (D,)
+    out[tm + "final_layer_norm.weight"] = (D,)
+    out[tm + "final_layer_norm.bias"] = (D,)
+    return out
+
+
+def text_state_dict_numpy(shapes, seed=0, round_bf16=True):
+    """Seeded synthetic encoder weights: matrices ~N(0, 1/fan_in), embeddings ~N(0,1) (T5 relative
+    bias ~N(0,1)), norm weights 1 + 0.1 N(0,1), biases 0.1 N(0,1); rounded to bf16 values."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for name, shp in shapes.items():
+        if len(shp) == 2 and ("embedding" in name or name == "shared.weight" or "relative_attention_bias" in name):
+            a = rng.standard_normal(shp)
+        elif len(shp) == 2:
+            a = rng.standard_normal(shp) / np.sqrt(shp[1])
+            if name.endswith("SelfAttention.q.weight"):
+                a = a / 8.0  # T5 has no 1/sqrt(d_kv) in attention: its q init carries it (HF: std (d_model*d_kv)^-0.5)
+        elif name.endswith("norm.weight") or "layer_norm1.weight" in name or "layer_norm2.weight" in name:
+            a = 1.0 + 0.1 * rng.standard_normal(shp)
+        else:
+            a = 0.1 * rng.standard_normal(shp)
+        a = a.astype(np.float32)
+        sd[name] = to_bf16_f32(a) if round_bf16 else a
+    return sd
+
+
+def fill_text_random_device(model, seed=0, device="cuda"):
+    """Random-init an encoder at full size directly on the GPU (T5-XXL: 4.7 B parameters)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    for name, shp in model.tensor_names().items():
+        if len(shp) == 2 and ("embedding" in name or name == "shared.weight" or "relative_attention_bias" in name):
+            t = torch.randn(shp, generator=g, device=device)
+        elif len(shp) == 2:
+            t = torch.randn(shp, generator=g, device=device) / shp[1] ** 0.5
+            if name.endswith("SelfAttention.q.weight"):
+                t = t / 8.0
+        elif "norm" in name and name.endswith(".weight"):
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g, device=device)
+        else:
+            t = 0.1 * torch.randn(shp, generator=g, device=device)
+        model.set_tensor(name, t.to(torch.bfloat16))

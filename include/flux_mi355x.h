@@ -205,6 +205,58 @@ double fmi_vae_shift_factor(const fmi_vae*);
 int fmi_vae_decode(fmi_vae*, const float* z, int B, int h, int w, float* image_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Text encoders — they run once per image in front of the denoise loop and
+ * produce its `txt` (B,T,4096) and `y` (B,768) inputs (pipelines/flux/mod.rs:237-262).
+ * Token ids are int32, row-major (B,T), in host OR device memory (copied with hipMemcpyDefault).
+ * Tokenisation itself (tokenizers crate, flux/mod.rs:203-221) stays on the host side.
+ * ---------------------------------------------------------------------------------- */
+/* T5Config (diffusion_rs_core/src/models/t5/mod.rs:72-91); feed_forward_proj as an enum */
+typedef enum fmi_t5_act { FMI_T5_RELU = 0 /* "relu", ungated */, FMI_T5_GATED_GELU = 1 /* "gated-gelu" (NewGelu) */, FMI_T5_GATED_SILU = 2 } fmi_t5_act;
+typedef struct fmi_t5_config {
+  int vocab_size, d_model, d_kv, d_ff, num_layers, num_heads;
+  int relative_attention_num_buckets, relative_attention_max_distance;
+  float layer_norm_epsilon;
+  fmi_t5_act feed_forward_act;
+} fmi_t5_config;
+typedef struct fmi_t5 fmi_t5;
+void fmi_t5_default_config(fmi_t5_config*); /* t5-v1_1-xxl encoder (FLUX.1 text_encoder_2) */
+/* == T5EncoderModel::new (t5/mod.rs:614-627); d_kv must be 64, d_model/d_ff multiples of 64;
+ * quantised (bnb) T5 linears are not supported (FMI_ERR_INVALID on their side tensors). */
+int fmi_t5_create(const fmi_t5_config*, fmi_t5** out);
+void fmi_t5_destroy(fmi_t5*);
+/* tensor names as T5EncoderModel's VarBuilder reads them: shared.weight,
+ * encoder.block.N.layer.0.{layer_norm.weight, SelfAttention.{q,k,v,o}.weight},
+ * encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight,
+ * encoder.block.N.layer.1.{layer_norm.weight, DenseReluDense.{wi_0,wi_1,wo}.weight},
+ * encoder.final_layer_norm.weight */
+int fmi_t5_set_tensor(fmi_t5*, const char* name, const void* data, fmi_dtype dtype, const int64_t* shape, int rank);
+int fmi_t5_missing_count(const fmi_t5*);
+const char* fmi_t5_missing_name(fmi_t5*, int i);
+size_t fmi_t5_size_in_bytes(const fmi_t5*);
+/* == T5EncoderModel::forward (t5/mod.rs:629-631): out (B,T,d_model) device, FMI_BF16 or FMI_F32.
+ * Synchronises the stream before returning (token-id range check). */
+int fmi_t5_forward(fmi_t5*, const int32_t* input_ids, int B, int T, void* out, fmi_dtype out_dtype, void* stream);
+
+/* ClipTextConfig (models/clip/text.rs:24-33): projection_dim is used as the hidden width */
+typedef struct fmi_clip_config {
+  int vocab_size, projection_dim, intermediate_size, max_position_embeddings, num_hidden_layers, num_attention_heads;
+} fmi_clip_config;
+typedef struct fmi_clip fmi_clip;
+void fmi_clip_default_config(fmi_clip_config*); /* clip-vit-large-patch14 text tower (FLUX.1 text_encoder) */
+int fmi_clip_create(const fmi_clip_config*, fmi_clip** out); /* head dim must be 64 */
+void fmi_clip_destroy(fmi_clip*);
+/* names under the "text_model." prefix (flux/mod.rs:105), e.g.
+ * text_model.encoder.layers.N.self_attn.q_proj.{weight,bias} */
+int fmi_clip_set_tensor(fmi_clip*, const char* name, const void* data, fmi_dtype dtype, const int64_t* shape, int rank);
+int fmi_clip_missing_count(const fmi_clip*);
+const char* fmi_clip_missing_name(fmi_clip*, int i);
+size_t fmi_clip_size_in_bytes(const fmi_clip*);
+/* == ClipTextTransformer::forward (clip/text.rs:303-317): pooled (B,projection_dim) = final
+ * hidden state at argmax(token id) of each row, FMI_F32 or FMI_BF16; hidden_out (B,T,dim) f32
+ * optional (NULL to skip).  Synchronises the stream before returning. */
+int fmi_clip_forward(fmi_clip*, const int32_t* input_ids, int B, int T, void* pooled_out, fmi_dtype pooled_dtype, float* hidden_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Pipeline glue on device — the tensor code of FluxPipeline::forward
  * (pipelines/flux/mod.rs:270-332) and flux/sampling.rs
  * ---------------------------------------------------------------------------------- */

@@ -159,3 +159,77 @@ def test_dduf_with_bnb_nf4_nested_absmax(tmp_path):
         z.writestr("model_index.json", json.dumps({"_class_name": "FluxPipeline"}) * 50)
     with pytest.raises(ValueError):
         d.Pipeline(d.ModelSource.DdufFile(bad))
+
+
+def test_prompt_to_image_with_text_encoders(tmp_path):
+    """§8(f) rank 2: string prompts -> tokenizers -> T5 + CLIP on the GPU -> denoise -> VAE -> u8, from a
+    diffusers directory that ships text_encoder / text_encoder_2 / tokenizer / tokenizer_2, vs the oracle
+    chain (oracle T5/CLIP -> oracle FLUX -> oracle VAE) on the same token ids and latents."""
+    import torch
+    from safetensors.torch import save_file
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    import diffusion_rs_amd as d
+    from oracle import oracle as orc
+    t5_cfg = dict(vocab_size=64, d_model=SMALL_FLUX["joint_attention_dim"], d_kv=64, d_ff=256, num_layers=2, num_heads=2, relative_attention_num_buckets=32,
+                  relative_attention_max_distance=128, layer_norm_epsilon=1e-6, feed_forward_proj="gated-gelu")
+    clip_cfg = dict(vocab_size=40, projection_dim=SMALL_FLUX["pooled_projection_dim"], intermediate_size=128, max_position_embeddings=77, num_hidden_layers=2,
+                    num_attention_heads=1)
+    sd = d.synth.flux_state_dict_numpy(SMALL_FLUX, seed=4)
+    vsd = d.synth.vae_state_dict_numpy(SMALL_VAE, seed=4)
+    tsd = d.synth.text_state_dict_numpy(d.synth.t5_tensor_shapes(t5_cfg), seed=5)
+    csd = d.synth.text_state_dict_numpy(d.synth.clip_tensor_shapes(clip_cfg), seed=6)
+    root = str(tmp_path / "tiny-flux-full")
+    _write_diffusers_dir(root, sd, vsd)
+    for sub in ("text_encoder", "text_encoder_2", "tokenizer", "tokenizer_2"):
+        os.makedirs(os.path.join(root, sub))
+    json.dump(dict(clip_cfg, hidden_size=clip_cfg["projection_dim"], hidden_act="quick_gelu"), open(os.path.join(root, "text_encoder", "config.json"), "w"))
+    json.dump(dict(t5_cfg, is_encoder_decoder=True), open(os.path.join(root, "text_encoder_2", "config.json"), "w"))
+    save_file({k: torch.from_numpy(v).to(torch.bfloat16) for k, v in csd.items()}, os.path.join(root, "text_encoder", "model.safetensors"))
+    t5_file = {k: torch.from_numpy(v).to(torch.bfloat16) for k, v in tsd.items()}
+    t5_file["encoder.embed_tokens.weight"] = t5_file["shared.weight"].clone()  # tied copy real checkpoints carry
+    save_file(t5_file, os.path.join(root, "text_encoder_2", "model.safetensors"))
+    # CLIP tokenizer files: vocab.json + merges.txt (first line is a header the reference skips, tokenizer.rs:14-16)
+    letters = "abcdefghijklmnopqrstuvwxyz "
+    vocab = {ch: i for i, ch in enumerate(letters)}
+    merges = [("t", "h"), ("th", "e"), ("a", "t"), ("c", "at")]
+    for a, b in merges:
+        vocab[a + b] = len(vocab)
+    json.dump(vocab, open(os.path.join(root, "tokenizer", "vocab.json"), "w"))
+    open(os.path.join(root, "tokenizer", "merges.txt"), "w").write("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n")
+    # T5 tokenizer.json: word-level stand-in with an </s> post-processor (ids: pad 0, </s> 1, unk 2)
+    words = ["<pad>", "</s>", "<unk>", "the", "cat", "sat", "on", "a", "mat", "dog", "ran"]
+    tk = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tk.post_processor = processors.TemplateProcessing(single="$A </s>", special_tokens=[("</s>", 1)])
+    tk.save(os.path.join(root, "tokenizer_2", "tokenizer.json"))
+
+    pipe = d.Pipeline(d.ModelSource.ModelId(root))
+    assert pipe.t5 is not None and pipe.clip is not None and pipe.t5_tokenizer is not None and pipe.clip_tokenizer is not None
+    prompts = ["the cat sat on a mat", "a dog ran"]
+    t5_ids = np.array(d.tokenize_and_pad(prompts, pipe.t5_tokenizer), np.int32)
+    clip_ids = np.array(d.tokenize_and_pad(prompts, pipe.clip_tokenizer), np.int32)
+    assert t5_ids.shape == (2, 7) and t5_ids[1].tolist() == [7, 9, 10, 1, 0, 0, 0]  # </s> appended, zero padded to the longest
+    assert clip_ids.shape[0] == 2 and (clip_ids[1][-3:] == 0).all()
+    params = d.DiffusionGenerationParams(height=128, width=128, num_steps=3, guidance_scale=3.5)
+    lat = np.random.default_rng(8).standard_normal((2, 16, 16, 16)).astype(np.float32)
+    u8 = pipe.forward(prompts, params, latents=dev(lat), output="tensor")
+    torch.cuda.synchronize()
+    # oracle chain on the same ids
+    ot, oc = orc.T5(t5_cfg), orc.Clip(clip_cfg)
+    ot.load(tsd)
+    oc.load(csd)
+    t5_emb, clip_emb = ot.forward(t5_ids), oc.forward(clip_ids)
+    g_t5, g_clip = pipe.encode_prompts(prompts)
+    print(f"prompt embeddings: T5 rel-L2 {rel_l2(host(g_t5.float()), t5_emb):.3e}, CLIP rel-L2 {rel_l2(host(g_clip), clip_emb):.3e}")
+    assert rel_l2(host(g_t5.float()), t5_emb) <= 1.2e-2 and rel_l2(host(g_clip), clip_emb) <= 1e-2
+    ref_u8, _ = _oracle_pipeline_cfg(sd, vsd, lat, t5_emb, clip_emb, 3, 3.5, pipe.scheduler)
+    diff = np.abs(u8.cpu().numpy().astype(np.int32) - ref_u8.astype(np.int32))
+    print(f"prompt -> image u8: max |d| {diff.max()}, frac<=2 {float((diff <= 2).mean()):.4f}")
+    assert float((diff <= 2).mean()) >= 0.99
+    # token_ids= bypasses the tokenizers and gives the same image
+    u8b = pipe.forward(prompts, params, latents=dev(lat), output="tensor", token_ids=(t5_ids, clip_ids))
+    assert torch.equal(u8, u8b)
+
+
+def _oracle_pipeline_cfg(sd, vsd, lat, t5, clip, steps, guidance, sched):
+    return _oracle_pipeline(sd, vsd, lat, t5.astype(np.float32), clip.astype(np.float32), steps, guidance, sched)
