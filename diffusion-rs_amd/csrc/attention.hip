@@ -22,6 +22,8 @@
 //     address so the ds_read_b128 operand reads are bank-conflict free.
 //   * Online softmax in the exp2 domain with deferred rescale (skip the O rescale while the row
 //     max grows by < THR; P stays bounded by 2^THR, cdna guide T13).
+#include <type_traits>
+
 #include "common.h"
 
 namespace fmi {
@@ -34,6 +36,9 @@ constexpr int ATT_THREADS = 512;
 constexpr int ATT_QBLK = 256;  // query rows per workgroup
 constexpr int ATT_KV = 64;     // kv rows per tile
 constexpr int HD = 128;
+#ifndef ATT_PF
+#define ATT_PF 4  // operand reads in flight in the ping-pong kernel's MFMA phase (4/6/8 measured within 2 %)
+#endif
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -247,13 +252,307 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong variant of the kernel above (same math, same accumulation order: bit-identical output).
+//
+// Per KV tile a wave has ~1040 clocks of softmax VALU work (exp2 is quarter rate) and 1024 clocks
+// of MFMA work (16 QK^T + 16 PV).  With one workgroup barrier per tile both waves of a SIMD did
+// their softmax at the same time (matrix pipe idle) and then their MFMAs at the same time (VALU
+// idle): measured 46 % MFMA utilisation.  Here the 8 waves form two groups (waves 0-3 / 4-7, one
+// of each per SIMD) that alternate barrier-delimited slots:
+//     slot      2t        2t+1       2t+2       2t+3
+//     group 0   V(t)      M(t)       V(t+1)     M(t+1)
+//     group 1   M(t-1)    V(t)       M(t)       V(t+1)
+//   V(t) = this wave's DMA pieces of K(t+3) / Vt(t+2), then the online softmax of S(t) -> P(t)
+//   M(t) = PV(t) then QK^T(t+1) -> S(t+1) (the ONE S buffer: nothing overlaps inside a wave any
+//          more), 32 (ds_read_b128, MFMA) steps as one software pipeline with ATT_PF operand reads
+//          in flight — only this wave feeds the SIMD's matrix pipe in its slot, so an LDS latency
+//          (~150 clk) in front of every 32-clk MFMA would idle it; ends with vmcnt(4) (everything
+//          the wave issued before V(t) has landed; the closing barrier publishes it)
+// so on every SIMD one wave keeps the VALU busy while the other keeps the matrix pipe busy.
+// K and Vt live in 4-deep LDS rings (128 KiB): a piece has >= 4 slots (two tile periods) to land.
+#ifdef ATT_PP_TRACE
+__device__ long long g_att_trace[8 * 64];
+#define ATT_TR(k) do { if (blockIdx.x == 0 && lane == 0 && t >= 16 && t < 24) g_att_trace[wave * 64 + (t - 16) * 8 + (k)] = clock64(); } while (0)
+#else
+#define ATT_TR(k) do {} while (0)
+#endif
+template <int THR_X16>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16_t* __restrict Q, const bf16_t* __restrict K,
+                                                                       const bf16_t* __restrict Vt, AttnOut out, int H, int Lq, int Lk,
+                                                                       int Lkpad, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * 16384];  // K ring [4][64x128] at 0, Vt ring [4][128x64] at 64K
+  constexpr int VT_RING = 4 * 16384;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2;
+  const int nqb = (Lq + ATT_QBLK - 1) / ATT_QBLK;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lid / nqb;
+  const int b = bh / H, h = bh % H;
+  const int q0 = (lid % nqb) * ATT_QBLK + wave * 32;
+  const int hl = lane >> 5;
+  const int l31 = lane & 31;
+
+  const bf16_t* Kb = K + (int64_t)bh * Lk * HD;
+  const bf16_t* Vb = Vt + (int64_t)bh * HD * Lkpad;
+
+  bf16x8_t qf[8];
+  {
+    int qr = q0 + l31;
+    qr = qr > Lq - 1 ? Lq - 1 : qr;
+    const bf16_t* qp = Q + ((int64_t)bh * Lq + qr) * HD + 8 * hl;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * s);
+  }
+  f32x16 ot[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  // LDS operand offsets.  The swizzles are XORs of disjoint bit fields, so the offset of k-step s /
+  // slot c is the step-0 offset XOR an immediate: 2 registers instead of 16.
+  //   K tile  [64][128] bf16: row l31, 16-B slot (2s + hl) ^ (lane & 15)  ==  k_off0 ^ (s << 5)
+  //   Vt tile [128][64] bf16: row l31, 16-B slot (2c' + hl) ^ ((l31>>1)&7) ==  v_off0 ^ (c' << 5)
+  const int k_off0 = l31 * 256 + ((hl ^ (lane & 15)) << 4);
+  const int v_off0 = l31 * 128 + ((hl ^ ((l31 >> 1) & 7)) << 4);
+
+  auto stage_k = [&](int tile) {
+    char* kd = smem + (tile & 3) * 16384;
+    const int kv0 = tile * ATT_KV;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int chunk = wave * 2 + i;
+      const int row = chunk * 4 + (lane >> 4);
+      int kr = kv0 + row;
+      kr = kr > Lk - 1 ? Lk - 1 : kr;
+      const bf16_t* src = Kb + (int64_t)kr * HD + (((lane & 15) ^ (row & 15)) << 3);
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(kd + chunk * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_v = [&](int tile) {
+    char* vd = smem + VT_RING + (tile & 3) * 16384;
+    const int kv0 = tile * ATT_KV;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int chunk = wave * 2 + i;
+      const int row = chunk * 8 + (lane >> 3);
+      const bf16_t* src = Vb + (int64_t)row * Lkpad + kv0 + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(vd + chunk * 1024), 16, 0, 0);
+    }
+  };
+  auto slot_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int ntiles = (Lk + ATT_KV - 1) / ATT_KV;
+  // ---- prologue: K(0..2), Vt(0..1) in flight; S(0) computed by everyone
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+    if (t < ntiles) stage_k(t);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    if (t < ntiles) stage_v(t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  slot_barrier();
+  f32x16 sc[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[u][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(smem + u * 32 * 256 + (k_off0 ^ (s << 5)));
+      sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc[u], 0, 0, 0);
+    }
+  }
+  if (g == 1) slot_barrier();  // group 1 runs one slot behind
+
+  bf16x8_t pf[4];
+  auto body = [&](int t, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;  // a tile t+1 exists
+    ATT_TR(0);
+    // ================= V(t): DMA issue + online softmax of S(t) -> pf
+#ifndef ATT_PP_NO_DMA
+    if (t + 3 < ntiles) stage_k(t + 3);
+    if (t + 2 < ntiles) stage_v(t + 2);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if ((t + 1) * ATT_KV > Lk) {
+      const int kvb = t * ATT_KV + 4 * hl;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kvb + 32 * u + (r & 3) + 8 * (r >> 2) >= Lk) sc[u][r] = -1e30f;
+    }
+#ifndef ATT_PP_NO_V
+    float pmax = sc[0][0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pmax = fmaxf(pmax, sc[u][r]);
+    pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+    const float ps = pmax * scale_log2e;
+    if (__any(ps - m_run > (float)THR_X16 * 0.0625f)) {
+      const float mn = fmaxf(m_run, ps);
+      const float alpha = fast_exp2(m_run - mn);
+      m_run = mn;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[i][r] *= alpha;
+    }
+    float lsum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      uint32_t pk[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = fast_exp2(sc[u][r] * scale_log2e - m_run);
+        const float p1 = fast_exp2(sc[u][r + 1] * scale_log2e - m_run);
+        lsum += p0 + p1;
+        pk[r >> 1] = pack_bf16x2(p0, p1);
+      }
+      uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      uint4 hi = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+      __builtin_memcpy(&pf[2 * u], &lo, 16);
+      __builtin_memcpy(&pf[2 * u + 1], &hi, 16);
+    }
+    l_run += lsum;
+    ATT_TR(1);
+#else
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pf[c] = __builtin_bit_cast(bf16x8_t, make_uint4(__float_as_uint(sc[c >> 1][0]), 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+#endif
+    slot_barrier();
+#ifdef ATT_PP_SETPRIO
+    __builtin_amdgcn_s_setprio(ATT_PP_SETPRIO);  // the MFMA wave wins issue arbitration against the softmax wave of its SIMD
+#endif
+    ATT_TR(2);
+    // ================= M(t): PV(t) (steps 0..15), then QK^T(t+1) (steps 16..31) into sc
+    {
+      const char* vl = smem + VT_RING + (t & 3) * 16384;
+      const char* kl = smem + ((t + 1) & 3) * 16384;
+      constexpr int NSTEP = MORE ? 32 : 16;
+      bf16x8_t fr[ATT_PF];
+      // Step order: consecutive MFMAs never hit the same accumulator (a dependent 32x32 MFMA cannot
+      // issue until the previous one has drained: 4- and 8-long chains ran the phase at half rate).
+      // PV steps walk dt fastest (4 accumulators), QK steps walk u fastest (2 accumulators); the
+      // k-order inside every accumulator is unchanged, so results stay bit-identical.
+      // The reads are inline asm with hand-placed `s_waitcnt lgkmcnt(ATT_PF-1)`: hipcc's own waitcnt
+      // insertion waits for lgkmcnt(0) — i.e. for the read it has just issued — every few steps,
+      // which exposes a full LDS latency per ATT_PF MFMAs (measured 62 clocks per MFMA instead of 32).
+      // LDS reads retire in order, so before MFMA i at most (reads issued) - (i+1) may be pending.
+      const uint32_t vbase = (uint32_t)(uintptr_t)(lds_void*)vl, kbase = (uint32_t)(uintptr_t)(lds_void*)kl;
+      auto load = [&](int i, bf16x8_t& dst) {  // i is a compile-time constant after unrolling
+        const uint32_t a = i < 16 ? vbase + (i & 3) * 32 * 128 + (v_off0 ^ ((i >> 2) << 5)) : kbase + ((i - 16) & 1) * 32 * 256 + (k_off0 ^ (((i - 16) >> 1) << 5));
+#ifndef ATT_PP_NO_LDS
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(a));
+#else
+        dst = __builtin_bit_cast(bf16x8_t, make_uint4(a, 0x3f803f80u, 0x3f803f80u, a));  // ablation: no LDS traffic
+#endif
+      };
+#pragma unroll
+      for (int i = 0; i < ATT_PF; ++i) load(i, fr[i]);
+#pragma unroll
+      for (int i = 0; i < NSTEP; ++i) {
+        {
+          const int pending = (i + ATT_PF < NSTEP ? ATT_PF : NSTEP - i) - 1;  // reads issued after read i
+          bf16x8_t& f = fr[i % ATT_PF];
+          // the "+v" ties the wait to the fragment: the MFMA below cannot be scheduled above it
+          if (pending >= 7) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(f));
+          else if (pending == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f));
+          else if (pending == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(f));
+          else if (pending == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f));
+          else if (pending == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f));
+          else if (pending == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f));
+          else if (pending == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f));
+        }
+#ifdef ATT_PP_NO_MFMA
+        sc[0][i & 15] += __builtin_bit_cast(f32x4, fr[i % ATT_PF])[0];
+        if (i + ATT_PF < NSTEP) load(i + ATT_PF, fr[i % ATT_PF]);
+        continue;
+#endif
+        if (i < 16) {
+          ot[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % ATT_PF], pf[i >> 2], ot[i & 3], 0, 0, 0);
+        } else {
+          const int u = (i - 16) & 1, sq = (i - 16) >> 1;
+          if (sq == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[u][r] = 0.f;
+          }
+          sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % ATT_PF], qf[sq], sc[u], 0, 0, 0);
+        }
+        if (i + ATT_PF < NSTEP) load(i + ATT_PF, fr[i % ATT_PF]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the read-ahead distance: one read issued per MFMA
+      }
+    }
+    ATT_TR(3);
+#ifdef ATT_PP_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    // everything older than the pieces issued in this tile's V phase must have landed
+    if (t + 3 < ntiles)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (t + 2 < ntiles)
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_TR(4);
+    slot_barrier();
+    ATT_TR(5);
+  };
+  for (int t = 0; t < ntiles - 1; ++t) body(t, std::true_type{});
+  body(ntiles - 1, std::false_type{});
+  if (g == 0) slot_barrier();  // group 0 finished one slot early
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < Lq) {
+    bf16_t* op;
+    if (out.head_major)
+      op = out.p1 + ((int64_t)bh * Lq + q) * HD;
+    else if (q < out.rows0)
+      op = out.p0 + (int64_t)b * out.bstride0 + (int64_t)q * out.ld0 + h * HD;
+    else
+      op = out.p1 + (int64_t)b * out.bstride1 + (int64_t)(q - out.rows0) * out.ld1 + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = dt * 32 + gq * 8 + 4 * hl;
+        const uint2 v = make_uint2(pack_bf16x2(ot[dt][4 * gq] * inv, ot[dt][4 * gq + 1] * inv),
+                                   pack_bf16x2(ot[dt][4 * gq + 2] * inv, ot[dt][4 * gq + 3] * inv));
+        *reinterpret_cast<uint2*>(op + d) = v;
+      }
+  }
+}
+
+static bool g_att_pingpong = true;
+void set_attention_pingpong(bool on) { g_att_pingpong = on; }
+
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
                         int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream) {
   if (Lq <= 0 || Lk <= 0) return fail(FMI_ERR_INVALID, "attention: empty sequence");
   if (Lkpad % ATT_KV != 0 || Lkpad < Lk) return fail(FMI_ERR_INVALID, "attention: Lkpad must be a multiple of 64 and >= Lk");
   dim3 grid(cdiv(Lq, ATT_QBLK) * B * H);
   const float sl = scale * 1.4426950408889634f;
-  if (rescale_thr_x16 == 0)
+  if (g_att_pingpong) {
+    if (rescale_thr_x16 == 0)
+      hipLaunchKernelGGL(attention_pp_kernel<0>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+    else
+      hipLaunchKernelGGL(attention_pp_kernel<96>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+  } else if (rescale_thr_x16 == 0)
     hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
   else
     hipLaunchKernelGGL(attention_kernel<96>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);

@@ -157,6 +157,7 @@ struct AttnOut {
 };
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
                         int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream);
+void set_attention_pingpong(bool on);  // ping-pong kernel (default) or the single-barrier one
 // flash attention, d = 128.  q,k: (BH, L, 128) bf16; vt: (BH, 128, Lpad) bf16 with the kv axis
 // permuted inside each group of 16 (see attention.hip); out token-major (B, L, H*128) or (BH,L,128)
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int H,

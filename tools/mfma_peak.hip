@@ -46,22 +46,25 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int threads : {256, 512}) {
-    for (int blocks : {256, 512}) {
-      for (int rep = 0; rep < 2; ++rep) {
-        const int n = rep ? iters * 20 : iters;  // short (~ms) and long (~100 ms) runs: DVFS settles in the long one
-        mfma_loop<8><<<blocks, threads>>>(in, out, 100);
-        hipDeviceSynchronize();
-        hipEventRecord(e0);
-        mfma_loop<8><<<blocks, threads>>>(in, out, n);
-        hipEventRecord(e1);
-        hipEventSynchronize(e1);
-        float ms;
-        hipEventElapsedTime(&ms, e0, e1);
-        const double flop = (double)blocks * (threads / 64) * (double)n * 8 * 2.0 * 32 * 32 * 16;
-        printf("blocks %3d x %d waves, %8d iters: %8.2f ms  %7.1f TFLOP/s\n", blocks, threads / 64, n, ms, flop / (ms * 1e-3) / 1e12);
-      }
-    }
-  }
+  auto run = [&](auto kern, const char* what, int nacc, int blocks, int threads, int n) {
+    kern<<<blocks, threads>>>(in, out, 100);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    kern<<<blocks, threads>>>(in, out, n);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)blocks * (threads / 64) * (double)n * nacc * 2.0 * 32 * 32 * 16;
+    printf("%-34s blocks %3d x %d waves, %8d iters: %8.2f ms  %7.1f TFLOP/s\n", what, blocks, threads / 64, n, ms, flop / (ms * 1e-3) / 1e12);
+  };
+  for (int threads : {256, 512})
+    for (int blocks : {256, 512})
+      for (int rep = 0; rep < 2; ++rep) run(mfma_loop<8>, "8 accumulators round-robin", 8, blocks, threads, rep ? iters * 20 : iters);
+  // accumulator reuse distance (dependent-issue latency of the 8-pass MFMA), one wave per SIMD
+  run(mfma_loop<4>, "4 accumulators round-robin", 4, 256, 256, iters * 10);
+  run(mfma_loop<2>, "2 accumulators round-robin", 2, 256, 256, iters * 10);
+  run(mfma_loop<1>, "1 accumulator (back to back)", 1, 256, 256, iters * 10);
+  run(mfma_loop<2>, "2 accumulators, 2 waves per SIMD", 2, 256, 512, iters * 10);
   return 0;
 }
