@@ -136,7 +136,9 @@ struct GemmProblem {
   int q_type;  // 0 none, 1 fp4, 2 nf4
   // implicit-GEMM convolution (optional, cv_ks != 0): A is an NHWC image (B, cv_h, cv_w, cv_cin),
   // M = B * (cv_h<<cv_up) * (cv_w<<cv_up) output pixels, K = cv_ks^2 * cv_cin with k = (tap, cin),
-  // W is (N, cv_ks, cv_ks, cv_cin); cv_up = 1 folds a nearest-2x upsample into the gather.
+  // W is (N, cv_ks, cv_ks, cv_cin); cv_up = 1 folds a nearest-2x upsample into the gather;
+  // cv_up = -1 is the stride-2 Downsample of the VAE encoder (M = B * (cv_h/2) * (cv_w/2),
+  // zero padding on the right/bottom edge only, vaes/vae.rs:194-201).
   int cv_ks, cv_h, cv_w, cv_cin, cv_up;
   const bf16_t* cv_zero;  // >= 128 B of zeros for padding taps
 };

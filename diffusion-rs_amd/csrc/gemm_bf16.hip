@@ -345,10 +345,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
     for (int i = 0; i < 4; ++i) {
       int m = m0 + (wave * 4 + i) * 8 + (lane >> 3);
       m = m > P.M - 1 ? P.M - 1 : m;
-      const int ow = P.cv_w << P.cv_up, oh = P.cv_h << P.cv_up;
+      // cv_up > 0: nearest-2x upsample folded in; cv_up < 0: the VAE encoder's Downsample (stride 2,
+      // one zero column / row on the right / bottom only): input pixel = 2*out + tap, no centring
+      const bool down = P.cv_up < 0;
+      const int up = down ? 0 : P.cv_up;
+      const int ow = down ? P.cv_w >> 1 : P.cv_w << up, oh = down ? P.cv_h >> 1 : P.cv_h << up;
       const int x = m % ow, y = (m / ow) % oh, b = m / (ow * oh);
-      cv_x[i] = x;
-      cv_y[i] = y;
+      cv_x[i] = down ? 2 * x : x;
+      cv_y[i] = down ? 2 * y : y;
       cv_base[i] = (int64_t)b * P.cv_h * P.cv_w;
     }
   }
@@ -377,9 +381,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
     if (MODE == 2) {
       const int cpt = P.cv_cin >> 6;  // 64-channel slices per tap
       const int tap = kt / cpt, c0 = (kt - tap * cpt) << 6;
-      const int half = P.cv_ks >> 1;
+      const int up = P.cv_up < 0 ? 0 : P.cv_up;
+      const int half = P.cv_up < 0 ? 0 : P.cv_ks >> 1;
       const int dy = tap / P.cv_ks - half, dx = tap % P.cv_ks - half;
-      const int ow = P.cv_w << P.cv_up, oh = P.cv_h << P.cv_up;
+      const int ow = P.cv_w << up, oh = P.cv_h << up;  // bounds of the (virtually upsampled) input
       const int cs = lane & 7;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
         const int yy = cv_y[i] + dy, xx = cv_x[i] + dx;
         const bf16_t* src;
         if (yy >= 0 && yy < oh && xx >= 0 && xx < ow)
-          src = P.A + (cv_base[i] + (int64_t)(yy >> P.cv_up) * P.cv_w + (xx >> P.cv_up)) * P.cv_cin + c0 + src_slot * 8;
+          src = P.A + (cv_base[i] + (int64_t)(yy >> up) * P.cv_w + (xx >> up)) * P.cv_cin + c0 + src_slot * 8;
         else
           src = P.cv_zero + src_slot * 8;  // zero padding (conv2d pad = k/2)
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + chunk * 1024), 16, 0, 0);

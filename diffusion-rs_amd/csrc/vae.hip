@@ -198,7 +198,7 @@ GemmProblem conv_problem(const bf16_t* x, const bf16_t* w, const bf16_t* bias, c
                          int cin_pad, int cout, int ks, int up, const bf16_t* zero) {
   GemmProblem p{};
   p.A = x, p.W = w, p.bias = bias, p.out = out, p.resid = resid;
-  p.M = B * (in_h << up) * (in_w << up);
+  p.M = up < 0 ? B * (in_h / 2) * (in_w / 2) : B * (in_h << up) * (in_w << up);
   p.N = cout;
   p.K = ks * ks * cin_pad;
   p.lda = cin_pad, p.ldw = p.K, p.ldo = cout;
@@ -246,6 +246,13 @@ struct fmi_vae {
   Conv aq, ak, av, ao;
   std::vector<std::vector<Resnet>> up;
   std::vector<Conv> upconv;  // per level (cout == 0 if none)
+  // encoder (vae.rs:236-349) + optional quant_conv (autoencoder_kl.rs:67-77)
+  Conv e_conv_in, e_conv_out, quant_conv;
+  Resnet e_mid1, e_mid2;
+  GN e_attn_gn, e_norm_out;
+  Conv e_aq, e_ak, e_av, e_ao;
+  std::vector<std::vector<Resnet>> down;
+  std::vector<Conv> downconv;  // per level (cout == 0 if none)
   bf16_t* zero = nullptr;
   std::map<std::string, Dest> names;
   std::set<std::string> missing;
@@ -366,10 +373,14 @@ int run_resnet(fmi_vae* v, const Resnet& r, int B, int H, int W, hipStream_t s) 
   return FMI_OK;
 }
 // AttnBlock::forward (vae.rs:95-111) with the model-dtype sdpa of vae.rs:28-33
-int run_attn(fmi_vae* v, int B, int H, int W, hipStream_t s) {
-  const int C = v->aq.cout, HW = H * W;
+struct AttnW {
+  const GN& gn;
+  const Conv &q, &k, &v, &o;
+};
+int run_attn(fmi_vae* v, const AttnW& a, int B, int H, int W, hipStream_t s) {
+  const int C = a.q.cout, HW = H * W;
   if (HW % 64) return fail(FMI_ERR_UNSUPPORTED, "vae attention: latent h*w must be a multiple of 64");
-  FMI_TRY(run_gn(v, v->attn_gn, v->bx, v->bt1, B, HW, 0, s));
+  FMI_TRY(run_gn(v, a.gn, v->bx, v->bt1, B, HW, 0, s));
   const float scale = (float)(1.0 / sqrt((double)C));
   for (int b = 0; b < B; ++b) {
     const bf16_t* xn = v->bt1 + (size_t)b * HW * C;
@@ -378,12 +389,12 @@ int run_attn(fmi_vae* v, int B, int H, int W, hipStream_t s) {
     bf16_t* vt = v->bt2 + (size_t)2 * HW * C; // (C, HW)
     bf16_t* o = v->bsc;                       // (HW, C)
     GemmProblem p[2];
-    p[0] = conv_problem(xn, v->aq.w, v->aq.b, nullptr, q, 1, H, W, C, C, 1, 0, v->zero);
-    p[1] = conv_problem(xn, v->ak.w, v->ak.b, nullptr, k, 1, H, W, C, C, 1, 0, v->zero);
+    p[0] = conv_problem(xn, a.q.w, a.q.b, nullptr, q, 1, H, W, C, C, 1, 0, v->zero);
+    p[1] = conv_problem(xn, a.k.w, a.k.b, nullptr, k, 1, H, W, C, C, 1, 0, v->zero);
     FMI_TRY(launch_gemm(p, 2, s));
     // V^T (C, HW) = Wv (C,C) · xn(HW,C)^T ; the v bias is added after P·V (softmax rows sum to 1)
     GemmProblem pv{};
-    pv.A = v->av.w, pv.W = xn, pv.out = vt, pv.M = C, pv.N = HW, pv.K = C, pv.lda = C, pv.ldw = C, pv.ldo = HW, pv.epi = EPI_STORE_BF16, pv.alpha = 1.f;
+    pv.A = a.v.w, pv.W = xn, pv.out = vt, pv.M = C, pv.N = HW, pv.K = C, pv.lda = C, pv.ldw = C, pv.ldo = HW, pv.epi = EPI_STORE_BF16, pv.alpha = 1.f;
     FMI_TRY(launch_gemm(&pv, 1, s));
     // scores = (q k^T) * scale  -> bf16 (HW, HW)
     GemmProblem ps{};
@@ -393,12 +404,12 @@ int run_attn(fmi_vae* v, int B, int H, int W, hipStream_t s) {
     FMI_LAUNCH_CHECK();
     // o = P · V + b_v
     GemmProblem po{};
-    po.A = v->scores, po.W = vt, po.bias = v->av.b, po.out = o, po.M = HW, po.N = C, po.K = HW, po.lda = HW, po.ldw = HW, po.ldo = C, po.epi = EPI_STORE_BF16,
+    po.A = v->scores, po.W = vt, po.bias = a.v.b, po.out = o, po.M = HW, po.N = C, po.K = HW, po.lda = HW, po.ldw = HW, po.ldo = C, po.epi = EPI_STORE_BF16,
     po.alpha = 1.f;
     FMI_TRY(launch_gemm(&po, 1, s));
     // x[b] = to_out(o) + x[b]   (in place on the trunk)
     bf16_t* xb = v->bx + (size_t)b * HW * C;
-    GemmProblem pf = conv_problem(o, v->ao.w, v->ao.b, xb, xb, 1, H, W, C, C, 1, 0, v->zero);
+    GemmProblem pf = conv_problem(o, a.o.w, a.o.b, xb, xb, 1, H, W, C, C, 1, 0, v->zero);
     FMI_TRY(launch_gemm(&pf, 1, s));
   }
   return FMI_OK;
@@ -411,6 +422,7 @@ extern "C" void fmi_vae_default_config(fmi_vae_config* c) {
   c->n_blocks = 4, c->layers_per_block = 2, c->latent_channels = 16, c->norm_num_groups = 32;
   c->mid_block_add_attention = 1, c->use_post_quant_conv = 0;
   c->scaling_factor = 0.3611, c->shift_factor = 0.1159;
+  c->use_quant_conv = 0;
 }
 
 extern "C" int fmi_vae_create(const fmi_vae_config* cfg, fmi_model_dtype dtype, fmi_vae** out) {
@@ -453,6 +465,34 @@ extern "C" int fmi_vae_create(const fmi_vae_config* cfg, fmi_model_dtype dtype, 
   }
   ok = ok && make_gn(v, v->norm_out, "decoder.conv_norm_out", cfg->block_out_channels[0]);
   ok = ok && make_conv(v, v->conv_out, "decoder.conv_out", cfg->block_out_channels[0], cfg->out_channels, 3);
+  // ---- encoder (Encoder::new, vae.rs:249-327)
+  {
+    int ch = cfg->block_out_channels[0];
+    ok = ok && make_conv(v, v->e_conv_in, "encoder.conv_in", cfg->in_channels, ch, 3);
+    v->down.resize(nb);
+    v->downconv.resize(nb);
+    for (int lvl = 0; lvl < nb && ok; ++lvl) {
+      const int block_out = cfg->block_out_channels[lvl];
+      const std::string p = "encoder.down_blocks." + std::to_string(lvl);
+      v->down[lvl].resize(cfg->layers_per_block);
+      for (int i = 0; i < cfg->layers_per_block && ok; ++i) {
+        ok = make_resnet(v, v->down[lvl][i], p + ".resnets." + std::to_string(i), ch, block_out);
+        ch = block_out;
+      }
+      if (lvl != nb - 1 && ok) ok = make_conv(v, v->downconv[lvl], p + ".downsamplers.0.conv", ch, ch, 3);
+    }
+    ok = ok && make_resnet(v, v->e_mid1, "encoder.mid_block.resnets.0", ch, ch);
+    if (cfg->mid_block_add_attention) {
+      const std::string p = "encoder.mid_block.attentions.0";
+      ok = ok && make_gn(v, v->e_attn_gn, p + ".group_norm", ch);
+      ok = ok && make_conv(v, v->e_aq, p + ".to_q", ch, ch, 1, true) && make_conv(v, v->e_ak, p + ".to_k", ch, ch, 1, true) &&
+           make_conv(v, v->e_av, p + ".to_v", ch, ch, 1, true) && make_conv(v, v->e_ao, p + ".to_out.0", ch, ch, 1, true);
+    }
+    ok = ok && make_resnet(v, v->e_mid2, "encoder.mid_block.resnets.1", ch, ch);
+    ok = ok && make_gn(v, v->e_norm_out, "encoder.conv_norm_out", ch);
+    ok = ok && make_conv(v, v->e_conv_out, "encoder.conv_out", ch, 2 * cfg->latent_channels, 3);
+    if (cfg->use_quant_conv) ok = ok && make_conv(v, v->quant_conv, "quant_conv", 2 * cfg->latent_channels, 2 * cfg->latent_channels, 1);
+  }
   if (!ok) {
     fmi_vae_destroy(v);
     return fail(FMI_ERR_NOMEM, "vae_create: device allocation failed");
@@ -520,10 +560,89 @@ extern "C" const char* fmi_vae_missing_name(const fmi_vae* v, int i) {
 extern "C" double fmi_vae_scale_factor(const fmi_vae* v) { return v ? v->cfg.scaling_factor : 0.0; }
 extern "C" double fmi_vae_shift_factor(const fmi_vae* v) { return v ? v->cfg.shift_factor : 0.0; }
 
+namespace {
+bool is_encoder_name(const std::string& n) { return n.rfind("encoder.", 0) == 0 || n.rfind("quant_conv.", 0) == 0; }
+// decode needs only the decoder's tensors and encode only the encoder's (+ quant_conv)
+int check_part(fmi_vae* v, bool decoder) {
+  int n = 0;
+  const std::string* first = nullptr;
+  for (const auto& m : v->missing)
+    if (is_encoder_name(m) != decoder) {
+      if (!first) first = &m;
+      ++n;
+    }
+  if (n) return fail(FMI_ERR_STATE, std::string("vae ") + (decoder ? "decoder" : "encoder") + ": " + std::to_string(n) + " tensors not set, first: " + *first);
+  return FMI_OK;
+}
+
+// NHWC bf16 moments (B, hw, 2L) -> z (B, L, hw) f32 NCHW = mean + exp(0.5 logvar) * noise, and
+// optionally the moments as f32 NCHW.  DiagonalGaussian::forward (vae.rs:470-480).
+__global__ void diag_gaussian_kernel(const bf16_t* __restrict mom, const float* __restrict noise, float* __restrict z, float* __restrict mom_out, int L, int hw,
+                                     int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(e % hw);
+    const int c = (int)((e / hw) % L);
+    const int64_t b = e / ((int64_t)hw * L);
+    const bf16_t* m = mom + (b * hw + p) * 2 * L;
+    const float mean = bf16_to_f32(m[c]), logvar = bf16_to_f32(m[L + c]);
+    z[e] = noise ? mean + __expf(0.5f * logvar) * noise[e] : mean;
+    if (mom_out) {
+      mom_out[(b * 2 * L + c) * hw + p] = mean;
+      mom_out[(b * 2 * L + L + c) * hw + p] = logvar;
+    }
+  }
+}
+}  // namespace
+
+// == AutoEncoderKl::encode (autoencoder_kl.rs:103-110) = Encoder::forward (vae.rs:330-349),
+// optional quant_conv, DiagonalGaussian.  H, W must be multiples of 8.
+extern "C" int fmi_vae_encode(fmi_vae* v, const float* image, int B, int H, int W, const float* noise, float* z_out, float* moments_out, void* stream) {
+  if (!v || !image || !z_out) return fail(FMI_ERR_INVALID, "vae_encode: null argument");
+  if (B <= 0 || H <= 0 || W <= 0 || H % 8 || W % 8) return fail(FMI_ERR_INVALID, "vae_encode: H and W must be positive multiples of 8");
+  FMI_TRY(check_part(v, false));
+  hipStream_t s = (hipStream_t)stream;
+  const fmi_vae_config& c = v->cfg;
+  FMI_TRY(vae_workspace(v, B, H / 8, W / 8));
+  {
+    const int cp = v->e_conv_in.cin_pad;
+    const int64_t n = (int64_t)B * H * W * cp;
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, s, image, v->bt1, c.in_channels, cp, H * W, n);
+    FMI_LAUNCH_CHECK();
+  }
+  FMI_TRY(run_conv(v, v->e_conv_in, v->bt1, nullptr, v->bx, B, H, W, 0, s));
+  for (int lvl = 0; lvl < c.n_blocks; ++lvl) {
+    for (auto& r : v->down[lvl]) FMI_TRY(run_resnet(v, r, B, H, W, s));
+    if (v->downconv[lvl].cout) {  // Downsample::forward (vae.rs:194-201): stride 2, zero column/row on the right/bottom
+      FMI_TRY(run_conv(v, v->downconv[lvl], v->bx, nullptr, v->bt2, B, H, W, -1, s));
+      std::swap(v->bx, v->bt2);
+      H /= 2, W /= 2;
+    }
+  }
+  FMI_TRY(run_resnet(v, v->e_mid1, B, H, W, s));
+  if (c.mid_block_add_attention) FMI_TRY(run_attn(v, AttnW{v->e_attn_gn, v->e_aq, v->e_ak, v->e_av, v->e_ao}, B, H, W, s));
+  FMI_TRY(run_resnet(v, v->e_mid2, B, H, W, s));
+  FMI_TRY(run_gn(v, v->e_norm_out, v->bx, v->bt1, B, H * W, 1, s));
+  FMI_TRY(run_conv(v, v->e_conv_out, v->bt1, nullptr, v->bt2, B, H, W, 0, s));
+  const bf16_t* mom = v->bt2;
+  if (c.use_quant_conv) {
+    // conv_out leaves 2L channels per pixel; the 1x1 conv reads cin_pad = 64-channel rows: re-pad through bt1
+    const int L2 = 2 * c.latent_channels, cp = v->quant_conv.cin_pad;
+    FMI_HIP_TRY(hipMemsetAsync(v->bt1, 0, (size_t)B * H * W * cp * 2, s));
+    FMI_HIP_TRY(hipMemcpy2DAsync(v->bt1, (size_t)cp * 2, v->bt2, (size_t)L2 * 2, (size_t)L2 * 2, (size_t)B * H * W, hipMemcpyDeviceToDevice, s));
+    FMI_TRY(run_conv(v, v->quant_conv, v->bt1, nullptr, v->bx, B, H, W, 0, s));
+    mom = v->bx;
+  }
+  const int64_t n = (int64_t)B * c.latent_channels * H * W;
+  hipLaunchKernelGGL(diag_gaussian_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, s, mom, noise, z_out, moments_out, c.latent_channels,
+                     H * W, n);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
 extern "C" int fmi_vae_decode(fmi_vae* v, const float* z, int B, int h, int w, float* image_out, void* stream) {
   if (!v || !z || !image_out) return fail(FMI_ERR_INVALID, "vae_decode: null argument");
   if (B <= 0 || h <= 0 || w <= 0) return fail(FMI_ERR_INVALID, "vae_decode: empty input");
-  if (!v->missing.empty()) return fail(FMI_ERR_STATE, "vae: " + std::to_string(v->missing.size()) + " tensors not set, first: " + *v->missing.begin());
+  FMI_TRY(check_part(v, true));
   hipStream_t s = (hipStream_t)stream;
   FMI_TRY(vae_workspace(v, B, h, w));
   const fmi_vae_config& c = v->cfg;
@@ -537,7 +656,7 @@ extern "C" int fmi_vae_decode(fmi_vae* v, const float* z, int B, int h, int w, f
   }
   FMI_TRY(run_conv(v, v->conv_in, v->bt1, nullptr, v->bx, B, H, W, 0, s));  // vae.rs:438
   FMI_TRY(run_resnet(v, v->mid1, B, H, W, s));
-  if (c.mid_block_add_attention) FMI_TRY(run_attn(v, B, H, W, s));
+  if (c.mid_block_add_attention) FMI_TRY(run_attn(v, AttnW{v->attn_gn, v->aq, v->ak, v->av, v->ao}, B, H, W, s));
   FMI_TRY(run_resnet(v, v->mid2, B, H, W, s));
   for (int lvl = 0; lvl < c.n_blocks; ++lvl) {
     for (auto& r : v->up[lvl]) FMI_TRY(run_resnet(v, r, B, H, W, s));

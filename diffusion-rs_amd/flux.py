@@ -176,7 +176,7 @@ class AutoEncoderKl:
             raise L.FmiError("block_out_channels must have 4 entries (the reference hard-codes i_level != 3, vae.rs:412)")
         c = L.VaeConfig(cfg["in_channels"], cfg["out_channels"], (C.c_int * 4)(*boc), 4, cfg["layers_per_block"], cfg["latent_channels"],
                         cfg["norm_num_groups"], int(cfg["mid_block_add_attention"]), int(cfg.get("use_post_quant_conv", False)),
-                        cfg["scaling_factor"], cfg["shift_factor"])
+                        cfg["scaling_factor"], cfg["shift_factor"], int(cfg.get("use_quant_conv", False)))
         h = C.c_void_p()
         L.check(self.lib.fmi_vae_create(C.byref(c), L.MODEL_BF16, C.byref(h)))
         self.h = h
@@ -197,12 +197,35 @@ class AutoEncoderKl:
         sh = (C.c_int64 * len(shape))(*shape)
         L.check(self.lib.fmi_vae_set_tensor(self.h, name.encode(), p, dt, sh, len(shape)))
 
+    def missing(self):
+        n = self.lib.fmi_vae_missing_count(self.h)
+        return [self.lib.fmi_vae_missing_name(self.h, i).decode() for i in range(n)]
+
     def load_state_dict(self, tensors: dict):
+        """Decoder tensors are required; encoder (`encoder.*`, `quant_conv.*`) tensors are optional
+        (only `encode` needs them, and it reports what is missing)."""
         for k, v in tensors.items():
             self.set_tensor(k, v)
-        n = self.lib.fmi_vae_missing_count(self.h)
-        if n:
-            raise L.FmiError(f"{n} VAE tensors missing, e.g. {self.lib.fmi_vae_missing_name(self.h, 0).decode()}")
+        m = [n for n in self.missing() if not (n.startswith("encoder.") or n.startswith("quant_conv."))]
+        if m:
+            raise L.FmiError(f"{len(m)} VAE tensors missing, e.g. {m[0]}")
+
+    def encode(self, image, noise=None, seed=None, return_moments=False):
+        """== VAEModel::encode (vaes/mod.rs:15-28, autoencoder_kl.rs:103-110): image (B,3,H,W) f32 ->
+        z (B,16,H/8,W/8) f32 = mean + exp(0.5 logvar) * noise.  noise: explicit tensor, or Philox
+        N(0,1) from `seed`, or None and seed None -> the distribution mean."""
+        image = image.to(torch.float32).contiguous()
+        B, _, H, W = image.shape
+        lat = self.cfg["latent_channels"]
+        if noise is None and seed is not None:
+            noise = randn_latents(B, lat, H // 8, W // 8, seed, 0, image.device)
+        if noise is not None:
+            noise = noise.to(device=image.device, dtype=torch.float32).contiguous()
+        z = torch.empty((B, lat, H // 8, W // 8), dtype=torch.float32, device=image.device)
+        mom = torch.empty((B, 2 * lat, H // 8, W // 8), dtype=torch.float32, device=image.device) if return_moments else None
+        L.check(self.lib.fmi_vae_encode(self.h, _ptr(image), B, H, W, _ptr(noise) if noise is not None else None, _ptr(z),
+                                        _ptr(mom) if mom is not None else None, _stream()))
+        return (z, mom) if return_moments else z
 
     def scale_factor(self) -> float:
         return self.lib.fmi_vae_scale_factor(self.h)

@@ -161,7 +161,7 @@ def load_flux(flux, tensors: Iterator[Tuple[str, torch.Tensor]]) -> dict:
 
 
 def load_vae(vae, tensors: Iterator[Tuple[str, torch.Tensor]]) -> int:
-    want = synth.vae_tensor_shapes(vae.cfg)
+    want = synth.vae_tensor_shapes(vae.cfg, encoder=True)  # encoder tensors are loaded when the checkpoint has them
     n = 0
     for name, t in tensors:
         if name in want:

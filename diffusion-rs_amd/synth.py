@@ -106,7 +106,8 @@ def fill_flux_random_device(model, seed=0, w_std=0.02, mod_std=0.01, bias_std=0.
     model.assert_complete()
 
 
-def vae_tensor_shapes(cfg) -> "OrderedDict[str, tuple]":
+def vae_tensor_shapes(cfg, encoder=False) -> "OrderedDict[str, tuple]":
+    """Decoder tensors (vae.rs:371-433); with encoder=True also the encoder's (vae.rs:249-327) and quant_conv."""
     boc = list(cfg["block_out_channels"])
     t = OrderedDict()
 
@@ -144,14 +145,36 @@ def vae_tensor_shapes(cfg) -> "OrderedDict[str, tuple]":
             conv(f"decoder.up_blocks.{lvl}.upsamplers.0.conv", block_in, block_in, 3)
     gn("decoder.conv_norm_out", boc[0])
     conv("decoder.conv_out", cfg["out_channels"], boc[0], 3)
+    if encoder:
+        ch = boc[0]
+        conv("encoder.conv_in", ch, cfg["in_channels"], 3)
+        for lvl, block_out in enumerate(boc):
+            for i in range(cfg["layers_per_block"]):
+                resnet(f"encoder.down_blocks.{lvl}.resnets.{i}", ch, block_out)
+                ch = block_out
+            if lvl != len(boc) - 1:
+                conv(f"encoder.down_blocks.{lvl}.downsamplers.0.conv", ch, ch, 3)
+        resnet("encoder.mid_block.resnets.0", ch, ch)
+        if cfg["mid_block_add_attention"]:
+            p = "encoder.mid_block.attentions.0"
+            gn(p + ".group_norm", ch)
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                t[f"{p}.{n}.weight"] = (ch, ch)
+                t[f"{p}.{n}.bias"] = (ch,)
+        resnet("encoder.mid_block.resnets.1", ch, ch)
+        gn("encoder.conv_norm_out", ch)
+        conv("encoder.conv_out", 2 * cfg["latent_channels"], ch, 3)
+        if cfg.get("use_quant_conv", False):
+            conv("quant_conv", 2 * cfg["latent_channels"], 2 * cfg["latent_channels"], 1)
     return t
 
 
-def vae_state_dict_numpy(cfg, seed=0, round_bf16=True):
-    """Conv W~N(0, 1/fan_in), small biases, GroupNorm w = 1+0.1N, b = 0.1N."""
+def vae_state_dict_numpy(cfg, seed=0, round_bf16=True, encoder=False):
+    """Conv W~N(0, 1/fan_in), small biases, GroupNorm w = 1+0.1N, b = 0.1N.  Decoder tensors come
+    first, so encoder=True leaves their values unchanged."""
     rng = np.random.default_rng(seed)
     out = OrderedDict()
-    for name, shape in vae_tensor_shapes(cfg).items():
+    for name, shape in vae_tensor_shapes(cfg, encoder).items():
         if len(shape) == 4 or len(shape) == 2:
             fan_in = int(np.prod(shape[1:]))
             a = rng.standard_normal(shape) / np.sqrt(fan_in)
@@ -164,11 +187,11 @@ def vae_state_dict_numpy(cfg, seed=0, round_bf16=True):
     return out
 
 
-def fill_vae_random_device(vae, seed=0, device="cuda"):
+def fill_vae_random_device(vae, seed=0, device="cuda", encoder=False):
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    for name, shape in vae_tensor_shapes(vae.cfg).items():
+    for name, shape in vae_tensor_shapes(vae.cfg, encoder).items():
         if len(shape) in (2, 4):
             fan_in = 1
             for s in shape[1:]:

@@ -182,6 +182,7 @@ typedef struct fmi_vae_config {
   int use_post_quant_conv;   /* 0 for FLUX */
   double scaling_factor;     /* 0.3611 */
   double shift_factor;       /* 0.1159 */
+  int use_quant_conv;        /* 0 for FLUX (encoder side 1x1 conv, autoencoder_kl.rs:67-77) */
 } fmi_vae_config;
 
 typedef struct fmi_vae fmi_vae;
@@ -203,6 +204,13 @@ double fmi_vae_shift_factor(const fmi_vae*);
 /* z (B,latent_channels,h,w) f32 NCHW -> image (B,out_channels,8h,8w) f32 NCHW.
  * == VAEModel::decode. */
 int fmi_vae_decode(fmi_vae*, const float* z, int B, int h, int w, float* image_out, void* stream);
+/* image (B,in_channels,H,W) f32 NCHW, H and W multiples of 8 -> z (B,latent_channels,H/8,W/8) f32 =
+ * mean + exp(0.5*logvar) * noise.  == VAEModel::encode = Encoder::forward (vaes/vae.rs:330-349),
+ * optional quant_conv, DiagonalGaussian (vae.rs:470-480).  The reference draws `noise` with an
+ * unseedable randn_like; here the caller passes it (fmi_randn) or NULL for z = mean.
+ * moments_out (B,2*latent_channels,H/8,W/8) f32 optional.  decode needs only the `decoder.*`
+ * tensors, encode only `encoder.*` (+ `quant_conv.*`). */
+int fmi_vae_encode(fmi_vae*, const float* image, int B, int H, int W, const float* noise, float* z_out, float* moments_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Text encoders — they run once per image in front of the denoise loop and

@@ -985,3 +985,62 @@ extern "C" int orc_vae_decode(orc_vae* v, const float* z, int B, int h, int w, f
   memcpy(out, y.data(), sizeof(float) * y.size());
   return 0;
 }
+
+// ---- VAE encoder ---------------------------------------------------------
+// Encoder::forward (vaes/vae.rs:330-349): conv_in, per level `layers_per_block` ResnetBlocks then
+// Downsample on every level but the last (vae.rs:285-290), mid block, GroupNorm + SiLU, conv_out
+// to 2*latent channels.  Downsample::forward (vae.rs:194-201): zero-pad ONE column on the right
+// and ONE row at the bottom, then a 3x3 stride-2 convolution with no padding.
+// AutoEncoderKl::encode (autoencoder_kl.rs:103-110): optional quant_conv (1x1), then
+// DiagonalGaussian(sample = true, chunk_dim = 1) (vae.rs:470-480): mean + exp(0.5*logvar) * noise.
+// The reference draws the noise with an unseedable randn_like; here it is an input (NULL -> mean).
+extern "C" int orc_vae_encode(orc_vae* v, const float* img, int B, int in_channels, int H, int W, int use_quant_conv, const float* noise, float* moments_out, float* z_out) {
+  const int nb = (int)v->boc.size();
+  F x(img, img + (size_t)B * in_channels * H * W), y;
+  int ch = v->boc[0];
+  if (!v_conv(v, "encoder.conv_in", x, B, in_channels, H, W, ch, 3, y)) return -1;
+  x.swap(y);
+  for (int lvl = 0; lvl < nb; ++lvl) {
+    const int block_out = v->boc[lvl];
+    const std::string p = "encoder.down_blocks." + std::to_string(lvl);
+    for (int i = 0; i < v->layers_per_block; ++i) {
+      if (!v_resnet(v, p + ".resnets." + std::to_string(i), x, B, ch, block_out, H, W)) return -1;
+      ch = block_out;
+    }
+    if (lvl != nb - 1) {
+      const float* w = v->get(p + ".downsamplers.0.conv.weight", (int64_t)ch * ch * 9);
+      const float* b = v->get(p + ".downsamplers.0.conv.bias", ch);
+      if (!w || !b) return -1;
+      const int Hp = H + 1, Wp = W + 1;
+      F pad((size_t)B * ch * Hp * Wp, 0.f);
+      for (int64_t bc = 0; bc < (int64_t)B * ch; ++bc)
+        for (int yy = 0; yy < H; ++yy) memcpy(&pad[(bc * Hp + yy) * Wp], &x[(bc * H + yy) * W], sizeof(float) * W);
+      const int Ho = (Hp - 3) / 2 + 1, Wo = (Wp - 3) / 2 + 1;
+      y.assign((size_t)B * ch * Ho * Wo, 0.f);
+      orc_conv2d(pad.data(), w, b, B, ch, Hp, Wp, ch, 3, 3, 0, 2, 1, y.data());
+      x.swap(y);
+      H = Ho, W = Wo;
+    }
+  }
+  if (!v_resnet(v, "encoder.mid_block.resnets.0", x, B, ch, ch, H, W)) return -1;
+  if (v->mid_attn && !v_attn(v, "encoder.mid_block.attentions.0", x, B, ch, H, W)) return -1;
+  if (!v_resnet(v, "encoder.mid_block.resnets.1", x, B, ch, ch, H, W)) return -1;
+  F n;
+  if (!v_gn(v, "encoder.conv_norm_out", x, B, ch, H * W, n, true)) return -1;
+  const int L2 = 2 * v->latent;
+  if (!v_conv(v, "encoder.conv_out", n, B, ch, H, W, L2, 3, y)) return -1;
+  if (use_quant_conv) {
+    F q;
+    if (!v_conv(v, "quant_conv", y, B, L2, H, W, L2, 1, q)) return -1;
+    y.swap(q);
+  }
+  if (moments_out) memcpy(moments_out, y.data(), sizeof(float) * y.size());
+  const int64_t plane = (int64_t)v->latent * H * W;
+  for (int b = 0; b < B; ++b)
+    for (int64_t i = 0; i < plane; ++i) {
+      const float mean = y[(int64_t)b * 2 * plane + i], logvar = y[(int64_t)b * 2 * plane + plane + i];
+      z_out[(int64_t)b * plane + i] = noise ? mean + expf(0.5f * logvar) * noise[(int64_t)b * plane + i] : mean;
+    }
+  return 0;
+}
+

@@ -70,6 +70,8 @@ orc_vae* orc_vae_create(const int* block_out_channels, int n_blocks, int layers_
 void orc_vae_destroy(orc_vae*);
 int orc_vae_set_tensor(orc_vae*, const char* name, const float* data, int64_t numel);
 int orc_vae_decode(orc_vae*, const float* z, int B, int h, int w, float* out);
+/* image (B,in_channels,H,W) -> moments (B,2*latent,H/8,W/8) [optional] and z = mean + exp(0.5 logvar) * noise (noise NULL: z = mean) */
+int orc_vae_encode(orc_vae*, const float* img, int B, int in_channels, int H, int W, int use_quant_conv, const float* noise, float* moments_out, float* z_out);
 
 /* ---- text encoders (oracle/text_oracle.cpp) ---- */
 typedef struct orc_t5 orc_t5;

@@ -361,6 +361,21 @@ class Vae:
             a, ap = _f(v)
             lib().orc_vae_set_tensor(self.h, k.encode(), ap, C.c_int64(a.size))
 
+    def encode(self, img, noise=None, return_moments=False):
+        """AutoEncoderKl::encode (autoencoder_kl.rs:103-110); noise = the DiagonalGaussian's randn (None -> mean)."""
+        img, ip = _f(img)
+        B, Cin, H, W = img.shape
+        f = 2 ** (len(self.cfg["block_out_channels"]) - 1)
+        h, w = H // f, W // f  # each Downsample: (n + 1 - 3) // 2 + 1 = floor(n / 2)
+        lat = self.cfg["latent_channels"]
+        mom = np.empty((B, 2 * lat, h, w), np.float32)
+        z = np.empty((B, lat, h, w), np.float32)
+        n_, npnt = _opt(noise)
+        rc = lib().orc_vae_encode(self.h, ip, B, Cin, H, W, int(self.cfg.get("use_quant_conv", False)), npnt, mom.ctypes.data_as(f32p), z.ctypes.data_as(f32p))
+        if rc:
+            raise RuntimeError("oracle vae_encode failed rc=%d" % rc)
+        return (z, mom) if return_moments else z
+
     def decode(self, z):
         z, zp = _f(z)
         B, _, h, w = z.shape

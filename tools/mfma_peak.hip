@@ -28,6 +28,35 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(const uint4* in, float* out,
   out[(size_t)blockIdx.x * blockDim.x + tid] = s;
 }
 
+// GEMM-like register use: NA x NB accumulators, acc[i][j] += mfma(a[i], b[j]) with distinct operand tuples
+template <int NA, int NB>
+__global__ __launch_bounds__(512, 2) void mfma_tile(const uint4* in, float* out, int iters) {
+  const int tid = threadIdx.x;
+  bf16x8_t a[NA], b[NB];
+  for (int i = 0; i < NA; ++i) a[i] = __builtin_bit_cast(bf16x8_t, in[(tid + 64 * i) & 1023]);
+  for (int j = 0; j < NB; ++j) b[j] = __builtin_bit_cast(bf16x8_t, in[(tid + 64 * j + 512) & 1023]);
+  f32x16 acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    asm volatile("" : "+v"(a[0]));  // keep the loop from being folded; no instruction emitted
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) s += acc[i][j][0] + acc[i][j][7];
+  out[(size_t)blockIdx.x * blockDim.x + tid] = s;
+}
+
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 20000;
   uint4* in;
@@ -66,5 +95,7 @@ int main(int argc, char** argv) {
   run(mfma_loop<2>, "2 accumulators round-robin", 2, 256, 256, iters * 10);
   run(mfma_loop<1>, "1 accumulator (back to back)", 1, 256, 256, iters * 10);
   run(mfma_loop<2>, "2 accumulators, 2 waves per SIMD", 2, 256, 512, iters * 10);
+  run(mfma_tile<4, 2>, "4x2 tile, distinct A/B tuples, 1 w/SIMD", 8, 256, 256, iters * 10);
+  run(mfma_tile<4, 2>, "4x2 tile, distinct A/B tuples, 2 w/SIMD", 8, 256, 512, iters * 10);
   return 0;
 }
