@@ -132,6 +132,15 @@ void launch_scb(const int8_t* w, const float* scb, void* out, int col, int n) {
   hipLaunchKernelGGL((dequant_int8_scb_kernel<T>), dim3((unsigned)cdiv64(n, 256 * 8)), dim3(256), 0, (hipStream_t) nullptr, w, scb, (T*)out, col, n);
 }
 
+// stream-ordered form for the model's own use (LLM.int8 weights are expanded right before their GEMM)
+int launch_dequant_int8_scb_bf16(const int8_t* w, const float* scb, bf16_t* out, int col, int64_t n, hipStream_t stream) {
+  if (n <= 0) return FMI_OK;
+  if (n >= (1ll << 31)) return fail(FMI_ERR_UNSUPPORTED, "dequant_int8_scb: more than 2^31 elements");
+  hipLaunchKernelGGL((dequant_int8_scb_kernel<bf16_bits>), dim3((unsigned)cdiv64(n, 256 * 8)), dim3(256), 0, stream, w, scb, (bf16_bits*)out, col, (int)n);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
 }  // namespace fmi
 
 using namespace fmi;

@@ -183,6 +183,8 @@ int launch_layernorm_mod(const float* x, const float* scale, const float* shift,
 // y(M,N) f32 (+)= act_in(x(M,K) f32) W(N,K)^T bf16 + bias bf16 ; M <= 8
 int launch_gemv(const float* x, const bf16_t* W, const bf16_t* bias, float* y, int M, int N, int K,
                 int silu_in, int accumulate, hipStream_t stream);
+// bf16 out = w_i8 * SCB[row] / 127 (dequant.cu:205-214) on `stream`
+int launch_dequant_int8_scb_bf16(const int8_t* w, const float* scb, bf16_t* out, int col, int64_t n, hipStream_t stream);
 int launch_timestep_embedding(const float* t, int B, int dim, float* out, hipStream_t stream);
 int launch_cast_to_bf16(const void* src, fmi_dtype dt, bf16_t* dst, int64_t n, hipStream_t stream);
 int launch_cast_to_f32(const void* src, fmi_dtype dt, float* dst, int64_t n, hipStream_t stream);

@@ -306,7 +306,8 @@ void with_gate(GemmProblem& p, const float* gate, int rows_per_batch, int bstrid
 // (bitsandbytes/mod.rs:301-312) without allocating or leaving the device.
 int densify(fmi_flux* m, GemmProblem* p, int n, hipStream_t s) {
   for (int i = 0; i < n && i < 2; ++i) {
-    if (!p[i].q_type || p[i].M < m->q_fused_max_rows) continue;
+    // q_type 3 = LLM.int8 (SCB): no fused kernel, always expanded (BnbLinear::Int8 forward, mod.rs:293-300)
+    if (!p[i].q_type || (p[i].q_type != 3 && p[i].M < m->q_fused_max_rows)) continue;
     const size_t elems = (size_t)p[i].N * p[i].K;
     if (elems > m->wscratch_elems || !m->wscratch[0]) {
       const size_t want = std::max(elems, (size_t)(3 * m->D + m->M) * (size_t)m->D);  // largest fused weight of the model
@@ -318,7 +319,9 @@ int densify(fmi_flux* m, GemmProblem* p, int n, hipStream_t s) {
       m->wscratch_elems = want;
     }
     if (elems >= (1ull << 31)) return fail(FMI_ERR_UNSUPPORTED, "densify: weight too large");
-    if (p[i].q_type == 2)
+    if (p[i].q_type == 3)
+      FMI_TRY(launch_dequant_int8_scb_bf16(reinterpret_cast<const int8_t*>(p[i].Wq), p[i].absmax, m->wscratch[i], p[i].K, (int64_t)elems, s));
+    else if (p[i].q_type == 2)
       dequantize_blockwise_bf16_nf4(nullptr, p[i].Wq, p[i].absmax, m->wscratch[i], p[i].q_blocksize, (int)elems, s);
     else
       dequantize_blockwise_bf16_fp4(nullptr, p[i].Wq, p[i].absmax, m->wscratch[i], p[i].q_blocksize, (int)elems, s);
@@ -727,6 +730,7 @@ extern "C" int fmi_flux_set_linear_bnb4(fmi_flux* m, const char* prefix, const u
     return FMI_OK;
   }
   if (in_features != d->K || row0 + out_features > d->N) return fail(FMI_ERR_INVALID, "set_linear_bnb4: shape mismatch for " + wname);
+  if (d->q_type == 3) return fail(FMI_ERR_UNSUPPORTED, "set_linear_bnb4: this fused projection already holds int8 parts");
   if (d->q_type && (d->q_type != quant_type || d->q_blocksize != blocksize))
     return fail(FMI_ERR_UNSUPPORTED, "set_linear_bnb4: all parts of a fused projection must share quant type and blocksize");
   if (!d->wq) {
@@ -740,6 +744,50 @@ extern "C" int fmi_flux_set_linear_bnb4(fmi_flux* m, const char* prefix, const u
   const size_t n = (size_t)out_features * in_features;
   FMI_HIP_TRY(hipMemcpy(d->wq + (size_t)row0 * d->K / 2, packed, n / 2, hipMemcpyDefault));
   FMI_HIP_TRY(hipMemcpy(d->absmax + (size_t)row0 * d->K / blocksize, absmax, n / blocksize * 4, hipMemcpyDefault));
+  m->missing.erase(wname);
+  return FMI_OK;
+}
+
+// LLM.int8 linears (BnbLinear::Int8, bitsandbytes/mod.rs:104-134): weight i8 (out,in) + SCB f32 (out).
+// forward = dequantize_8bit (w * SCB[row] / 127, dequant.cu:205-214) then matmul (mod.rs:293-300):
+// block linears keep the int8 weight and are expanded into the bf16 scratch right before their GEMM.
+extern "C" int fmi_flux_set_linear_int8(fmi_flux* m, const char* prefix, const int8_t* weight, const float* scb, int out_features, int in_features) {
+  if (!m || !prefix || !weight || !scb) return fail(FMI_ERR_INVALID, "set_linear_int8: null argument");
+  int row0 = 0;
+  Dense* d = find_dense(m, prefix, &row0);
+  const std::string wname = std::string(prefix) + ".weight";
+  const int64_t n = (int64_t)out_features * in_features;
+  if (!d) {  // embedders / modulation: expand once into the dense arena
+    auto it = m->names.find(wname);
+    if (it == m->names.end()) return fail(FMI_ERR_INVALID, std::string("set_linear_int8: unknown linear '") + prefix + "'");
+    const Dest& dst = it->second;
+    if (dst.rows != out_features || dst.cols != in_features) return fail(FMI_ERR_INVALID, "set_linear_int8: shape mismatch for " + wname);
+    int8_t* dq = nullptr;
+    float* ds = nullptr;
+    FMI_HIP_TRY(hipMalloc((void**)&dq, n));
+    FMI_HIP_TRY(hipMalloc((void**)&ds, (size_t)out_features * 4));
+    FMI_HIP_TRY(hipMemcpy(dq, weight, n, hipMemcpyDefault));
+    FMI_HIP_TRY(hipMemcpy(ds, scb, (size_t)out_features * 4, hipMemcpyDefault));
+    int rc = launch_dequant_int8_scb_bf16(dq, ds, (bf16_t*)dst.ptr, in_features, n, nullptr);
+    hipDeviceSynchronize();
+    hipFree(dq);
+    hipFree(ds);
+    if (rc) return rc;
+    m->missing.erase(wname);
+    return FMI_OK;
+  }
+  if (in_features != d->K || row0 + out_features > d->N) return fail(FMI_ERR_INVALID, "set_linear_int8: shape mismatch for " + wname);
+  if (d->q_type && d->q_type != 3) return fail(FMI_ERR_UNSUPPORTED, "set_linear_int8: all parts of a fused projection must share the quantisation type");
+  if (!d->wq) {
+    FMI_HIP_TRY(hipMalloc((void**)&d->wq, (size_t)d->N * d->K));
+    FMI_HIP_TRY(hipMalloc((void**)&d->absmax, (size_t)d->N * 4));
+    FMI_HIP_TRY(hipMemset(d->wq, 0, (size_t)d->N * d->K));
+    FMI_HIP_TRY(hipMemset(d->absmax, 0, (size_t)d->N * 4));
+  }
+  d->q_type = 3;
+  d->q_blocksize = 0;
+  FMI_HIP_TRY(hipMemcpy(d->wq + (size_t)row0 * d->K, weight, n, hipMemcpyDefault));
+  FMI_HIP_TRY(hipMemcpy(d->absmax + row0, scb, (size_t)out_features * 4, hipMemcpyDefault));
   m->missing.erase(wname);
   return FMI_OK;
 }

@@ -117,6 +117,18 @@ class FluxModel:
             pp, ap = C.c_void_p(pk.ctypes.data), C.c_void_p(am.ctypes.data)
         L.check(self.lib.fmi_flux_set_linear_bnb4(self.h, prefix.encode(), pp, ap, blocksize, q, out_features, in_features))
 
+    def set_linear_int8(self, prefix: str, weight, scb, out_features: int, in_features: int):
+        """LLM.int8 linear (BnbLinear::Int8): weight int8 (out,in), SCB f32 (out)."""
+        if isinstance(weight, torch.Tensor):
+            w, sc = weight.contiguous(), scb.to(torch.float32).contiguous()
+            assert w.dtype == torch.int8
+            wp, sp = C.c_void_p(w.data_ptr()), C.c_void_p(sc.data_ptr())
+        else:
+            w = np.ascontiguousarray(weight, np.int8)
+            sc = np.ascontiguousarray(scb, np.float32)
+            wp, sp = C.c_void_p(w.ctypes.data), C.c_void_p(sc.ctypes.data)
+        L.check(self.lib.fmi_flux_set_linear_int8(self.h, prefix.encode(), wp, sp, out_features, in_features))
+
     def missing(self) -> List[str]:
         n = self.lib.fmi_flux_missing_count(self.h)
         return [self.lib.fmi_flux_missing_name(self.h, i).decode() for i in range(n)]

@@ -136,7 +136,12 @@ def load_flux(flux, tensors: Iterator[Tuple[str, torch.Tensor]]) -> dict:
             prefix, rest = name.split(".weight.", 1)
             pending.setdefault(prefix, {})["weight." + rest] = t
             continue
-        if name.endswith(".weight") and t.dtype == torch.uint8:  # packed 4-bit weight of a bnb linear
+        if name.endswith(".SCB"):  # LLM.int8 row scales (bitsandbytes/mod.rs:113,126)
+            pending.setdefault(name[:-len(".SCB")], {})["SCB"] = t
+            continue
+        if name.endswith(".weight_format"):
+            continue
+        if name.endswith(".weight") and t.dtype in (torch.uint8, torch.int8):  # packed 4-bit / int8 weight of a bnb linear
             pending.setdefault(name[:-len(".weight")], {})["weight"] = t
             continue
         if name in want:
@@ -144,7 +149,17 @@ def load_flux(flux, tensors: Iterator[Tuple[str, torch.Tensor]]) -> dict:
             stats["dense"] += 1
         else:
             stats["skipped"].append(name)
+    stats["int8"] = 0
     for prefix, group in pending.items():
+        if "SCB" in group:  # BnbLinear::Int8
+            if "weight" not in group or group["weight"].dtype != torch.int8:
+                raise ValueError(f"`BnbLinear` int8 layer {prefix} needs an int8 `weight` next to `SCB`")
+            out_f, in_f = want[prefix + ".weight"]
+            if tuple(group["weight"].shape) != (out_f, in_f) or group["SCB"].numel() != out_f:
+                raise ValueError(f"{prefix}: int8 weight {tuple(group['weight'].shape)} / SCB {tuple(group['SCB'].shape)} != expected {(out_f, in_f)}")
+            flux.set_linear_int8(prefix, group["weight"], group["SCB"], out_f, in_f)
+            stats["int8"] += 1
+            continue
         qkey = next((k for k in group if k.startswith("weight.quant_state.bitsandbytes__")), None)
         if qkey is None or "weight" not in group or "weight.absmax" not in group:
             raise ValueError(f"`BnbLinear` expects fp4/nf4 layers: incomplete tensors for {prefix}: {sorted(group)}")  # bitsandbytes/mod.rs:120

@@ -118,6 +118,10 @@ int fmi_flux_set_linear_bnb4(fmi_flux*, const char* prefix, const uint8_t* packe
                              int out_features, int in_features);
 
 /* Number of tensors still missing (never set); names via fmi_flux_missing_name(i). */
+/* LLM.int8 linear (BnbLinear::Int8, bitsandbytes/mod.rs:104-134,293-300): weight int8 (out,in) row
+ * major + SCB f32 (out); effective weight = w * SCB[row] / 127 (dequant.cu:205-214), expanded to
+ * bf16 right before the layer's GEMM.  Same prefix rules as fmi_flux_set_linear_bnb4. */
+int fmi_flux_set_linear_int8(fmi_flux*, const char* prefix, const int8_t* weight, const float* scb, int out_features, int in_features);
 int fmi_flux_missing_count(const fmi_flux*);
 const char* fmi_flux_missing_name(const fmi_flux*, int i);
 /* Bytes of HBM held by the model (weights + current workspace). */

@@ -115,3 +115,38 @@ def test_flux_nf4_blocks_match_dequantised_oracle(models):
     assert err2 <= 1e-2
     # both paths multiply the same bf16 weights: they agree far below the oracle tolerance
     assert rel_l2(got2, got) <= 2e-3
+
+
+def test_flux_int8_scb_blocks_match_dequantised_oracle(models, tmp_path):
+    """LLM.int8 linears (BnbLinear::Int8, bitsandbytes/mod.rs:104-134,293-300): block linears stored as int8 + SCB,
+    loaded through the HF-bnb naming (`<prefix>.weight` int8, `<prefix>.SCB`), equal the oracle on w*SCB/127."""
+    torch, d = models["torch"], models["d"]
+    from oracle import oracle as orc
+    from diffusion_rs_amd import loader
+    sd = dict(models["sd"])
+    oq = orc.Flux(SMALL_FLUX)
+    tensors = []
+    nq = 0
+    for name, w in sd.items():
+        if d.synth.is_block_linear(name) or name == "x_embedder.weight":  # one non-block linear too (expanded at load)
+            scb = np.abs(w).max(axis=1).astype(np.float32)
+            w8 = np.clip(np.rint(w / scb[:, None] * 127.0), -127, 127).astype(np.int8)
+            wdq = orc.dequantize_8bit(w8, scb, w.shape[0], w.shape[1], "bf16").reshape(w.shape)
+            oq.set_tensor(name, wdq)
+            tensors.append((name, torch.from_numpy(w8)))
+            tensors.append((name[:-len(".weight")] + ".SCB", torch.from_numpy(scb)))
+            nq += 1
+        else:
+            oq.set_tensor(name, w)
+            tensors.append((name, torch.from_numpy(w).to(torch.bfloat16)))
+    gq = d.FluxModel(SMALL_FLUX)
+    stats = loader.load_flux(gq, iter(tensors))
+    assert stats["int8"] == nq and stats["bnb4"] == 0
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, 2, (8, 8), 32, seed=13)
+    t = np.array([0.8, 0.3], np.float32)
+    g = np.array([3.5, 3.5], np.float32)
+    ref = oq.forward(img, ids, txt, txt_ids, t, y, g)
+    got = host(gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
+    err = rel_l2(got, ref)
+    print(f"int8 (SCB) forward, {nq} quantised linears: rel-L2 {err:.3e}")
+    assert err <= 1e-2
