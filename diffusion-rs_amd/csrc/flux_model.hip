@@ -83,6 +83,9 @@ struct fmi_flux {
   float phase_ms[PH_COUNT] = {0};
   int attn_thr = 96;
   // 4-bit weights, large-M regime: per-layer streaming dequant into a reusable bf16 scratch
+  // all denoise steps' modulation vectors (n_steps*B, n_mod) and vec (n_steps*B, D), see fmi_flux_denoise
+  float *mod_steps = nullptr, *vec_steps = nullptr;
+  size_t mod_steps_rows = 0;
   bf16_t* wscratch[2] = {nullptr, nullptr};
   size_t wscratch_elems = 0;
   int q_fused_max_rows = 512;  // M below this keeps the fused dequant-GEMM (weight-bandwidth-bound regime)
@@ -377,8 +380,29 @@ int prepare_static(fmi_flux* m, const fmi_flux_inputs* in, hipStream_t s) {
   return FMI_OK;
 }
 
+// vec_ = time_in(temb(t)) [+ guidance_in(temb(g))] + vector_in(y)   (model.rs:813-820) -> vec_out (B, D) f32
+int compute_vec(fmi_flux* m, const fmi_flux_inputs* in, const float* timesteps_dev, float* vec_out, hipStream_t s) {
+  auto& w = m->ws;
+  const fmi_flux_config& c = m->cfg;
+  const int B = in->B, D = m->D;
+  FMI_TRY(launch_timestep_embedding(timesteps_dev, B, 256, w.temb, s));
+  FMI_TRY(launch_gemv(w.temb, m->time1.w, m->time1.b, w.h1, B, D, 256, 0, 0, s));
+  FMI_TRY(launch_gemv(w.h1, m->time2.w, m->time2.b, vec_out, B, D, D, 1, 0, s));
+  if (c.guidance_embeds) {
+    if (!in->guidance) return fail(FMI_ERR_INVALID, "flux: guidance_embeds model needs a guidance vector");
+    FMI_TRY(launch_timestep_embedding(in->guidance, B, 256, w.temb, s));
+    FMI_TRY(launch_gemv(w.temb, m->guid1.w, m->guid1.b, w.h1, B, D, 256, 0, 0, s));
+    FMI_TRY(launch_gemv(w.h1, m->guid2.w, m->guid2.b, vec_out, B, D, D, 1, 1, s));
+  }
+  FMI_TRY(launch_gemv(w.yf, m->vecin1.w, m->vecin1.b, w.h1, B, D, c.pooled_projection_dim, 0, 0, s));
+  FMI_TRY(launch_gemv(w.h1, m->vecin2.w, m->vecin2.b, vec_out, B, D, D, 1, 1, s));
+  return FMI_OK;
+}
+
 // One model evaluation given prepared static inputs; img_f32 (B,S,C) -> pred (B,S,C) f32.
-int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, const float* timesteps_dev, float* pred, hipStream_t s) {
+// mod_pre: this step's (B, n_mod) modulation vectors if the caller precomputed them (fmi_flux_denoise), else null.
+int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, const float* timesteps_dev, float* pred, hipStream_t s,
+                 const float* mod_pre = nullptr) {
   auto& w = m->ws;
   const fmi_flux_config& c = m->cfg;
   const int B = in->B, S = in->S, T = in->T, L = S + T;
@@ -390,35 +414,25 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
   {
     PhaseTimer pt(m, s, PH_EMBED);
     FMI_TRY(launch_cast_to_bf16(img_f32, FMI_F32, w.img_bf, (int64_t)B * S * C, s));
-    // vec_ = time_in(temb(t)) [+ guidance_in(temb(g))] + vector_in(y)   (model.rs:813-820)
-    FMI_TRY(launch_timestep_embedding(timesteps_dev, B, 256, w.temb, s));
-    FMI_TRY(launch_gemv(w.temb, m->time1.w, m->time1.b, w.h1, B, D, 256, 0, 0, s));
-    FMI_TRY(launch_gemv(w.h1, m->time2.w, m->time2.b, w.vec, B, D, D, 1, 0, s));
-    if (c.guidance_embeds) {
-      if (!in->guidance) return fail(FMI_ERR_INVALID, "flux: guidance_embeds model needs a guidance vector");
-      FMI_TRY(launch_timestep_embedding(in->guidance, B, 256, w.temb, s));
-      FMI_TRY(launch_gemv(w.temb, m->guid1.w, m->guid1.b, w.h1, B, D, 256, 0, 0, s));
-      FMI_TRY(launch_gemv(w.h1, m->guid2.w, m->guid2.b, w.vec, B, D, D, 1, 1, s));
-    }
-    FMI_TRY(launch_gemv(w.yf, m->vecin1.w, m->vecin1.b, w.h1, B, D, c.pooled_projection_dim, 0, 0, s));
-    FMI_TRY(launch_gemv(w.h1, m->vecin2.w, m->vecin2.b, w.vec, B, D, D, 1, 1, s));
+    if (!mod_pre) FMI_TRY(compute_vec(m, in, timesteps_dev, w.vec, s));
     // img = img_in(img), txt = txt_in(txt)   (model.rs:811-812) -> f32 residual streams
     GemmProblem p[2];
     p[0] = make_problem(m->img_in, w.img_bf, C, B * S, w.x_img, D, EPI_STORE_F32);
     p[1] = make_problem(m->txt_in, w.txt_bf, c.joint_attention_dim, B * T, w.x_txt, D, EPI_STORE_F32);
     FMI_TRY(gemm2(m, p, 2, s));
   }
-  {
+  if (!mod_pre) {
     // every Modulation1/2 + LastLayer.ada_ln of the model in one GEMV: lin(silu(vec)) (model.rs:244-299,695-698)
     PhaseTimer pt(m, s, PH_MOD);
     FMI_TRY(launch_gemv(w.vec, m->mod_all.w, m->mod_all.b, w.mod, B, nmod, D, 1, 0, s));
   }
+  const float* const mod = mod_pre ? mod_pre : w.mod;
 
   // ---------------- double-stream blocks (model.rs:523-565)
   for (int i = 0; i < c.num_layers; ++i) {
     auto& bw = m->dbl[i];
-    const float* mi = w.mod + bw.mod_off[0];  // shift1, scale1, gate1, shift2, scale2, gate2
-    const float* mt = w.mod + bw.mod_off[1];
+    const float* mi = mod + bw.mod_off[0];  // shift1, scale1, gate1, shift2, scale2, gate2
+    const float* mt = mod + bw.mod_off[1];
     bf16_t* xm_txt = w.xm;
     bf16_t* xm_img = w.xm + (size_t)B * T * D;
     {
@@ -486,7 +500,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
   const int ldbig = 3 * D + Mh;
   for (int i = 0; i < c.num_single_layers; ++i) {
     auto& bw = m->sgl[i];
-    const float* mo = w.mod + bw.mod_off;  // shift, scale, gate
+    const float* mo = mod + bw.mod_off;  // shift, scale, gate
     {
       PhaseTimer pt(m, s, PH_LN);
       FMI_TRY(launch_layernorm_mod(w.x, mo + D, mo, nmod, L, w.xm, B * L, D, 1e-6f, s));
@@ -523,7 +537,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
   // ---------------- img = img[:, T:] ; LastLayer (model.rs:694-705): chunks = (scale, shift)
   {
     PhaseTimer pt(m, s, PH_FINAL);
-    const float* mf = w.mod + m->mod_final_off;
+    const float* mf = mod + m->mod_final_off;
     for (int b = 0; b < B; ++b)
       FMI_TRY(launch_layernorm_mod(w.x + ((size_t)b * L + T) * D, mf + (size_t)b * nmod, mf + (size_t)b * nmod + D, 0, 0,
                                    w.xm + (size_t)b * S * D, S, D, 1e-6f, s));
@@ -593,6 +607,8 @@ extern "C" void fmi_flux_destroy(fmi_flux* m) {
   if (m->arena) hipFree(m->arena);
   for (int k = 0; k < 2; ++k)
     if (m->wscratch[k]) hipFree(m->wscratch[k]);
+  if (m->mod_steps) hipFree(m->mod_steps);
+  if (m->vec_steps) hipFree(m->vec_steps);
   for (auto& b : m->dbl)
     for (int s = 0; s < 2; ++s)
       for (Dense* d : {&b.qkv[s], &b.proj[s], &b.mlp1[s], &b.mlp2[s]}) {
@@ -827,8 +843,36 @@ extern "C" int fmi_flux_denoise(fmi_flux* m, const fmi_flux_inputs* in, float* i
     for (int b = 0; b < B; ++b) tv[(size_t)i * B + b] = 1.0f * (float)timesteps_host[i];
   FMI_HIP_TRY(hipMemcpyAsync(m->ws.tv, tv.data(), tv.size() * 4, hipMemcpyHostToDevice, s));
   FMI_HIP_TRY(hipStreamSynchronize(s));  // tv is pageable host memory: finish the copy before it dies
+  // The modulation vectors depend on (t, guidance, y) only, never on the latent: all steps' vectors are
+  // computed up front, GEMV_MAXROWS rows per pass over the 6.5 GB modulation matrix (13 passes for 50
+  // steps instead of 50: the per-step GEMV was 1.2 ms of pure HBM streaming per denoise step).
+  const float* mod_steps = nullptr;
+  const size_t R = (size_t)n_steps * B, nmod = (size_t)m->n_mod;
+  if (n_steps > 1 && R * nmod * 4 <= (2ull << 30)) {
+    if (m->mod_steps_rows < R) {
+      FMI_HIP_TRY(hipStreamSynchronize(s));
+      if (m->mod_steps) FMI_HIP_TRY(hipFree(m->mod_steps));
+      if (m->vec_steps) FMI_HIP_TRY(hipFree(m->vec_steps));
+      m->mod_steps = m->vec_steps = nullptr, m->mod_steps_rows = 0;
+      FMI_HIP_TRY(hipMalloc((void**)&m->mod_steps, R * nmod * 4));
+      FMI_HIP_TRY(hipMalloc((void**)&m->vec_steps, R * (size_t)m->D * 4));
+      m->mod_steps_rows = R;
+    }
+    {
+      PhaseTimer pt(m, s, PH_EMBED);
+      for (int i = 0; i < n_steps; ++i) FMI_TRY(compute_vec(m, in, m->ws.tv + (size_t)i * B, m->vec_steps + (size_t)i * B * m->D, s));
+    }
+    {
+      PhaseTimer pt(m, s, PH_MOD);
+      constexpr int GEMV_MAXROWS = 4;  // rows * D * 4 B of x staged in LDS per block (<= 64 KiB)
+      for (size_t r0 = 0; r0 < R; r0 += GEMV_MAXROWS)
+        FMI_TRY(launch_gemv(m->vec_steps + r0 * m->D, m->mod_all.w, m->mod_all.b, m->mod_steps + r0 * nmod, (int)std::min<size_t>(GEMV_MAXROWS, R - r0), (int)nmod,
+                            m->D, 1, 0, s));
+    }
+    mod_steps = m->mod_steps;
+  }
   for (int i = 0; i < n_steps; ++i) {
-    FMI_TRY(forward_core(m, in, img_inout, m->ws.tv + (size_t)i * B, m->ws.pred_tmp, s));
+    FMI_TRY(forward_core(m, in, img_inout, m->ws.tv + (size_t)i * B, m->ws.pred_tmp, s, mod_steps ? mod_steps + (size_t)i * B * nmod : nullptr));
     // img = img + pred * (t_prev - t_curr)  (sampling.rs:43), scalar rounded to f32 like candle's affine
     const float dt = (float)(timesteps_host[i + 1] - timesteps_host[i]);
     FMI_TRY(launch_euler_update(img_inout, m->ws.pred_tmp, dt, n, s));
