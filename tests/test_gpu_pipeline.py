@@ -233,3 +233,44 @@ def test_prompt_to_image_with_text_encoders(tmp_path):
 
 def _oracle_pipeline_cfg(sd, vsd, lat, t5, clip, steps, guidance, sched):
     return _oracle_pipeline(sd, vsd, lat, t5.astype(np.float32), clip.astype(np.float32), steps, guidance, sched)
+
+
+def test_c1_schnell_256x256_4step_matches_oracle(tmp_path):
+    """BASELINE.json configs[0] (C1) at the shapes the oracle can hold: FLUX.1-schnell semantics — no guidance
+    embedder (guidance_embeds=false), 256x256 image (S = 256), T = 256 text tokens, 4 Euler steps on the
+    non-dynamic shift=1.0 schedule — through Pipeline (diffusers directory) vs the oracle chain."""
+    import torch
+    import diffusion_rs_amd as d
+    from oracle import oracle as orc
+    cfg = dict(SMALL_FLUX, guidance_embeds=False)
+    sd = d.synth.flux_state_dict_numpy(cfg, seed=21)
+    vsd = d.synth.vae_state_dict_numpy(SMALL_VAE, seed=21)
+    assert not any("guidance_embedder" in k for k in sd)
+    root = str(tmp_path / "tiny-schnell")
+    _write_diffusers_dir(root, sd, vsd)
+    json.dump({k: cfg[k] for k in ("in_channels", "pooled_projection_dim", "joint_attention_dim", "num_attention_heads", "num_layers", "num_single_layers",
+                                   "guidance_embeds")}, open(os.path.join(root, "transformer", "config.json"), "w"))
+    json.dump({"_class_name": "FlowMatchEulerDiscreteScheduler", "base_image_seq_len": 256, "base_shift": 0.5, "max_image_seq_len": 4096, "max_shift": 1.15,
+               "shift": 1.0, "use_dynamic_shifting": False}, open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    pipe = d.Pipeline(d.ModelSource.ModelId(root))
+    assert not pipe.flux.is_guidance()
+    B, T = 1, 256
+    rng = np.random.default_rng(4)
+    t5 = bf16_round(rng.standard_normal((B, T, cfg["joint_attention_dim"])).astype(np.float32))
+    clip = rng.standard_normal((B, cfg["pooled_projection_dim"])).astype(np.float32)
+    lat = rng.standard_normal((B, 16, 32, 32)).astype(np.float32)  # 256x256 -> 32x32 latent -> S = 256
+    params = d.DiffusionGenerationParams(height=256, width=256, num_steps=4, guidance_scale=0.0)
+    u8 = pipe.forward(["x"], params, embeddings=(dev(t5, torch.bfloat16), dev(clip)), latents=dev(lat), output="tensor")
+    ts = pipe.scheduler.get_timesteps(4, pipe.scheduler.calculate_shift(256))
+    np.testing.assert_allclose(ts, [1.0, 0.75, 0.5, 0.25, 0.0], atol=1e-12)  # linspace, shift 1.0 (scheduler.rs / schnell)
+    om, ov = orc.Flux(cfg), orc.Vae(SMALL_VAE)
+    om.load(sd)
+    ov.load(vsd)
+    img, ids = orc.pack_latents(lat)
+    assert img.shape[1] == 256
+    img = om.denoise(img, ids, t5, np.zeros((B, T, 3), np.float32), clip, None, ts)
+    z = orc.unpack_latents(img, 16, 32, 32) * np.float32(1.0 / SMALL_VAE["scaling_factor"]) + np.float32(SMALL_VAE["shift_factor"])
+    ref_u8 = orc.postprocess_u8(ov.decode(z.astype(np.float32)))
+    diff = np.abs(u8.cpu().numpy().astype(np.int32) - ref_u8.astype(np.int32))
+    print(f"C1 (schnell 256x256 4-step) u8: max |d| {diff.max()}, frac<=2 {float((diff <= 2).mean()):.4f}")
+    assert float((diff <= 2).mean()) >= 0.99
