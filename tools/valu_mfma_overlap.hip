@@ -8,9 +8,12 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__global__ __launch_bounds__(512, 2) void k(const uint4* in, float* out, long long* cyc, int mfma_iters, int valu_iters, int with_exp) {
+template <int YIELD>
+__global__ __launch_bounds__(512, 2) void k(const uint4* in, float* out, long long* cyc, int mfma_iters, int valu_iters, int with_exp, int valu_prio) {
   const int tid = threadIdx.x, wave = tid >> 6;
   float res = 0.f;
+  if (wave >= 4 && valu_prio == 1) __builtin_amdgcn_s_setprio(1);
+  if (wave >= 4 && valu_prio == 3) __builtin_amdgcn_s_setprio(3);
   long long t0 = clock64();
   if (wave < 4) {
     bf16x8_t a = __builtin_bit_cast(bf16x8_t, in[tid & 255]), b = __builtin_bit_cast(bf16x8_t, in[256 + (tid & 255)]);
@@ -19,7 +22,14 @@ __global__ __launch_bounds__(512, 2) void k(const uint4* in, float* out, long lo
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     for (int it = 0; it < mfma_iters; ++it) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+        // does the MFMA wave have to yield explicitly for the other wave's VALU to get issue slots?
+        if (YIELD == 1) asm volatile("s_nop 7");
+        if (YIELD == 2) asm volatile("s_nop 15");
+        if (YIELD == 3) asm volatile("s_nop 15\n\ts_nop 7");
+        if (YIELD == 4) __builtin_amdgcn_s_sleep(1);
+      }
     }
     for (int i = 0; i < 8; ++i) res += acc[i][0];
   } else {
@@ -78,12 +88,20 @@ int main() {
   for (int i = 0; i < 2048; ++i) h[i] = 0x3f803f80u ^ (i * 2654435761u & 0x007f007fu);
   hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
   const int MI = 4000, VI = 4000;  // 8 MFMAs (256 clk of pipe) vs 16 FMAs (68 clk) per iteration
-  struct Case { int mi, vi, ex; const char* what; } cases[] = {
-      {MI, 0, 0, "MFMA waves alone"},           {0, VI * 4, 0, "VALU (fma) waves alone"},          {0, VI * 2, 1, "VALU (fma+exp) waves alone"},
-      {MI, VI * 4, 0, "MFMA + VALU(fma) together"}, {MI, VI * 2, 1, "MFMA + VALU(fma+exp) together"},
+  struct Case { int mi, vi, ex, prio; const char* what; } cases[] = {
+      {MI, 0, 0, 0, "MFMA waves alone"},           {0, VI * 4, 0, 0, "VALU (fma) waves alone"},          {0, VI * 2, 1, 0, "VALU (fma+exp) waves alone"},
+      {MI, VI * 4, 0, 0, "MFMA + VALU(fma) together"}, {MI, VI * 2, 1, 0, "MFMA + VALU(fma+exp) together"},
+      {MI, VI * 4, 0, 3, "MFMA + VALU(fma), VALU prio 3"}, {MI, VI * 2, 1, 3, "MFMA + VALU(fma+exp), VALU prio 3"},
+      {MI, VI, 0, 3, "MFMA + short VALU(fma), prio 3"},
+      {MI, VI * 4, 0, 10, "MFMA(+s_nop 7) + VALU(fma)"}, {MI, VI * 4, 0, 11, "MFMA(+s_nop 15) + VALU(fma)"}, {MI, VI * 4, 0, 12, "MFMA(+s_nop 15+7) + VALU(fma)"},
+      {MI, VI * 4, 0, 13, "MFMA(+s_sleep 1) + VALU(fma)"},
   };
   for (auto& c : cases) {
-    k<<<256, 512>>>(in, out, cyc, c.mi, c.vi, c.ex);
+    if (c.prio == 10) k<1><<<256, 512>>>(in, out, cyc, c.mi, c.vi, c.ex, 0);
+    else if (c.prio == 11) k<2><<<256, 512>>>(in, out, cyc, c.mi, c.vi, c.ex, 0);
+    else if (c.prio == 12) k<3><<<256, 512>>>(in, out, cyc, c.mi, c.vi, c.ex, 0);
+    else if (c.prio == 13) k<4><<<256, 512>>>(in, out, cyc, c.mi, c.vi, c.ex, 0);
+    else k<0><<<256, 512>>>(in, out, cyc, c.mi, c.vi, c.ex, c.prio);
     hipDeviceSynchronize();
     long long t[8];
     hipMemcpy(t, cyc, 64, hipMemcpyDeviceToHost);
