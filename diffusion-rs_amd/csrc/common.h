@@ -141,6 +141,19 @@ struct GemmProblem {
   // zero padding on the right/bottom edge only, vaes/vae.rs:194-201).
   int cv_ks, cv_h, cv_w, cv_cin, cv_up;
   const bf16_t* cv_zero;  // >= 128 B of zeros for padding taps
+  // Fused [q|k|v] relayout epilogue (optional, qk_qh != null; 256-wide N tiles only): output columns
+  // [0, 3*qk_D) are q | k | v of a fused projection, head h at columns h*128 of each part.  Instead of
+  // being stored to `out`, a q / k tile goes through QkNorm (RMS, eps 1e-6, weight qk_wq / qk_wk) + RoPE
+  // into the head-major (B,H,qk_Ltot,128) buffers and a v tile into the transposed, kv-permuted
+  // (B,H,128,qk_Lpad) layout the attention kernel reads — exactly what qk_norm_rope_kernel and
+  // v_transpose_kernel produce from the stored bf16 projection, minus two HBM round trips per layer.
+  // Rows m of this problem are tokens: batch m / qk_rows, position qk_row_off + m % qk_rows.
+  // Columns >= 3*qk_D (single-stream block: the MLP part) take the normal path.
+  bf16_t *qk_qh, *qk_kh, *qk_vt;
+  const bf16_t *qk_wq, *qk_wk;
+  const float* qk_pe;  // (B or 1, qk_Ltot, 64, {cos, sin}) f32
+  int64_t qk_pe_bstride;
+  int qk_H, qk_D, qk_rows, qk_row_off, qk_Ltot, qk_Lpad;
 };
 int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream);
 void set_gemm_pingpong(bool on);  // dense N>128 launches: ping-pong kernel (default) or the double-buffered one

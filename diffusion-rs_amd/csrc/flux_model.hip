@@ -89,6 +89,7 @@ struct fmi_flux {
   bf16_t* wscratch[2] = {nullptr, nullptr};
   size_t wscratch_elems = 0;
   int q_fused_max_rows = 512;  // M below this keeps the fused dequant-GEMM (weight-bandwidth-bound regime)
+  bool fuse_qkv_relayout = true;  // QkNorm + RoPE + head/transposed relayout in the QKV GEMM's epilogue
 };
 
 namespace {
@@ -296,6 +297,17 @@ GemmProblem make_problem(const Dense& d, const bf16_t* A, int lda, int Mrows, vo
   }
   return p;
 }
+// Fused relayout epilogue of a [q|k|v](|mlp) projection (GemmProblem::qk_*); returns false if this
+// shape must take the stand-alone kernels (positions not 16-aligned, model width not 256-aligned).
+bool with_qkv_relayout(fmi_flux* m, GemmProblem& p, const bf16_t* nq, const bf16_t* nk, int64_t pe_bs, int rows, int row_off, int Ltot) {
+  auto& w = m->ws;
+  if (!m->fuse_qkv_relayout || m->D % 256 || rows % 16 || row_off % 16 || p.M % 16 || p.N < 256) return false;
+  p.qk_qh = w.Qh, p.qk_kh = w.Kh, p.qk_vt = w.Vt;
+  p.qk_wq = nq, p.qk_wk = nk;
+  p.qk_pe = w.pe, p.qk_pe_bstride = pe_bs;
+  p.qk_H = m->H, p.qk_D = m->D, p.qk_rows = rows, p.qk_row_off = row_off, p.qk_Ltot = Ltot, p.qk_Lpad = w.Lpad;
+  return true;
+}
 void with_gate(GemmProblem& p, const float* gate, int rows_per_batch, int bstride) {
   p.gate = gate;
   p.rows_per_batch = rows_per_batch;
@@ -435,6 +447,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     const float* mt = mod + bw.mod_off[1];
     bf16_t* xm_txt = w.xm;
     bf16_t* xm_img = w.xm + (size_t)B * T * D;
+    bool fused_img = false, fused_txt = false;
     {
       PhaseTimer pt(m, s, PH_LN);
       FMI_TRY(launch_layernorm_mod(w.x_img, mi + D, mi, nmod, S, xm_img, B * S, D, 1e-6f, s));
@@ -445,15 +458,22 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       GemmProblem p[2];
       p[0] = make_problem(bw.qkv[0], xm_img, D, B * S, w.qkv_img, 3 * D, EPI_STORE_BF16);
       p[1] = make_problem(bw.qkv[1], xm_txt, D, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16);
+      // joint order [txt, img] (model.rs:540-542): txt tokens at positions [0,T), img at [T,T+S)
+      fused_img = with_qkv_relayout(m, p[0], bw.nq[0], bw.nk[0], pe_bs, S, T, L);
+      fused_txt = with_qkv_relayout(m, p[1], bw.nq[1], bw.nk[1], pe_bs, T, 0, L);
       FMI_TRY(gemm2(m, p, 2, s));
     }
-    {
+    if (!(fused_img && fused_txt)) {
       PhaseTimer pt(m, s, PH_RELAYOUT);
       // q,k: QkNorm + rope + head-major, joint order [txt, img] (model.rs:540-542)
-      FMI_TRY(launch_qk_norm_rope(w.qkv_txt, w.qkv_txt + D, 3 * D, (int64_t)T * 3 * D, bw.nq[1], bw.nk[1], w.pe, pe_bs, w.Qh, w.Kh, B, H, T, 0, L, s));
-      FMI_TRY(launch_qk_norm_rope(w.qkv_img, w.qkv_img + D, 3 * D, (int64_t)S * 3 * D, bw.nq[0], bw.nk[0], w.pe, pe_bs, w.Qh, w.Kh, B, H, S, T, L, s));
-      FMI_TRY(launch_v_transpose(w.qkv_txt + 2 * D, 3 * D, (int64_t)T * 3 * D, w.Vt, B, H, T, 0, w.Lpad, s));
-      FMI_TRY(launch_v_transpose(w.qkv_img + 2 * D, 3 * D, (int64_t)S * 3 * D, w.Vt, B, H, S, T, w.Lpad, s));
+      if (!fused_txt) {
+        FMI_TRY(launch_qk_norm_rope(w.qkv_txt, w.qkv_txt + D, 3 * D, (int64_t)T * 3 * D, bw.nq[1], bw.nk[1], w.pe, pe_bs, w.Qh, w.Kh, B, H, T, 0, L, s));
+        FMI_TRY(launch_v_transpose(w.qkv_txt + 2 * D, 3 * D, (int64_t)T * 3 * D, w.Vt, B, H, T, 0, w.Lpad, s));
+      }
+      if (!fused_img) {
+        FMI_TRY(launch_qk_norm_rope(w.qkv_img, w.qkv_img + D, 3 * D, (int64_t)S * 3 * D, bw.nq[0], bw.nk[0], w.pe, pe_bs, w.Qh, w.Kh, B, H, S, T, L, s));
+        FMI_TRY(launch_v_transpose(w.qkv_img + 2 * D, 3 * D, (int64_t)S * 3 * D, w.Vt, B, H, S, T, w.Lpad, s));
+      }
     }
     {
       PhaseTimer pt(m, s, PH_ATTN);
@@ -501,6 +521,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
   for (int i = 0; i < c.num_single_layers; ++i) {
     auto& bw = m->sgl[i];
     const float* mo = mod + bw.mod_off;  // shift, scale, gate
+    bool fused = false;
     {
       PhaseTimer pt(m, s, PH_LN);
       FMI_TRY(launch_layernorm_mod(w.x, mo + D, mo, nmod, L, w.xm, B * L, D, 1e-6f, s));
@@ -510,9 +531,10 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       // [q|k|v|gelu(proj_mlp)] in one GEMM; the concat of model.rs:660 is never materialised
       GemmProblem p = make_problem(bw.w1, w.xm, D, B * L, w.big, ldbig, EPI_GELU_FROM_COL);
       p.gelu_from = 3 * D;
+      fused = with_qkv_relayout(m, p, bw.nq, bw.nk, pe_bs, L, 0, L);
       FMI_TRY(gemm2(m, &p, 1, s));
     }
-    {
+    if (!fused) {
       PhaseTimer pt(m, s, PH_RELAYOUT);
       FMI_TRY(launch_qk_norm_rope(w.big, w.big + D, ldbig, (int64_t)L * ldbig, bw.nq, bw.nk, w.pe, pe_bs, w.Qh, w.Kh, B, H, L, 0, L, s));
       FMI_TRY(launch_v_transpose(w.big + 2 * D, ldbig, (int64_t)L * ldbig, w.Vt, B, H, L, 0, w.Lpad, s));
@@ -891,6 +913,12 @@ extern "C" const char* fmi_flux_phase_name(int i) { return (i >= 0 && i < PH_COU
 extern "C" int fmi_flux_phase_ms(fmi_flux* m, float* ms_out) {
   if (!m || !ms_out) return fail(FMI_ERR_INVALID, "null argument");
   for (int i = 0; i < PH_COUNT; ++i) ms_out[i] = m->phase_ms[i];
+  return FMI_OK;
+}
+// QkNorm + RoPE + head-major / transposed relayout fused into the QKV GEMM's epilogue (default) or as stand-alone kernels
+extern "C" int fmi_flux_set_fused_qkv_relayout(fmi_flux* m, int enable) {
+  if (!m) return fail(FMI_ERR_INVALID, "null handle");
+  m->fuse_qkv_relayout = enable != 0;
   return FMI_OK;
 }
 // 4-bit dispatch threshold (rows): below it the fused dequant-GEMM runs, at or above it dequant-once + dense

@@ -127,9 +127,137 @@ __device__ __forceinline__ void stage_tile_q4(const GemmProblem& P, int n0, int 
 // Shared epilogue.  Lane holds, for accumulator (i, j): row m = m0 + wm*128 + i*32 + (lane&31) and
 // columns n = n0 + wn*32*NJ + j*32 + 8q + 4(lane>>5) + {0..3} in registers 4q..4q+3.
 // `smem` (>= 8 * 8192*NJ bytes) is free for staging once every wave has passed the leading barrier.
+// Fused [q|k|v] relayout of one 256 x 256 tile (two heads of q, k or v); see GemmProblem::qk_*.
+// The arithmetic (bf16 rounding of the projection first, then f32 RMS / RoPE in the same operation
+// order, 16 lanes x 8 elements per head row) is that of qk_norm_rope_kernel, so both paths produce
+// the same bits.  Requires qk_rows, qk_row_off and M to be multiples of 16 (host-checked).
+__device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int wave, int lane) {
+  const int wm = wave >> 2, wn = wave & 3;
+  const int hl = lane >> 5, l31 = lane & 31;
+  const int part = n0 / P.qk_D;                     // 0 q, 1 k, 2 v
+  const int head0 = (n0 - part * P.qk_D) >> 7;      // first of the tile's two heads
+  auto biased = [&](int n, float (&v)[4]) {
+    if (P.bias) {
+      const uint2 b = *reinterpret_cast<const uint2*>(P.bias + n);
+      v[0] += bf16_to_f32((bf16_t)(b.x & 0xffff));
+      v[1] += bf16_to_f32((bf16_t)(b.x >> 16));
+      v[2] += bf16_to_f32((bf16_t)(b.y & 0xffff));
+      v[3] += bf16_to_f32((bf16_t)(b.y >> 16));
+    }
+  };
+  __syncthreads();  // every wave is done with the operand tiles
+  if (part < 2) {
+    // ---- stage the bf16 tile in the wave-private swizzled regions of the normal store path
+    char* cw = smem + wave * 16384;
+    const int ncol0 = n0 + wn * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+          biased(ncol0 + j * 32 + q * 8 + 4 * hl, v);
+          const int r = i * 32 + l31, c = j * 8 + q * 2 + hl;
+          *reinterpret_cast<uint2*>(cw + r * 128 + ((c ^ (r & 15)) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+    __syncthreads();
+    // ---- 512 (row, head) vectors of 128: 16 lanes x 8 elements each; this wave takes rows 32*wave .. +31
+    const int sub = lane & 15, grp = lane >> 4;
+    const bf16_t* wsel = part == 0 ? P.qk_wq : P.qk_wk;
+    bf16_t* osel = part == 0 ? P.qk_qh : P.qk_kh;
+    const uint4 wraw = *reinterpret_cast<const uint4*>(wsel + sub * 8);
+    const bf16_t* we = reinterpret_cast<const bf16_t*>(&wraw);
+#pragma unroll 2
+    for (int it = 0; it < 16; ++it) {
+      const int item = wave * 64 + it * 4 + grp;
+      const int r = item >> 1, hh = item & 1;
+      const int m = m0 + r;
+      // source: staging region of wave (r>>7, 2*hh + (sub>>3)), row r&127, 16 B = 8-B slots 2*(sub&7), +1
+      const int rr = r & 127;
+      const char* reg = smem + ((r >> 7) * 4 + 2 * hh + (sub >> 3)) * 16384 + rr * 128;
+      const int sp = ((2 * (sub & 7)) ^ (rr & 15)) & ~1;
+      uint4 raw = *reinterpret_cast<const uint4*>(reg + (sp << 3));
+      if (rr & 1) raw = make_uint4(raw.z, raw.w, raw.x, raw.y);  // odd rows hold the slot pair swapped
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw);
+      float v[8];
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] = bf16_to_f32(e[i]);
+        ss += v[i] * v[i];
+      }
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      ss += __shfl_xor(ss, 4, 64);
+      ss += __shfl_xor(ss, 8, 64);
+      if (m < P.M) {
+        const int b = m / P.qk_rows, pos = P.qk_row_off + (m - b * P.qk_rows);
+        const float4* pp = reinterpret_cast<const float4*>(P.qk_pe + (int64_t)b * P.qk_pe_bstride + ((int64_t)pos * 64 + 4 * sub) * 2);
+        const float4 c01 = pp[0], c23 = pp[1];
+        const float cs[4] = {c01.x, c01.z, c23.x, c23.z};
+        const float sn[4] = {c01.y, c01.w, c23.y, c23.w};
+        const float inv = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+        uint32_t o[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float x0 = v[2 * p] * inv * bf16_to_f32(we[2 * p]);
+          const float x1 = v[2 * p + 1] * inv * bf16_to_f32(we[2 * p + 1]);
+          o[p] = pack_bf16x2(cs[p] * x0 - sn[p] * x1, sn[p] * x0 + cs[p] * x1);
+        }
+        bf16_t* dst = osel + (((int64_t)b * P.qk_H + head0 + hh) * P.qk_Ltot + pos) * 128 + sub * 8;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  } else {
+    // ---- v: stage TRANSPOSED, [d column 0..255][tile-local token 0..255] bf16 (512-B rows), with the
+    // attention kernel's kv permutation (swap bits 2,3 inside groups of 16) applied to the token
+    // index on the way in, so that a row leaves as plain 16-B pieces of consecutive stored positions
+    bf16_t* tp = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tl = wm * 128 + i * 32 + l31;
+      const int tpos = (tl & ~12) | ((tl & 4) << 1) | ((tl & 8) >> 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+          const int dc = wn * 64 + j * 32 + q * 8 + 4 * hl;
+          biased(n0 + dc, v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tp[(dc + e) * 256 + tpos] = f32_to_bf16(v[e]);
+        }
+    }
+    __syncthreads();
+    const int g8 = lane & 31;  // 8 stored positions (16 B) of a row per lane
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int dc = wave * 32 + it * 2 + hl;
+      const int m16 = m0 + 16 * (g8 >> 1);  // the 16 tokens this piece's group comes from
+      if (m16 < P.M) {
+        const uint4 x = *reinterpret_cast<const uint4*>(tp + dc * 256 + g8 * 8);
+        const int b = m16 / P.qk_rows, kv16 = P.qk_row_off + (m16 - b * P.qk_rows);
+        bf16_t* dst = P.qk_vt + (((int64_t)b * P.qk_H + head0 + (dc >> 7)) * 128 + (dc & 127)) * P.qk_Lpad + kv16 + (g8 & 1) * 8;
+        *reinterpret_cast<uint4*>(dst) = x;
+      }
+    }
+  }
+}
+
 template <int NJ>
 __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc)[4][NJ], char* smem, int m0, int n0, int wave, int lane) {
   constexpr int BN = 128 * NJ;
+  if constexpr (NJ == 2) {
+    if (P.qk_qh != nullptr && n0 < 3 * P.qk_D) {
+      qkv_relayout_epilogue(P, acc, smem, m0, n0, wave, lane);
+      return;
+    }
+  }
   const int wm = wave >> 2, wn = wave & 3;
   // ---- epilogue: lane holds row m = ..+(lane&31), columns n = ..+8q+4(lane>>5)+{0..3}
   const int epi = P.epi;
@@ -714,6 +842,11 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
     if ((!conv && p.lda % 8) || (!quant && p.ldw % 8)) return fail(FMI_ERR_INVALID, "launch_gemm: lda/ldw must be multiples of 8 elements (16-byte rows)");
     if (conv && (p.cv_cin % 64 || p.K != p.cv_ks * p.cv_ks * p.cv_cin || !p.cv_zero)) return fail(FMI_ERR_INVALID, "launch_gemm: bad conv descriptor (Cin % 64, K = k*k*Cin)");
     if (quant && (p.q_blocksize % 64 != 0 || p.q_blocksize <= 0)) return fail(FMI_ERR_INVALID, "launch_gemm: 4-bit blocksize must be a multiple of 64");
+    if (p.qk_qh) {
+      if (conv || bn != 256 || p.qk_D % 256 || p.qk_H * 128 != p.qk_D || 3 * p.qk_D > p.N || p.qk_rows <= 0 || p.qk_rows % 16 || p.qk_row_off % 16 || p.M % 16 ||
+          p.qk_Lpad % 64 || !p.qk_kh || !p.qk_vt || !p.qk_wq || !p.qk_wk || !p.qk_pe || (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 7)))
+        return fail(FMI_ERR_INVALID, "launch_gemm: bad fused qkv relayout descriptor (needs 256-wide tiles, D % 256 == 0, rows/row_off/M % 16 == 0)");
+    }
     b.p[i] = p;
     b.tile_start[i] = total;
     total += cdiv(p.M, BM) * cdiv(p.N, bn);

@@ -166,6 +166,12 @@ int fmi_flux_denoise(fmi_flux*, const fmi_flux_inputs* in, float* img_inout,
 /* Per-phase device time of the last forward in ms (hipEvents; enabled by
  * fmi_flux_set_profiling(1), which also serialises phases).  Phases: see fmi_flux_phase_name. */
 int fmi_flux_set_profiling(fmi_flux*, int enable);
+/* Tuning / verification knob (default 1): QkNorm (model.rs:433-452) + apply_rope (:77-101) + the
+ * head-major q,k and transposed v relayout run in the epilogue of the [q|k|v] projection GEMM
+ * instead of as stand-alone kernels over the stored projection.  Both forms use the same arithmetic
+ * and give bit-identical results; shapes whose token offsets are not multiples of 16 always take the
+ * stand-alone kernels. */
+int fmi_flux_set_fused_qkv_relayout(fmi_flux*, int enable);
 int fmi_flux_phase_count(void);
 const char* fmi_flux_phase_name(int i);
 int fmi_flux_phase_ms(fmi_flux*, float* ms_out /* [phase_count] */);

@@ -150,3 +150,25 @@ def test_flux_int8_scb_blocks_match_dequantised_oracle(models, tmp_path):
     err = rel_l2(got, ref)
     print(f"int8 (SCB) forward, {nq} quantised linears: rel-L2 {err:.3e}")
     assert err <= 1e-2
+
+
+@pytest.mark.parametrize("B,S_hw,T", [(2, (8, 8), 32), (1, (8, 12), 40), (1, (16, 16), 48)])
+def test_fused_qkv_relayout_is_bit_identical(models, B, S_hw, T):
+    """QkNorm + RoPE + head-major / transposed relayout fused into the QKV GEMM epilogue (default) vs the stand-alone
+    kernels over the stored projection: same arithmetic, bit-identical prediction.  (8,12)/T=40: the text stream's
+    offsets are not multiples of 16, so it stays on the kernels while the image stream is fused."""
+    torch, gm = models["torch"], models["gm"]
+    from diffusion_rs_amd import _lib as L
+    lib = L.load()
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, B, S_hw, T, seed=17)
+    t = np.linspace(0.9, 0.5, B).astype(np.float32)
+    g = np.full(B, 3.5, np.float32)
+    args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
+    try:
+        L.check(lib.fmi_flux_set_fused_qkv_relayout(gm.h, 0))
+        plain = host(gm.forward(*args))
+        L.check(lib.fmi_flux_set_fused_qkv_relayout(gm.h, 1))
+        fused = host(gm.forward(*args))
+    finally:
+        L.check(lib.fmi_flux_set_fused_qkv_relayout(gm.h, 1))
+    np.testing.assert_array_equal(fused, plain)
