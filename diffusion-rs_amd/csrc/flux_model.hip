@@ -90,6 +90,11 @@ struct fmi_flux {
   size_t wscratch_elems = 0;
   int q_fused_max_rows = 512;  // M below this keeps the fused dequant-GEMM (weight-bandwidth-bound regime)
   bool fuse_qkv_relayout = true;  // QkNorm + RoPE + head/transposed relayout in the QKV GEMM's epilogue
+  // Quantised block linears at large M: expanded ONCE into the layer's own slot of the bf16 arena (which
+  // is laid out for the whole dense model anyway) and reused by every later step, instead of once per GEMM
+  // call into the scratch (28 GB of traffic per denoise step for an nf4 FLUX.1-dev).
+  bool dense_cache = true;
+  std::set<const void*> dense_ready;
 };
 
 namespace {
@@ -324,6 +329,21 @@ int densify(fmi_flux* m, GemmProblem* p, int n, hipStream_t s) {
     // q_type 3 = LLM.int8 (SCB): no fused kernel, always expanded (BnbLinear::Int8 forward, mod.rs:293-300)
     if (!p[i].q_type || (p[i].q_type != 3 && p[i].M < m->q_fused_max_rows)) continue;
     const size_t elems = (size_t)p[i].N * p[i].K;
+    if (m->dense_cache && p[i].W && p[i].ldw == p[i].K) {
+      bf16_t* slot = const_cast<bf16_t*>(p[i].W);
+      if (!m->dense_ready.count(slot)) {
+        if (elems >= (1ull << 31)) return fail(FMI_ERR_UNSUPPORTED, "densify: weight too large");
+        if (p[i].q_type == 3)
+          FMI_TRY(launch_dequant_int8_scb_bf16(reinterpret_cast<const int8_t*>(p[i].Wq), p[i].absmax, slot, p[i].K, (int64_t)elems, s));
+        else if (p[i].q_type == 2)
+          dequantize_blockwise_bf16_nf4(nullptr, p[i].Wq, p[i].absmax, slot, p[i].q_blocksize, (int)elems, s);
+        else
+          dequantize_blockwise_bf16_fp4(nullptr, p[i].Wq, p[i].absmax, slot, p[i].q_blocksize, (int)elems, s);
+        m->dense_ready.insert(slot);
+      }
+      p[i].Wq = nullptr, p[i].absmax = nullptr, p[i].q_type = 0, p[i].q_blocksize = 0;
+      continue;
+    }
     if (elems > m->wscratch_elems || !m->wscratch[0]) {
       const size_t want = std::max(elems, (size_t)(3 * m->D + m->M) * (size_t)m->D);  // largest fused weight of the model
       FMI_HIP_TRY(hipDeviceSynchronize());
@@ -779,6 +799,7 @@ extern "C" int fmi_flux_set_linear_bnb4(fmi_flux* m, const char* prefix, const u
   }
   d->q_type = quant_type;
   d->q_blocksize = blocksize;
+  m->dense_ready.erase(d->w);
   const size_t n = (size_t)out_features * in_features;
   FMI_HIP_TRY(hipMemcpy(d->wq + (size_t)row0 * d->K / 2, packed, n / 2, hipMemcpyDefault));
   FMI_HIP_TRY(hipMemcpy(d->absmax + (size_t)row0 * d->K / blocksize, absmax, n / blocksize * 4, hipMemcpyDefault));
@@ -824,6 +845,7 @@ extern "C" int fmi_flux_set_linear_int8(fmi_flux* m, const char* prefix, const i
   }
   d->q_type = 3;
   d->q_blocksize = 0;
+  m->dense_ready.erase(d->w);
   FMI_HIP_TRY(hipMemcpy(d->wq + (size_t)row0 * d->K, weight, n, hipMemcpyDefault));
   FMI_HIP_TRY(hipMemcpy(d->absmax + row0, scb, (size_t)out_features * 4, hipMemcpyDefault));
   m->missing.erase(wname);
@@ -919,6 +941,13 @@ extern "C" int fmi_flux_phase_ms(fmi_flux* m, float* ms_out) {
 extern "C" int fmi_flux_set_fused_qkv_relayout(fmi_flux* m, int enable) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
   m->fuse_qkv_relayout = enable != 0;
+  return FMI_OK;
+}
+// keep (1, default) or drop (0: per-call scratch expansion) the expanded bf16 copies of quantised block linears
+extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int enable) {
+  if (!m) return fail(FMI_ERR_INVALID, "null handle");
+  m->dense_cache = enable != 0;
+  m->dense_ready.clear();
   return FMI_OK;
 }
 // 4-bit dispatch threshold (rows): below it the fused dequant-GEMM runs, at or above it dequant-once + dense

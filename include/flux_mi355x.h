@@ -122,6 +122,12 @@ int fmi_flux_set_linear_bnb4(fmi_flux*, const char* prefix, const uint8_t* packe
  * major + SCB f32 (out); effective weight = w * SCB[row] / 127 (dequant.cu:205-214), expanded to
  * bf16 right before the layer's GEMM.  Same prefix rules as fmi_flux_set_linear_bnb4. */
 int fmi_flux_set_linear_int8(fmi_flux*, const char* prefix, const int8_t* weight, const float* scb, int out_features, int in_features);
+/* Quantised (nf4/fp4/int8) block linears in the MFMA-bound regime (rows >= 512): 1 (default) = each
+ * layer is expanded once into its slot of the bf16 weight arena on first use and reused afterwards
+ * (BnbLinear::forward's dequantize-then-matmul, bitsandbytes/mod.rs:301-312, amortised over the denoise
+ * loop); 0 = expanded into a scratch before every GEMM call.  Small-row calls always use the fused
+ * dequant-GEMM on the packed weights. */
+int fmi_flux_set_quant_dense_cache(fmi_flux*, int enable);
 int fmi_flux_missing_count(const fmi_flux*);
 const char* fmi_flux_missing_name(const fmi_flux*, int i);
 /* Bytes of HBM held by the model (weights + current workspace). */

@@ -115,6 +115,21 @@ def test_flux_nf4_blocks_match_dequantised_oracle(models):
     assert err2 <= 1e-2
     # both paths multiply the same bf16 weights: they agree far below the oracle tolerance
     assert rel_l2(got2, got) <= 2e-3
+    # the expanded copies are cached in the arena (default) — a second call reuses them; the per-call scratch form agrees bit for bit
+    got3 = host(gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
+    np.testing.assert_array_equal(got3, got2)
+    L.check(L.load().fmi_flux_set_quant_dense_cache(gq.h, 0))
+    got4 = host(gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
+    np.testing.assert_array_equal(got4, got2)
+    # re-setting a quantised linear invalidates its cached copy
+    L.check(L.load().fmi_flux_set_quant_dense_cache(gq.h, 1))
+    gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
+    name = next(n for n in sd if n.endswith("ff.net.2.weight"))
+    w = sd[name]
+    packed, absmax = orc.quantize_blockwise_4bit((2.0 * w).ravel(), 64, "nf4")
+    gq.set_linear_bnb4(name[:-len(".weight")], packed, absmax, 64, "nf4", w.shape[0], w.shape[1])
+    got5 = host(gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
+    assert not np.array_equal(got5, got2)
 
 
 def test_flux_int8_scb_blocks_match_dequantised_oracle(models, tmp_path):
