@@ -258,3 +258,35 @@ def test_conv2d_nhwc(env, Cin, Cout, H, W, ks, up, resid):
     got = host(out).transpose(0, 3, 1, 2)
     assert np.isfinite(got).all()
     assert rel_l2(got, ref) <= 4e-3
+
+
+def test_empty_and_null_inputs_fail_cleanly(env):
+    """Empty / null inputs return a negative fmi_status with a message (no crash, no launch): the C-ABI's
+    equivalent of candle's shape errors.  Zero-length dequant is a no-op, like the CUDA launcher (grid 0)."""
+    torch, L, lib, d = env["torch"], env["L"], env["lib"], env["d"]
+    x = torch.zeros((64, 64), dtype=torch.bfloat16, device="cuda")
+    assert lib.fmi_linear_bf16(_p(x), _p(x), None, _p(x), 0, 64, 64, 0, None) == 0  # zero rows: an empty result, nothing launched
+    assert lib.fmi_linear_bf16(None, _p(x), None, _p(x), 64, 64, 64, 0, None) < 0
+    q = torch.zeros((1, 1, 64, 128), dtype=torch.bfloat16, device="cuda")
+    assert lib.fmi_sdpa_bf16(_p(q), _p(q), _p(q), _p(q), 1, 1, 0, 64, 128, C.c_float(1.0), 0, None) < 0
+    assert lib.fmi_sdpa_bf16(_p(q), _p(q), _p(q), _p(q), 1, 1, 64, 64, 64, C.c_float(1.0), 0, None) < 0  # head dim != 128
+    out = torch.full((4,), 7.0, dtype=torch.float32, device="cuda")
+    a = torch.zeros((4,), dtype=torch.uint8, device="cuda")
+    am = torch.ones((1,), dtype=torch.float32, device="cuda")
+    lib.dequantize_blockwise_f32_nf4(None, _p(a), _p(am), _p(out), 64, 0, None)
+    torch.cuda.synchronize()
+    assert float(out.sum()) == 28.0  # untouched
+    from tests.util import SMALL_FLUX, SMALL_VAE
+    fm = d.FluxModel(SMALL_FLUX)
+    with pytest.raises(d.FmiError):  # weights not loaded
+        z = torch.zeros((1, 4, 64), device="cuda")
+        fm.forward(z, torch.zeros((1, 4, 3), device="cuda"), torch.zeros((1, 4, SMALL_FLUX["joint_attention_dim"]), dtype=torch.bfloat16, device="cuda"),
+                   torch.zeros((1, 4, 3), device="cuda"), torch.ones(1, device="cuda"), torch.zeros((1, SMALL_FLUX["pooled_projection_dim"]), device="cuda"),
+                   torch.ones(1, device="cuda"))
+    with pytest.raises(d.FmiError):
+        fm.set_tensor("no.such.tensor", torch.zeros(3))
+    with pytest.raises(d.FmiError):
+        fm.set_tensor("x_embedder.weight", torch.zeros((3, 3)))  # wrong shape
+    va = d.AutoEncoderKl(SMALL_VAE)
+    with pytest.raises(d.FmiError):
+        va.decode(torch.zeros((1, 16, 4, 4), device="cuda"))  # decoder weights missing
