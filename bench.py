@@ -304,7 +304,7 @@ def main():
         out = {
             "metric": "images/sec, FLUX.1-dev 1024x1024 50-step" if (H, W, NS) == (1024, 1024, 50) else f"images/sec, FLUX.1-dev {W}x{H} {NS}-step",
             "value": total_images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.quant == "none" else "bf16 (nf4 weights, fused dequant-GEMM)",
+            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.quant == "none" else "bf16 (nf4 weights, expanded to bf16 once per layer on first use)",
             "data": "synthetic (random-init FLUX.1-dev + FLUX VAE weights, N(0,1) embeddings, Philox latents)",
             "config": {"workload": f"FLUX.1-dev bf16 {W}x{H} {NS}-step, batch=1 per GPU, S={S} img + T={T} txt tokens, step = one image "
                                    "(50x Flux::forward + Euler, unpack, VAE decode, u8)",
@@ -317,6 +317,7 @@ def main():
         out.update(extra)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # rank 0 ran the (untimed) profiled pass meanwhile: leave together
         dist.destroy_process_group()
 
 
