@@ -100,10 +100,14 @@ def main():
         print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # debugging aid for boxes with fewer GPUs than ranks: FMI_BENCH_BACKEND=gloo lets several ranks share device 0
+    backend = os.environ.get("FMI_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     import diffusion_rs_amd as d
     from diffusion_rs_amd import _lib as L
