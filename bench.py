@@ -83,7 +83,9 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--txt-tokens", type=int, default=512)
-    ap.add_argument("--quant", choices=["none", "nf4"], default="none", help="nf4: block linears stored bitsandbytes-nf4, fused dequant-GEMM (config C3)")
+    ap.add_argument("--quant", choices=["none", "nf4", "fp8"], default="none",
+                    help="nf4: block linears stored bitsandbytes-nf4, fused dequant-GEMM (config C3); fp8: block linears on the e4m3 MFMA path (config C5)")
+    ap.add_argument("--batch", type=int, default=1, help="samples per GPU per image step (C5: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--cpu-baseline-tokens", type=int, default=0, help="override L of the CPU sample (debug)")
@@ -142,6 +144,8 @@ def main():
             flux.set_tensor(name, t)
         del t
     flux.assert_complete()
+    if args.quant == "fp8":
+        flux.quantize_fp8()
     if world > 1:
         vsd = {}
         for name, shape in synth.vae_tensor_shapes(d.VAE_FLUX).items():
@@ -163,7 +167,7 @@ def main():
     H, W, NS, T = args.height, args.width, args.denoise_steps, args.txt_tokens
     h, w = (H + 15) // 16 * 2, (W + 15) // 16 * 2
     S = (h // 2) * (w // 2)
-    B = 1
+    B = args.batch
     gi = torch.Generator(device=dev)
     gi.manual_seed(1234 + rank)
     txt = torch.randn((B, T, 4096), generator=gi, device=dev, dtype=torch.float32).to(torch.bfloat16)
@@ -174,7 +178,7 @@ def main():
     timesteps = sched.get_timesteps(NS, sched.calculate_shift(S))
 
     def one_image(i):
-        lat = d.randn_latents(B, 16, h, w, seed=1234, first_sample=rank + world * i, device=dev)
+        lat = d.randn_latents(B, 16, h, w, seed=1234, first_sample=(rank + world * i) * B, device=dev)
         img, img_ids = d.pack_latents(lat)
         img = flux.denoise(img, img_ids, txt, txt_ids, y, guidance, timesteps)
         z = d.unpack_latents(img, 16, h, w, vae.scale_factor(), vae.shift_factor())
@@ -228,8 +232,13 @@ def main():
                 traffic = json.load(f).get("traffic_bytes_per_launch")
         except Exception:
             pass
-        roof = {"bound": "mfma", "kernel": "gemm_pp_kernel (bf16 MFMA GEMM, all block linears)", "achieved": round(ach, 1), "peak": 2500.0,
-                "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
+        fp8 = args.quant == "fp8"
+        peak = 5000.0 if fp8 else 2500.0
+        if fp8:
+            traffic = None  # the PMC summary on file is the bf16 kernel's
+        roof = {"bound": "mfma", "kernel": "gemm_pp_kernel<fp8> (e4m3 MFMA GEMM, all block linears)" if fp8 else "gemm_pp_kernel (bf16 MFMA GEMM, all block linears)",
+                "achieved": round(ach, 1), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "peak_note": "2500 = dense bf16 MFMA peak at 2.4 GHz; a register-only MFMA loop (tools/mfma_peak.hip) sustains 2020 on this part (power cap, ~1.95 GHz)",
                 "traffic_note": "HBM-side bytes per launch = FETCH_SIZE*2 + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/), not re-measured in this run",
                 "launches_per_step": gemm_launches, "avg_launch_ms": round(gemm_ms / gemm_launches, 4),
@@ -308,9 +317,10 @@ def main():
         out = {
             "metric": "images/sec, FLUX.1-dev 1024x1024 50-step" if (H, W, NS) == (1024, 1024, 50) else f"images/sec, FLUX.1-dev {W}x{H} {NS}-step",
             "value": total_images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.quant == "none" else "bf16 (nf4 weights, expanded to bf16 once per layer on first use)",
+            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"none": "bf16", "nf4": "bf16 (nf4 weights, expanded to bf16 once per layer on first use)",
+                                                                                                                 "fp8": "fp8 e4m3 block linears (per-channel weight / per-token activation scales, f32 accumulate), bf16 attention, f32 residual stream"}[args.quant],
             "data": "synthetic (random-init FLUX.1-dev + FLUX VAE weights, N(0,1) embeddings, Philox latents)",
-            "config": {"workload": f"FLUX.1-dev bf16 {W}x{H} {NS}-step, batch=1 per GPU, S={S} img + T={T} txt tokens, step = one image "
+            "config": {"workload": f"FLUX.1-dev {'fp8' if args.quant == 'fp8' else 'bf16'} {W}x{H} {NS}-step, batch={B} per GPU, S={S} img + T={T} txt tokens, step = one image "
                                    "(50x Flux::forward + Euler, unpack, VAE decode, u8)",
                        "global_batch": world * B, "parallelism": f"batch-sharded x{world}" if world > 1 else "single GPU"},
             "ms_per_denoise_step": round((ms_per_image - extra.get("vae_decode_ms", 0.0)) / NS, 2),

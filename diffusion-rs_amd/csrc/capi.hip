@@ -145,6 +145,34 @@ extern "C" int fmi_linear_bnb4_bf16(const void* x, const uint8_t* packed, const 
   return launch_gemm(&p, 1, (hipStream_t)stream);
 }
 
+extern "C" int fmi_quantize_rows_fp8(const void* x, int rows, int K, uint8_t* out, float* scale, void* stream) {
+  if (rows == 0) return FMI_OK;
+  if (!x || !out || !scale) return fail(FMI_ERR_INVALID, "quantize_rows_fp8: null pointer");
+  return launch_quantize_rows_fp8((const bf16_t*)x, K, rows, K, out, scale, (hipStream_t)stream);
+}
+
+extern "C" int fmi_linear_fp8(const void* x, const uint8_t* wq, const float* w_scale, const void* bias, void* y, int M, int N, int K,
+                              fmi_epilogue epi, void* stream) {
+  if (!x || !wq || !w_scale || !y) return fail(FMI_ERR_INVALID, "linear_fp8: null pointer");
+  if (M == 0 || N == 0) return FMI_OK;
+  if (N % 4 || N <= 128) return fail(FMI_ERR_INVALID, "linear_fp8: N must be a multiple of 4 and > 128");
+  hipStream_t s = (hipStream_t)stream;
+  uint8_t* xq = nullptr;
+  FMI_HIP_TRY(hipMalloc((void**)&xq, (size_t)M * K + (size_t)M * 4 + 256));
+  float* xs = reinterpret_cast<float*>(xq + ((size_t)M * K + 255) / 256 * 256);
+  int rc = launch_quantize_rows_fp8((const bf16_t*)x, K, M, K, xq, xs, s);
+  if (rc == FMI_OK) {
+    GemmProblem p{};
+    p.A = (const bf16_t*)xq, p.W = (const bf16_t*)wq, p.bias = (const bf16_t*)bias, p.out = y;
+    p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldo = N, p.epi = epi_of(epi), p.alpha = 1.f;
+    p.fp8 = 1, p.a_scale = xs, p.w_scale = w_scale;
+    rc = launch_gemm(&p, 1, s);
+  }
+  hipStreamSynchronize(s);
+  hipFree(xq);
+  return rc;
+}
+
 extern "C" int fmi_sdpa_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int d, float scale,
                              int out_token_major, void* stream) {
   if (!q || !k || !v || !o) return fail(FMI_ERR_INVALID, "sdpa_bf16: null pointer");

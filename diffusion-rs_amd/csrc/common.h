@@ -154,6 +154,12 @@ struct GemmProblem {
   const float* qk_pe;  // (B or 1, qk_Ltot, 64, {cos, sin}) f32
   int64_t qk_pe_bstride;
   int qk_H, qk_D, qk_rows, qk_row_off, qk_Ltot, qk_Lpad;
+  // fp8 operands (optional, fp8 != 0; dense 256-wide N tiles only): A and W point to OCP e4m3 bytes,
+  // K / lda / ldw count elements (= bytes, K % 128 == 0), and the f32 accumulator is multiplied by
+  // a_scale[m] * w_scale[n] (per-token / per-output-channel dequantisation) before the epilogue.
+  int fp8;
+  const float* a_scale;
+  const float* w_scale;
 };
 int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream);
 void set_gemm_pingpong(bool on);  // dense N>128 launches: ping-pong kernel (default) or the double-buffered one
@@ -194,6 +200,12 @@ int launch_rope_table(const float* txt_ids, const float* img_ids, int B, int T, 
 int launch_layernorm_mod(const float* x, const float* scale, const float* shift, int mod_bstride,
                          int rows_per_batch, bf16_t* out, int rows, int D, float eps, hipStream_t stream);
 // y(M,N) f32 (+)= act_in(x(M,K) f32) W(N,K)^T bf16 + bias bf16 ; M <= 8
+// fp8 path (fp8.hip).  Row-wise dynamic quantisation: scale[r] = max(absmax(x[r,:]), 1e-30) / 448,
+// out[r,k] = e4m3_rne(x[r,k] * (448 / max(absmax, 1e-30))); x bf16 with row stride ld, out (rows, K) dense.
+int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* out, float* scale, hipStream_t stream);
+// launch_layernorm_mod with the row quantisation fused (values quantised from f32, not via bf16)
+int launch_layernorm_mod_fp8(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch,
+                             uint8_t* out, float* out_scale, int rows, int D, float eps, hipStream_t stream);
 int launch_gemv(const float* x, const bf16_t* W, const bf16_t* bias, float* y, int M, int N, int K,
                 int silu_in, int accumulate, hipStream_t stream);
 // bf16 out = w_i8 * SCB[row] / 127 (dequant.cu:205-214) on `stream`

@@ -27,6 +27,9 @@ struct Dense {  // one (possibly fused) Linear: W (N,K) bf16 row-major, bias (N)
   uint8_t* wq = nullptr;
   float* absmax = nullptr;
   int q_type = 0, q_blocksize = 0;
+  // optional fp8 form (fmi_flux_quantize_fp8): e4m3 (N,K) + per-output-channel f32 scale, used instead of w
+  uint8_t* w8 = nullptr;
+  float* w8_scale = nullptr;
 };
 
 struct Dest {  // where a named tensor lands
@@ -75,6 +78,8 @@ struct fmi_flux {
     size_t bytes = 0;
     float *x_img, *x_txt, *x, *vec, *mod, *temb, *h1, *yf, *pe, *img_f32, *pred_tmp, *tv;
     bf16_t *img_bf, *txt_bf, *xm, *qkv_img, *qkv_txt, *big, *Qh, *Kh, *Vt, *attn_img, *attn_txt, *hid;
+    uint8_t* a8 = nullptr;  // fp8 mode: the current GEMM input, rows [txt | img], (B*L, <= D+M) e4m3
+    float* a8s = nullptr;   //           its per-token scales (B*L)
     int Lpad = 0;
   } ws;
   // profiling
@@ -95,6 +100,10 @@ struct fmi_flux {
   // call into the scratch (28 GB of traffic per denoise step for an nf4 FLUX.1-dev).
   bool dense_cache = true;
   std::set<const void*> dense_ready;
+  // fp8 mode (fmi_flux_quantize_fp8)
+  bool fp8 = false;
+  char* fp8_arena = nullptr;
+  size_t fp8_bytes = 0;
 };
 
 namespace {
@@ -266,6 +275,10 @@ int ensure_workspace(fmi_flux* m, int B, int S, int T) {
   add((void**)&w.attn_img, (size_t)B * S * D * 2);
   add((void**)&w.attn_txt, (size_t)B * T * D * 2);
   add((void**)&w.hid, (size_t)B * L * M * 2);
+  if (m->fp8) {
+    add((void**)&w.a8, (size_t)B * L * (D + M));
+    add((void**)&w.a8s, (size_t)B * L * 4);
+  }
   const size_t total = align_up(off, 256);
   if (w.base) {
     FMI_HIP_TRY(hipDeviceSynchronize());
@@ -280,6 +293,22 @@ int ensure_workspace(fmi_flux* m, int B, int S, int T) {
   return FMI_OK;
 }
 
+// fp8 mode: the block linear `d` on a quantised input (rows of a8 / a8s starting at `row0`, row length d.K)
+GemmProblem make_problem_fp8(const fmi_flux* m, const Dense& d, int row0, int Mrows, void* out, int ldo, int epi) {
+  GemmProblem p{};
+  p.A = reinterpret_cast<const bf16_t*>(m->ws.a8 + (size_t)row0 * d.K);
+  p.W = reinterpret_cast<const bf16_t*>(d.w8);
+  p.bias = d.b;
+  p.out = out;
+  p.M = Mrows, p.N = d.N, p.K = d.K;
+  p.lda = d.K, p.ldw = d.K, p.ldo = ldo;
+  p.epi = epi;
+  p.alpha = 1.0f;
+  p.fp8 = 1;
+  p.a_scale = m->ws.a8s + row0;
+  p.w_scale = d.w8_scale;
+  return p;
+}
 GemmProblem make_problem(const Dense& d, const bf16_t* A, int lda, int Mrows, void* out, int ldo, int epi) {
   GemmProblem p{};
   p.A = A;
@@ -442,6 +471,8 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
   const int nmod = (int)m->n_mod;
   const int64_t pe_bs = in->ids_per_sample ? (int64_t)L * 128 : 0;
   const float att_scale = 1.0f / sqrtf(128.0f);
+  const bool fp8 = m->fp8;
+  const int BT = B * T;  // a8 / a8s rows: [txt (B*T) | img (B*S)]
 
   {
     PhaseTimer pt(m, s, PH_EMBED);
@@ -470,14 +501,21 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     bool fused_img = false, fused_txt = false;
     {
       PhaseTimer pt(m, s, PH_LN);
-      FMI_TRY(launch_layernorm_mod(w.x_img, mi + D, mi, nmod, S, xm_img, B * S, D, 1e-6f, s));
-      FMI_TRY(launch_layernorm_mod(w.x_txt, mt + D, mt, nmod, T, xm_txt, B * T, D, 1e-6f, s));
+      if (fp8) {
+        FMI_TRY(launch_layernorm_mod_fp8(w.x_img, mi + D, mi, nmod, S, w.a8 + (size_t)BT * D, w.a8s + BT, B * S, D, 1e-6f, s));
+        FMI_TRY(launch_layernorm_mod_fp8(w.x_txt, mt + D, mt, nmod, T, w.a8, w.a8s, B * T, D, 1e-6f, s));
+      } else {
+        FMI_TRY(launch_layernorm_mod(w.x_img, mi + D, mi, nmod, S, xm_img, B * S, D, 1e-6f, s));
+        FMI_TRY(launch_layernorm_mod(w.x_txt, mt + D, mt, nmod, T, xm_txt, B * T, D, 1e-6f, s));
+      }
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_QKV);
       GemmProblem p[2];
-      p[0] = make_problem(bw.qkv[0], xm_img, D, B * S, w.qkv_img, 3 * D, EPI_STORE_BF16);
-      p[1] = make_problem(bw.qkv[1], xm_txt, D, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16);
+      p[0] = fp8 ? make_problem_fp8(m, bw.qkv[0], BT, B * S, w.qkv_img, 3 * D, EPI_STORE_BF16)
+                 : make_problem(bw.qkv[0], xm_img, D, B * S, w.qkv_img, 3 * D, EPI_STORE_BF16);
+      p[1] = fp8 ? make_problem_fp8(m, bw.qkv[1], 0, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16)
+                 : make_problem(bw.qkv[1], xm_txt, D, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16);
       // joint order [txt, img] (model.rs:540-542): txt tokens at positions [0,T), img at [T,T+S)
       fused_img = with_qkv_relayout(m, p[0], bw.nq[0], bw.nk[0], pe_bs, S, T, L);
       fused_txt = with_qkv_relayout(m, p[1], bw.nq[1], bw.nk[1], pe_bs, T, 0, L);
@@ -505,28 +543,44 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
       GemmProblem p[2];
-      p[0] = make_problem(bw.proj[0], w.attn_img, D, B * S, w.x_img, D, EPI_RESID_GATE_F32);
+      if (fp8) {
+        FMI_TRY(launch_quantize_rows_fp8(w.attn_img, D, B * S, D, w.a8 + (size_t)BT * D, w.a8s + BT, s));
+        FMI_TRY(launch_quantize_rows_fp8(w.attn_txt, D, B * T, D, w.a8, w.a8s, s));
+      }
+      p[0] = fp8 ? make_problem_fp8(m, bw.proj[0], BT, B * S, w.x_img, D, EPI_RESID_GATE_F32)
+                 : make_problem(bw.proj[0], w.attn_img, D, B * S, w.x_img, D, EPI_RESID_GATE_F32);
       with_gate(p[0], mi + 2 * D, S, nmod);
-      p[1] = make_problem(bw.proj[1], w.attn_txt, D, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
+      p[1] = fp8 ? make_problem_fp8(m, bw.proj[1], 0, B * T, w.x_txt, D, EPI_RESID_GATE_F32)
+                 : make_problem(bw.proj[1], w.attn_txt, D, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
       with_gate(p[1], mt + 2 * D, T, nmod);
       FMI_TRY(gemm2(m, p, 2, s));
     }
     {
       PhaseTimer pt(m, s, PH_LN);
-      FMI_TRY(launch_layernorm_mod(w.x_img, mi + 4 * D, mi + 3 * D, nmod, S, xm_img, B * S, D, 1e-6f, s));
-      FMI_TRY(launch_layernorm_mod(w.x_txt, mt + 4 * D, mt + 3 * D, nmod, T, xm_txt, B * T, D, 1e-6f, s));
+      if (fp8) {
+        FMI_TRY(launch_layernorm_mod_fp8(w.x_img, mi + 4 * D, mi + 3 * D, nmod, S, w.a8 + (size_t)BT * D, w.a8s + BT, B * S, D, 1e-6f, s));
+        FMI_TRY(launch_layernorm_mod_fp8(w.x_txt, mt + 4 * D, mt + 3 * D, nmod, T, w.a8, w.a8s, B * T, D, 1e-6f, s));
+      } else {
+        FMI_TRY(launch_layernorm_mod(w.x_img, mi + 4 * D, mi + 3 * D, nmod, S, xm_img, B * S, D, 1e-6f, s));
+        FMI_TRY(launch_layernorm_mod(w.x_txt, mt + 4 * D, mt + 3 * D, nmod, T, xm_txt, B * T, D, 1e-6f, s));
+      }
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_MLP);
       bf16_t* hid_txt = w.hid;
       bf16_t* hid_img = w.hid + (size_t)B * T * Mh;
       GemmProblem p[2];
-      p[0] = make_problem(bw.mlp1[0], xm_img, D, B * S, hid_img, Mh, EPI_GELU_BF16);
-      p[1] = make_problem(bw.mlp1[1], xm_txt, D, B * T, hid_txt, Mh, EPI_GELU_BF16);
+      p[0] = fp8 ? make_problem_fp8(m, bw.mlp1[0], BT, B * S, hid_img, Mh, EPI_GELU_BF16) : make_problem(bw.mlp1[0], xm_img, D, B * S, hid_img, Mh, EPI_GELU_BF16);
+      p[1] = fp8 ? make_problem_fp8(m, bw.mlp1[1], 0, B * T, hid_txt, Mh, EPI_GELU_BF16) : make_problem(bw.mlp1[1], xm_txt, D, B * T, hid_txt, Mh, EPI_GELU_BF16);
       FMI_TRY(gemm2(m, p, 2, s));
-      p[0] = make_problem(bw.mlp2[0], hid_img, Mh, B * S, w.x_img, D, EPI_RESID_GATE_F32);
+      if (fp8) {  // hid is (B*L, M) with the txt rows first, like a8
+        FMI_TRY(launch_quantize_rows_fp8(w.hid, Mh, B * L, Mh, w.a8, w.a8s, s));
+      }
+      p[0] = fp8 ? make_problem_fp8(m, bw.mlp2[0], BT, B * S, w.x_img, D, EPI_RESID_GATE_F32)
+                 : make_problem(bw.mlp2[0], hid_img, Mh, B * S, w.x_img, D, EPI_RESID_GATE_F32);
       with_gate(p[0], mi + 5 * D, S, nmod);
-      p[1] = make_problem(bw.mlp2[1], hid_txt, Mh, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
+      p[1] = fp8 ? make_problem_fp8(m, bw.mlp2[1], 0, B * T, w.x_txt, D, EPI_RESID_GATE_F32)
+                 : make_problem(bw.mlp2[1], hid_txt, Mh, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
       with_gate(p[1], mt + 5 * D, T, nmod);
       FMI_TRY(gemm2(m, p, 2, s));
     }
@@ -544,12 +598,16 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     bool fused = false;
     {
       PhaseTimer pt(m, s, PH_LN);
-      FMI_TRY(launch_layernorm_mod(w.x, mo + D, mo, nmod, L, w.xm, B * L, D, 1e-6f, s));
+      if (fp8)
+        FMI_TRY(launch_layernorm_mod_fp8(w.x, mo + D, mo, nmod, L, w.a8, w.a8s, B * L, D, 1e-6f, s));
+      else
+        FMI_TRY(launch_layernorm_mod(w.x, mo + D, mo, nmod, L, w.xm, B * L, D, 1e-6f, s));
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_QKV);
       // [q|k|v|gelu(proj_mlp)] in one GEMM; the concat of model.rs:660 is never materialised
-      GemmProblem p = make_problem(bw.w1, w.xm, D, B * L, w.big, ldbig, EPI_GELU_FROM_COL);
+      GemmProblem p = fp8 ? make_problem_fp8(m, bw.w1, 0, B * L, w.big, ldbig, EPI_GELU_FROM_COL)
+                          : make_problem(bw.w1, w.xm, D, B * L, w.big, ldbig, EPI_GELU_FROM_COL);
       p.gelu_from = 3 * D;
       fused = with_qkv_relayout(m, p, bw.nq, bw.nk, pe_bs, L, 0, L);
       FMI_TRY(gemm2(m, &p, 1, s));
@@ -570,7 +628,9 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
-      GemmProblem p = make_problem(bw.w2, w.big + 2 * D, ldbig, B * L, w.x, D, EPI_RESID_GATE_F32);
+      if (fp8) FMI_TRY(launch_quantize_rows_fp8(w.big + 2 * D, ldbig, B * L, D + Mh, w.a8, w.a8s, s));
+      GemmProblem p = fp8 ? make_problem_fp8(m, bw.w2, 0, B * L, w.x, D, EPI_RESID_GATE_F32)
+                          : make_problem(bw.w2, w.big + 2 * D, ldbig, B * L, w.x, D, EPI_RESID_GATE_F32);
       with_gate(p, mo + 2 * D, L, nmod);
       FMI_TRY(gemm2(m, &p, 1, s));
     }
@@ -651,6 +711,7 @@ extern "C" void fmi_flux_destroy(fmi_flux* m) {
     if (m->wscratch[k]) hipFree(m->wscratch[k]);
   if (m->mod_steps) hipFree(m->mod_steps);
   if (m->vec_steps) hipFree(m->vec_steps);
+  if (m->fp8_arena) hipFree(m->fp8_arena);
   for (auto& b : m->dbl)
     for (int s = 0; s < 2; ++s)
       for (Dense* d : {&b.qkv[s], &b.proj[s], &b.mlp1[s], &b.mlp2[s]}) {
@@ -669,6 +730,7 @@ extern "C" void fmi_flux_destroy(fmi_flux* m) {
 
 extern "C" int fmi_flux_set_tensor(fmi_flux* m, const char* name, const void* data, fmi_dtype dtype, const int64_t* shape, int rank) {
   if (!m || !name || !data) return fail(FMI_ERR_INVALID, "flux_set_tensor: null argument");
+  if (m->fp8) return fail(FMI_ERR_STATE, "flux_set_tensor: the model was quantised to fp8 (fmi_flux_quantize_fp8); create a new one to load other weights");
   auto it = m->names.find(name);
   if (it == m->names.end()) return fail(FMI_ERR_INVALID, std::string("flux_set_tensor: unknown tensor name '") + name + "'");
   const Dest& d = it->second;
@@ -758,6 +820,7 @@ Dense* find_dense(fmi_flux* m, const std::string& prefix, int* row0) {
 extern "C" int fmi_flux_set_linear_bnb4(fmi_flux* m, const char* prefix, const uint8_t* packed, const float* absmax, int blocksize,
                                         int quant_type, int out_features, int in_features) {
   if (!m || !prefix || !packed || !absmax) return fail(FMI_ERR_INVALID, "set_linear_bnb4: null argument");
+  if (m->fp8) return fail(FMI_ERR_STATE, "set_linear_bnb4: the model was quantised to fp8");
   if (quant_type != 1 && quant_type != 2) return fail(FMI_ERR_INVALID, "set_linear_bnb4: quant_type must be 1 (fp4) or 2 (nf4)");
   if (blocksize % 64 || blocksize <= 0 || in_features % blocksize)
     return fail(FMI_ERR_UNSUPPORTED, "set_linear_bnb4: blocksize must be a multiple of 64 dividing in_features");
@@ -812,6 +875,7 @@ extern "C" int fmi_flux_set_linear_bnb4(fmi_flux* m, const char* prefix, const u
 // block linears keep the int8 weight and are expanded into the bf16 scratch right before their GEMM.
 extern "C" int fmi_flux_set_linear_int8(fmi_flux* m, const char* prefix, const int8_t* weight, const float* scb, int out_features, int in_features) {
   if (!m || !prefix || !weight || !scb) return fail(FMI_ERR_INVALID, "set_linear_int8: null argument");
+  if (m->fp8) return fail(FMI_ERR_STATE, "set_linear_int8: the model was quantised to fp8");
   int row0 = 0;
   Dense* d = find_dense(m, prefix, &row0);
   const std::string wname = std::string(prefix) + ".weight";
@@ -859,7 +923,7 @@ extern "C" const char* fmi_flux_missing_name(const fmi_flux* m, int i) {
   mm->missing_list.assign(m->missing.begin(), m->missing.end());
   return mm->missing_list[i].c_str();
 }
-extern "C" size_t fmi_flux_size_in_bytes(const fmi_flux* m) { return m ? m->arena_bytes + m->ws.bytes : 0; }
+extern "C" size_t fmi_flux_size_in_bytes(const fmi_flux* m) { return m ? m->arena_bytes + m->ws.bytes + m->fp8_bytes : 0; }
 
 extern "C" int fmi_flux_forward(fmi_flux* m, const fmi_flux_inputs* in, float* pred_out, void* stream) {
   FMI_TRY(check_inputs(m, in));
@@ -948,6 +1012,44 @@ extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int enable) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
   m->dense_cache = enable != 0;
   m->dense_ready.clear();
+  return FMI_OK;
+}
+// fp8 mode: quantise every block Linear once (bf16 arena -> e4m3 + per-output-channel scale); see the header.
+extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) {
+  if (!m) return fail(FMI_ERR_INVALID, "null handle");
+  FMI_TRY(check_ready(m));
+  if (m->fp8) return FMI_OK;
+  std::vector<Dense*> lin;
+  for (auto& b : m->dbl)
+    for (int s = 0; s < 2; ++s)
+      for (Dense* d : {&b.qkv[s], &b.proj[s], &b.mlp1[s], &b.mlp2[s]}) lin.push_back(d);
+  for (auto& b : m->sgl)
+    for (Dense* d : {&b.w1, &b.w2}) lin.push_back(d);
+  size_t bytes = 0;
+  for (Dense* d : lin) {
+    if (d->q_type) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: model holds bitsandbytes-quantised linears; load a bf16 checkpoint");
+    if (d->K % 128 || d->N <= 128 || d->K > 16384) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: needs in_features % 128 == 0 (<= 16384) and out_features > 128");
+    bytes += align_up((size_t)d->N * d->K, 256) + align_up((size_t)d->N * 4, 256);
+  }
+  if (lin.empty()) return FMI_OK;
+  FMI_HIP_TRY(hipMalloc((void**)&m->fp8_arena, bytes));
+  m->fp8_bytes = bytes;
+  hipStream_t s = (hipStream_t)stream;
+  size_t off = 0;
+  for (Dense* d : lin) {
+    d->w8 = reinterpret_cast<uint8_t*>(m->fp8_arena + off);
+    off += align_up((size_t)d->N * d->K, 256);
+    d->w8_scale = reinterpret_cast<float*>(m->fp8_arena + off);
+    off += align_up((size_t)d->N * 4, 256);
+    FMI_TRY(launch_quantize_rows_fp8(d->w, d->K, d->N, d->K, d->w8, d->w8_scale, s));
+  }
+  FMI_HIP_TRY(hipStreamSynchronize(s));
+  if (m->ws.base) {  // the fp8 workspace has two more buffers: rebuild on the next call
+    FMI_HIP_TRY(hipFree(m->ws.base));
+    m->ws.base = nullptr;
+    m->ws.bytes = 0;
+  }
+  m->fp8 = true;
   return FMI_OK;
 }
 // 4-bit dispatch threshold (rows): below it the fused dequant-GEMM runs, at or above it dequant-once + dense

@@ -1,0 +1,168 @@
+// fp8.hip — dynamic row-wise e4m3 quantisation feeding the fp8 MFMA GEMM (gemm_pp_kernel<true>).
+//
+// BASELINE.json configs[4] ("FLUX.1-dev fp8, CDNA4 fp8 MFMA").  The reference has no fp8 path
+// ("our recipe; no reference"), so the recipe is defined here and restated in
+// oracle/flux_oracle.cpp (orc_quantize_rows_fp8):
+//   weights      per-output-channel scale, quantised once from the bf16 checkpoint values;
+//   activations  per-token scale, recomputed by the kernel that produces the GEMM input;
+//   scale[r]   = max(absmax(x[r,:]), 1e-30) / 448          (448 = largest finite OCP e4m3)
+//   q[r,k]     = e4m3_rne(x[r,k] * (448 / max(absmax, 1e-30)))   (v_cvt_pk_fp8_f32: RNE, saturating)
+//   y[m,n]     = (sum_k q_a[m,k] q_w[n,k]) * scale_a[m] * scale_w[n] + bias[n]     (f32 accumulate)
+// Both kernels are one pass over HBM per row block: a 256-thread block owns a row, keeps it in
+// registers between the absmax reduction and the conversion, 16-byte loads, 8-byte stores.
+#include "common.h"
+
+namespace fmi {
+
+namespace {
+
+constexpr float kE4M3Max = 448.0f;
+
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// 4 f32 -> 4 packed e4m3 bytes (byte i = element i)
+__device__ __forceinline__ uint32_t pack_e4m3x4(float a, float b, float c, float d) {
+  int v = 0;
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+  return (uint32_t)v;
+}
+
+constexpr int QR_MAXC = 8;  // 16-byte chunks per thread held in registers: K <= 256 * 8 * 8 = 16384
+
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __restrict x, int ld, int K, uint8_t* __restrict out,
+                                                                float* __restrict scale) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const uint4* xr = reinterpret_cast<const uint4*>(x + (int64_t)row * ld);
+  const int nc = K >> 3;
+  uint4 v[QR_MAXC];
+  float am = 0.f;
+#pragma unroll
+  for (int c = 0; c < QR_MAXC; ++c) {
+    const int i = threadIdx.x + c * 256;
+    if (i < nc) {
+      v[c] = xr[i];
+      const uint32_t u[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        am = fmaxf(am, fabsf(__uint_as_float(u[e] << 16)));
+        am = fmaxf(am, fabsf(__uint_as_float(u[e] & 0xffff0000u)));
+      }
+    }
+  }
+  am = fmaxf(block_max_256(am, red), 1e-30f);
+  const float inv = kE4M3Max / am;
+  if (threadIdx.x == 0) scale[row] = am / kE4M3Max;
+  uint2* o = reinterpret_cast<uint2*>(out + (int64_t)row * K);
+#pragma unroll
+  for (int c = 0; c < QR_MAXC; ++c) {
+    const int i = threadIdx.x + c * 256;
+    if (i < nc) {
+      const uint32_t u[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f[2 * e] = __uint_as_float(u[e] << 16) * inv;
+        f[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u) * inv;
+      }
+      o[i] = make_uint2(pack_e4m3x4(f[0], f[1], f[2], f[3]), pack_e4m3x4(f[4], f[5], f[6], f[7]));
+    }
+  }
+}
+
+// layernorm_mod_kernel (norm_rope.hip) with the quantisation fused: statistics, then the modulated
+// values are formed twice from the L1/L2-resident f32 row (absmax, then convert) — D <= 4096 keeps
+// them in registers instead.
+constexpr int LN_MAXV = 4;  // float4 per thread held in registers: D <= 256 * 4 * 4 = 4096
+
+__global__ __launch_bounds__(256) void layernorm_mod_fp8_kernel(const float* __restrict x, const float* __restrict scale,
+                                                                const float* __restrict shift, int mod_bstride, int rows_per_batch,
+                                                                uint8_t* __restrict out, float* __restrict out_scale, int D, float eps) {
+  __shared__ float red[2][4];
+  __shared__ float redm[4];
+  const int row = blockIdx.x;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+  const int nv = D >> 2;
+  float4 v[LN_MAXV];
+  float s = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAXV; ++c) {
+    const int i = threadIdx.x + c * 256;
+    if (i < nv) {
+      v[c] = xr[i];
+      s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+      s2 += (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w);
+    }
+  }
+  s = wave_sum(s);
+  s2 = wave_sum(s2);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][w] = s;
+    red[1][w] = s2;
+  }
+  __syncthreads();
+  s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  const float mean = s / (float)D;
+  const float var = s2 / (float)D - mean * mean;
+  const float inv_std = 1.0f / sqrtf(var + eps);
+  const int batch = rows_per_batch > 0 ? row / rows_per_batch : 0;
+  const float4* sc = scale ? reinterpret_cast<const float4*>(scale + (int64_t)batch * mod_bstride) : nullptr;
+  const float4* sh = shift ? reinterpret_cast<const float4*>(shift + (int64_t)batch * mod_bstride) : nullptr;
+  float am = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAXV; ++c) {
+    const int i = threadIdx.x + c * 256;
+    if (i < nv) {
+      float a = (v[c].x - mean) * inv_std, b = (v[c].y - mean) * inv_std, cc = (v[c].z - mean) * inv_std, d = (v[c].w - mean) * inv_std;
+      if (sc) {
+        const float4 k = sc[i];
+        a *= (k.x + 1.0f), b *= (k.y + 1.0f), cc *= (k.z + 1.0f), d *= (k.w + 1.0f);
+      }
+      if (sh) {
+        const float4 k = sh[i];
+        a += k.x, b += k.y, cc += k.z, d += k.w;
+      }
+      v[c] = make_float4(a, b, cc, d);
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(cc), fabsf(d)));
+    }
+  }
+  am = fmaxf(block_max_256(am, redm), 1e-30f);
+  const float inv = kE4M3Max / am;
+  if (threadIdx.x == 0) out_scale[row] = am / kE4M3Max;
+  uint32_t* o = reinterpret_cast<uint32_t*>(out + (int64_t)row * D);
+#pragma unroll
+  for (int c = 0; c < LN_MAXV; ++c) {
+    const int i = threadIdx.x + c * 256;
+    if (i < nv) o[i] = pack_e4m3x4(v[c].x * inv, v[c].y * inv, v[c].z * inv, v[c].w * inv);
+  }
+}
+
+}  // namespace
+
+int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* out, float* scale, hipStream_t stream) {
+  if (rows <= 0) return FMI_OK;
+  if (K <= 0 || K % 8 || ld % 8 || K > 256 * 8 * QR_MAXC) return fail(FMI_ERR_INVALID, "quantize_rows_fp8: K and ld must be multiples of 8, K <= 16384");
+  hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3(rows), dim3(256), 0, stream, x, ld, K, out, scale);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
+int launch_layernorm_mod_fp8(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch, uint8_t* out,
+                             float* out_scale, int rows, int D, float eps, hipStream_t stream) {
+  if (rows <= 0) return FMI_OK;
+  if (D % 4 || D > 256 * 4 * LN_MAXV) return fail(FMI_ERR_INVALID, "layernorm_mod_fp8: D must be a multiple of 4 and <= 4096");
+  hipLaunchKernelGGL(layernorm_mod_fp8_kernel, dim3(rows), dim3(256), 0, stream, x, scale, shift, mod_bstride, rows_per_batch, out, out_scale, D,
+                     eps);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
+}  // namespace fmi

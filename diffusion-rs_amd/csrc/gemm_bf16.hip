@@ -636,8 +636,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
 // lgkmcnt(0): a __syncthreads() would make hipcc drain vmcnt as well and collapse the pipeline,
 // and sched_barrier(0) keeps the MFMAs (not memory operations) from being hoisted across slots.
 // Accumulation order per output element is identical to gemm_bf16_kernel: bit-identical results.
+//
+// FP8 = true: the same pipeline on OCP e4m3 operands (GemmProblem::fp8).  A 128-byte tile row holds 128 k
+// instead of 64, so the LDS image, the swizzle, the DMA pieces and the 24 ds_read_b128 per LOAD are
+// unchanged; two 16-byte fragments are paired into the 32-byte operand of v_mfma_f32_32x32x64_f8f6f4
+// (16 per COMPUTE instead of 32 of the bf16 instruction, the same matrix-pipe time for twice the k).
+// Which k a (lane, byte) of the operand carries is irrelevant as long as A and W use the same map,
+// which they do: both tiles have the same LDS layout and are read with the same offsets.
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+template <bool FP8>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatch batch) {
   constexpr int NJ = 2, BN = 256;
+  constexpr int ES = FP8 ? 1 : 2;  // operand element size
   constexpr int A_RING = 0, W_RING = 2 * A_TILE_BYTES, TILE = A_TILE_BYTES;  // 2 x 32 KiB + 3 x 32 KiB
   __shared__ __attribute__((aligned(16))) char smem[5 * TILE];
   const int tid = threadIdx.x;
@@ -661,7 +672,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
   const int tin = t_in - band * GH * tiles_n;
   const int tn = tin / band_h, tm = band * GH + tin % band_h;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = P.K / BK;
+  const int nk = P.K * ES / (BK * 2);  // 128-byte K tiles
 
   f32x16 acc[4][NJ];
 #pragma unroll
@@ -687,8 +698,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int ra = (a_chunk0 + i) * 8 + (lane >> 3), rw = (w_chunk0 + i) * 8 + (lane >> 3);
-    a_off[i] = (uint32_t)(((int64_t)min(m0 + ra, P.M - 1) * P.lda + (((lane & 7) ^ ((ra >> 1) & 7)) << 3)) * 2);
-    w_off[i] = (uint32_t)(((int64_t)min(n0 + rw, P.N - 1) * P.ldw + (((lane & 7) ^ ((rw >> 1) & 7)) << 3)) * 2);
+    a_off[i] = (uint32_t)((int64_t)min(m0 + ra, P.M - 1) * P.lda * ES + (((lane & 7) ^ ((ra >> 1) & 7)) << 4));
+    w_off[i] = (uint32_t)((int64_t)min(n0 + rw, P.N - 1) * P.ldw * ES + (((lane & 7) ^ ((rw >> 1) & 7)) << 4));
   }
   const char* const a_base = reinterpret_cast<const char*>(P.A);
   const char* const w_base = reinterpret_cast<const char*>(P.W);
@@ -725,7 +736,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
   slot_barrier();
   if (g == 1) slot_barrier();  // group 1 starts one slot late
 
-  bf16x8_t xf[4][4], wf[4][NJ];
+  bf16x8_t xf[4][4], wf[4][NJ];   // bf16: fragments of the 4 k-steps
+  i32x8_t xq[2][4], wq[2][NJ];    // fp8: fragments of the 2 k-steps (two 16-byte reads each)
   int wr = 0;  // W slot of tile t = t % 3
   int wi = 2;  // W slot of tile t + 2
   auto ktile = [&](int t, auto main_tag) {
@@ -753,12 +765,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
     {
       const char* la = smem + A_RING + (t & 1) * TILE + a_row_off;
       const char* lw = smem + W_RING + wr * TILE + w_row_off;
+      if constexpr (FP8) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) wf[s][j] = *reinterpret_cast<const bf16x8_t*>(lw + j * 32 * 128 + koff[s]);
+          for (int j = 0; j < NJ; ++j)
+            wq[s][j] = __builtin_shufflevector(*reinterpret_cast<const i32x4_t*>(lw + j * 32 * 128 + koff[2 * s]),
+                                               *reinterpret_cast<const i32x4_t*>(lw + j * 32 * 128 + koff[2 * s + 1]), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xf[s][i] = *reinterpret_cast<const bf16x8_t*>(la + i * 32 * 128 + koff[s]);
+          for (int i = 0; i < 4; ++i)
+            xq[s][i] = __builtin_shufflevector(*reinterpret_cast<const i32x4_t*>(la + i * 32 * 128 + koff[2 * s]),
+                                               *reinterpret_cast<const i32x4_t*>(la + i * 32 * 128 + koff[2 * s + 1]), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) wf[s][j] = *reinterpret_cast<const bf16x8_t*>(lw + j * 32 * 128 + koff[s]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xf[s][i] = *reinterpret_cast<const bf16x8_t*>(la + i * 32 * 128 + koff[s]);
+        }
       }
     }
 #ifndef FMI_PP_DMA_FIRST
@@ -783,6 +809,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
 #ifdef FMI_PP_SETPRIO
     __builtin_amdgcn_s_setprio(1);
 #endif
+    if constexpr (FP8) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[s][j], xq[s][i], acc[i][j], 0, 0, 0, 0, 0, 0);  // e4m3 x e4m3, unscaled
+    } else {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -801,13 +836,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
 #endif
         }
       }
+    }
 #ifdef FMI_PP_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
 #ifdef FMI_PP_SLEEP
     __builtin_amdgcn_s_sleep(FMI_PP_SLEEP);  // ablation: stand-in for the MFMA time (64 clocks per unit)
 #endif
-    if (FMI_PP_EARLY == 0) slot_barrier();
+    if (FP8 || FMI_PP_EARLY == 0) slot_barrier();
     wr = wr == 2 ? 0 : wr + 1;
     wi = wi == 2 ? 0 : wi + 1;
   };
@@ -816,6 +852,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
   for (int t = nmain; t < nk; ++t) ktile(t, std::false_type{});
   if (g == 0) slot_barrier();  // group 0 finished one slot early
 
+  if constexpr (FP8) {  // dequantise: per-token scale of the row, per-channel scale of the 4 consecutive columns
+    float sa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sa[i] = P.a_scale[min(m0 + g * 128 + i * 32 + (lane & 31), P.M - 1)];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+        float sn[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sn[c] = P.w_scale[min(n + c, P.N - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] *= sa[i] * sn[c];
+      }
+  }
   gemm_epilogue<NJ>(P, acc, smem, m0, n0, wave, lane);
 }
 
@@ -830,12 +884,16 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   int total = 0;
   const bool quant = probs[0].q_type != 0;
   const bool conv = probs[0].cv_ks != 0;
+  const bool fp8 = probs[0].fp8 != 0;
   int max_n = 0;
   for (int i = 0; i < nprob; ++i) max_n = std::max(max_n, probs[i].N);
   const int bn = max_n <= 128 ? 128 : 256;
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem& p = probs[i];
     if (p.M <= 0 || p.N <= 0) return fail(FMI_ERR_INVALID, "launch_gemm: empty problem");
+    if ((p.fp8 != 0) != fp8) return fail(FMI_ERR_INVALID, "launch_gemm: cannot mix fp8 and bf16 problems in one group");
+    if (fp8 && (p.q_type || p.cv_ks || bn != 256 || p.K % 128 || p.lda % 16 || p.ldw % 16 || !p.a_scale || !p.w_scale))
+      return fail(FMI_ERR_INVALID, "launch_gemm: fp8 needs dense operands, N > 128, K / lda / ldw multiples of 128 / 16 / 16 and both scale vectors");
     if (p.K <= 0 || p.K % BK != 0) return fail(FMI_ERR_INVALID, "launch_gemm: K must be a positive multiple of 64, got " + std::to_string(p.K));
     if ((p.q_type != 0) != quant || (p.cv_ks != 0) != conv) return fail(FMI_ERR_INVALID, "launch_gemm: cannot mix dense / 4-bit / conv problems in one group");
     if (quant && conv) return fail(FMI_ERR_UNSUPPORTED, "launch_gemm: quantised convolution");
@@ -860,12 +918,14 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
     else                                                                                    \
       hipLaunchKernelGGL((gemm_bf16_kernel<MODE, 2>), grid, blk, 0, stream, b);             \
   } while (0)
-  if (conv)
+  if (fp8)
+    hipLaunchKernelGGL(gemm_pp_kernel<true>, grid, blk, 0, stream, b);
+  else if (conv)
     FMI_GEMM_LAUNCH(2);
   else if (quant)
     FMI_GEMM_LAUNCH(1);
   else if (bn == 256 && g_pingpong)
-    hipLaunchKernelGGL(gemm_pp_kernel, grid, blk, 0, stream, b);
+    hipLaunchKernelGGL(gemm_pp_kernel<false>, grid, blk, 0, stream, b);
   else
     FMI_GEMM_LAUNCH(0);
 #undef FMI_GEMM_LAUNCH

@@ -129,6 +129,11 @@ class FluxModel:
             wp, sp = C.c_void_p(w.ctypes.data), C.c_void_p(sc.ctypes.data)
         L.check(self.lib.fmi_flux_set_linear_int8(self.h, prefix.encode(), wp, sp, out_features, in_features))
 
+    def quantize_fp8(self, stream=None):
+        """Switch the DiT block linears to the fp8 (OCP e4m3) MFMA path: weights quantised once per output
+        channel from the loaded bf16 values, activations per token on the fly (BASELINE configs[4])."""
+        L.check(self.lib.fmi_flux_quantize_fp8(self.h, stream))
+
     def missing(self) -> List[str]:
         n = self.lib.fmi_flux_missing_count(self.h)
         return [self.lib.fmi_flux_missing_name(self.h, i).decode() for i in range(n)]

@@ -128,6 +128,14 @@ int fmi_flux_set_linear_int8(fmi_flux*, const char* prefix, const int8_t* weight
  * loop); 0 = expanded into a scratch before every GEMM call.  Small-row calls always use the fused
  * dequant-GEMM on the packed weights. */
 int fmi_flux_set_quant_dense_cache(fmi_flux*, int enable);
+/* fp8 inference mode (BASELINE.json configs[4]; the reference has no fp8 path, SURVEY.md §8d — the recipe
+ * is this library's own, restated in oracle/flux_oracle.cpp:orc_quantize_rows_fp8).  Call once after all
+ * tensors are set: every DiT block Linear (q|k|v, attention out, MLP, single-block linear1/linear2) is
+ * quantised from its bf16 values to OCP e4m3 with one f32 scale per output channel; from then on their
+ * GEMMs run on v_mfma_f32_32x32x64_f8f6f4 with activations quantised per token by the producing kernel
+ * (AdaLN-modulate) or by one row pass (attention output, GELU(MLP)).  Attention, the residual stream,
+ * modulation, embedders and the final layer stay bf16/f32.  Not combinable with bnb-quantised linears. */
+int fmi_flux_quantize_fp8(fmi_flux*, void* stream);
 int fmi_flux_missing_count(const fmi_flux*);
 const char* fmi_flux_missing_name(const fmi_flux*, int i);
 /* Bytes of HBM held by the model (weights + current workspace). */
@@ -333,6 +341,15 @@ int fmi_linear_bf16(const void* x, const void* w, const void* bias, void* y, int
 int fmi_linear_bnb4_bf16(const void* x, const uint8_t* packed, const float* absmax,
                          int blocksize, int quant_type, const void* bias, void* y, int M,
                          int N, int K, fmi_epilogue epi, void* stream);
+/* Row-wise dynamic e4m3 quantisation: scale[r] = max(absmax(x[r,:]), 1e-30) / 448,
+ * out[r,k] = e4m3_rne(x[r,k] * (448 / max(absmax, 1e-30))).  x (rows,K) bf16, out (rows,K) u8, K % 8 == 0,
+ * K <= 16384.  Used for weights (row = output channel) and activations (row = token). */
+int fmi_quantize_rows_fp8(const void* x, int rows, int K, uint8_t* out, float* scale, void* stream);
+/* y(M,N) = epi((xq · Wq^T) * xs[m] * ws[n] + bias), xq/xs = fmi_quantize_rows_fp8(x) computed internally,
+ * Wq (N,K) e4m3 + ws (N) from fmi_quantize_rows_fp8(W); y bf16, f32 accumulate on the fp8 MFMA.
+ * N > 128, K % 128 == 0. */
+int fmi_linear_fp8(const void* x, const uint8_t* wq, const float* w_scale, const void* bias, void* y, int M, int N,
+                   int K, fmi_epilogue epi, void* stream);
 /* softmax(q k^T * scale) v, q,k,v,o (B,H,L,d) bf16, d == 128, non-causal; o is written
  * token-major (B,L,H*d) when `out_token_major`, else (B,H,L,d).
  * == backend::ops::sdpa fallback (ops.rs:247-262) without materialising the scores. */

@@ -559,9 +559,66 @@ extern "C" void orc_postprocess_u8(const float* x, int64_t n, uint8_t* out) {
 }
 
 // ---------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) recipe of BASELINE.json configs[4].  PARITY UNPINNED: the reference has no fp8 path
+// ("our recipe; no reference"), so there is no reference file:line to follow and no
+// golden vector; this is the definition the HIP path (csrc/fp8.hip, gemm_pp_kernel<true>) is tested
+// against.  The e4m3 codec itself is pinned by the OCP 8-bit floating point specification's value
+// table (tests/test_oracle_fp8.py checks all 256 codes and round-to-nearest-even on the midpoints).
+//   scale[r] = max(absmax(x[r,:]), 1e-30) / 448 ;  q[r,k] = e4m3_rne_sat(x[r,k] * (448 / max(absmax, 1e-30)))
+// ---------------------------------------------------------------------------------------
+extern "C" float orc_e4m3_to_f32(uint8_t c) {
+  const int e = (c >> 3) & 15, mant = c & 7;
+  float v;
+  if (e == 15 && mant == 7) return NAN;
+  if (e == 0) v = ldexpf((float)mant, -9);       // subnormal: m/8 * 2^-6
+  else v = ldexpf(1.0f + mant / 8.0f, e - 7);
+  return (c & 0x80) ? -v : v;
+}
+extern "C" uint8_t orc_f32_to_e4m3(float x) {
+  if (x != x) return 0x7f;
+  const uint8_t sign = std::signbit(x) ? 0x80 : 0;
+  float a = fabsf(x);
+  if (a > 448.0f) a = 448.0f;  // saturating conversion: e4m3 (fn) has no infinity, 448 is the largest finite value
+  int e;
+  (void)frexpf(a, &e);                       // a = f * 2^e, f in [0.5, 1)  ->  a in [2^(e-1), 2^e)
+  int ue = e - 1;                            // unbiased exponent
+  if (ue < -6) ue = -6;                      // subnormal range shares the quantum of the smallest normal binade
+  const float quantum = ldexpf(1.0f, ue - 3);  // 3 mantissa bits
+  const float q = nearbyintf(a / quantum);   // RNE (default rounding mode); a / quantum is exact (power of two)
+  float r = q * quantum;
+  if (r > 448.0f) r = 448.0f;
+  if (r == 0.0f) return sign;
+  int re;
+  (void)frexpf(r, &re);
+  int rue = re - 1;
+  uint8_t code;
+  if (rue < -6) code = (uint8_t)(int)ldexpf(r, 9);  // subnormal: mant = r / 2^-9
+  else code = (uint8_t)(((rue + 7) << 3) | ((int)(ldexpf(r, 3 - rue)) - 8));
+  return sign | code;
+}
+extern "C" void orc_quantize_rows_fp8(const float* x, int rows, int K, uint8_t* out, float* scale) {
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r) {
+    const float* xr = x + (int64_t)r * K;
+    float am = 0.f;
+    for (int k = 0; k < K; ++k) am = fmaxf(am, fabsf(xr[k]));
+    am = fmaxf(am, 1e-30f);
+    const float inv = 448.0f / am;
+    scale[r] = am / 448.0f;
+    for (int k = 0; k < K; ++k) out[(int64_t)r * K + k] = orc_f32_to_e4m3(xr[k] * inv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // FLUX model — diffusion_rs_core/src/models/flux/model.rs
 // ---------------------------------------------------------------------------------------
+struct Fp8Weight {
+  std::vector<float> q;  // e4m3 values (dequantised codes, unscaled), (N, K)
+  std::vector<float> s;  // per-output-channel scale
+};
 struct orc_flux {
+  int fp8 = 0;  // block linears on the fp8 recipe above
+  std::map<const float*, Fp8Weight> fp8_w;
   int in_channels, pooled_dim, joint_dim, heads, n_double, n_single, guidance;
   int axes[3], theta;
   int D, M;
@@ -598,8 +655,10 @@ extern "C" orc_flux* orc_flux_create(int in_channels, int pooled_projection_dim,
   return m;
 }
 extern "C" void orc_flux_destroy(orc_flux* m) { delete m; }
+extern "C" void orc_flux_set_fp8(orc_flux* m, int on) { m->fp8 = on; }
 extern "C" int orc_flux_set_tensor(orc_flux* m, const char* name, const float* data, int64_t numel) {
   m->t[name] = std::vector<float>(data, data + numel);
+  m->fp8_w.clear();
   return 0;
 }
 
@@ -620,6 +679,27 @@ Lin get_lin(const orc_flux* m, const std::string& p, int in, int out, bool bias 
   return l;
 }
 void lin_fwd(const Lin& l, const float* x, int rows, float* y) { gemm_nt(x, l.in, l.w, l.in, l.b, rows, l.out, l.in, y, l.out, 1.0f); }
+// A DiT block Linear: lin_fwd, or the fp8 recipe when orc_flux_set_fp8 is on:
+// y[m,n] = (sum_k qx[m,k] qw[n,k]) * (sx[m] * sw[n]) + b[n]
+void lin_blk(orc_flux* m, const Lin& l, const float* x, int rows, float* y) {
+  if (!m->fp8) return lin_fwd(l, x, rows, y);
+  Fp8Weight& fw = m->fp8_w[l.w];
+  if (fw.q.empty()) {
+    std::vector<uint8_t> codes((size_t)l.out * l.in);
+    fw.s.resize(l.out);
+    orc_quantize_rows_fp8(l.w, l.out, l.in, codes.data(), fw.s.data());
+    fw.q.resize(codes.size());
+    for (size_t i = 0; i < codes.size(); ++i) fw.q[i] = orc_e4m3_to_f32(codes[i]);
+  }
+  std::vector<uint8_t> xc((size_t)rows * l.in);
+  std::vector<float> xs(rows), xq((size_t)rows * l.in);
+  orc_quantize_rows_fp8(x, rows, l.in, xc.data(), xs.data());
+  for (size_t i = 0; i < xc.size(); ++i) xq[i] = orc_e4m3_to_f32(xc[i]);
+  gemm_nt(xq.data(), l.in, fw.q.data(), l.in, nullptr, rows, l.out, l.in, y, l.out, 1.0f);
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r)
+    for (int n = 0; n < l.out; ++n) y[(int64_t)r * l.out + n] = y[(int64_t)r * l.out + n] * (xs[r] * fw.s[n]) + (l.b ? l.b[n] : 0.f);
+}
 
 // layer_norm() helper model.rs:33-38 (weight = 1, bias = 0, eps 1e-6) then
 // ModulationOut::scale_shift model.rs:218-221: xs*(scale+1)+shift
@@ -650,20 +730,20 @@ void attention(const float* q, const float* k, const float* v, const float* pe, 
     for (int h = 0; h < H; ++h) memcpy(out_tok + ((int64_t)l * H + h) * d, o.data() + ((int64_t)h * L + l) * d, sizeof(float) * d);
 }
 // SelfAttention::qkv, model.rs:399-427: three linears, head split, QkNorm on q and k.
-bool qkv(const orc_flux* m, const std::string& p, const char* qn, const char* kn, const char* vn, const char* nq, const char* nk, const float* x, int rows, int row_off, int Ltot, float* Q, float* K, float* V) {
+bool qkv(orc_flux* m, const std::string& p, const char* qn, const char* kn, const char* vn, const char* nq, const char* nk, const float* x, int rows, int row_off, int Ltot, float* Q, float* K, float* V) {
   const int D = m->D, H = m->heads, d = D / H;
   Lin lq = get_lin(m, p + qn, D, D), lk = get_lin(m, p + kn, D, D), lv = get_lin(m, p + vn, D, D);
   const float* wq = m->get(p + nq + ".weight", d);
   const float* wk = m->get(p + nk + ".weight", d);
   if (!lq.ok() || !lk.ok() || !lv.ok() || !wq || !wk) return false;
   std::vector<float> tmp((size_t)rows * D), tmp2((size_t)rows * D);
-  lin_fwd(lq, x, rows, tmp.data());
+  lin_blk(m, lq, x, rows, tmp.data());
   orc_rms_norm_slow(tmp.data(), wq, 1e-6f, rows * H, d, tmp2.data());
   to_heads(tmp2.data(), rows, H, d, Q, row_off, Ltot);
-  lin_fwd(lk, x, rows, tmp.data());
+  lin_blk(m, lk, x, rows, tmp.data());
   orc_rms_norm_slow(tmp.data(), wk, 1e-6f, rows * H, d, tmp2.data());
   to_heads(tmp2.data(), rows, H, d, K, row_off, Ltot);
-  lin_fwd(lv, x, rows, tmp.data());
+  lin_blk(m, lv, x, rows, tmp.data());
   to_heads(tmp.data(), rows, H, d, V, row_off, Ltot);
   return true;
 }
@@ -711,22 +791,22 @@ static int double_block_one(orc_flux* m, int idx, float* img, float* txt, const 
   if (!ip.ok() || !tp.ok() || !i1.ok() || !i2.ok() || !t1.ok() || !t2.ok()) return -1;
   {
     std::vector<float> y((size_t)S * D), h((size_t)S * M);
-    lin_fwd(ip, img_attn, S, y.data());
+    lin_blk(m, ip, img_attn, S, y.data());
     add_gated(img, imod.data() + 2 * D, y.data(), S, D);  // model.rs:548
     ln_mod(img, imod.data() + 3 * D, imod.data() + 4 * D, S, D, xm.data());
-    lin_fwd(i1, xm.data(), S, h.data());
+    lin_blk(m, i1, xm.data(), S, h.data());
     orc_gelu(h.data(), (int64_t)S * M, h.data());
-    lin_fwd(i2, h.data(), S, y.data());
+    lin_blk(m, i2, h.data(), S, y.data());
     add_gated(img, imod.data() + 5 * D, y.data(), S, D);  // model.rs:549-554
   }
   {
     std::vector<float> y((size_t)T * D), h((size_t)T * M);
-    lin_fwd(tp, txt_attn, T, y.data());
+    lin_blk(m, tp, txt_attn, T, y.data());
     add_gated(txt, tmod.data() + 2 * D, y.data(), T, D);  // model.rs:556
     ln_mod(txt, tmod.data() + 3 * D, tmod.data() + 4 * D, T, D, tm.data());
-    lin_fwd(t1, tm.data(), T, h.data());
+    lin_blk(m, t1, tm.data(), T, h.data());
     orc_gelu(h.data(), (int64_t)T * M, h.data());
-    lin_fwd(t2, h.data(), T, y.data());
+    lin_blk(m, t2, h.data(), T, y.data());
     add_gated(txt, tmod.data() + 5 * D, y.data(), T, D);  // model.rs:557-562
   }
   return 0;
@@ -745,7 +825,7 @@ static int single_block_one(orc_flux* m, int idx, float* x, const float* vec, co
   Lin pm = get_lin(m, p + "proj_mlp", D, M), l2 = get_lin(m, p + "proj_out", D + M, D);
   if (!pm.ok() || !l2.ok()) return -1;
   std::vector<float> cat((size_t)L * (D + M)), mlp((size_t)L * M), attn((size_t)L * D);
-  lin_fwd(pm, xm.data(), L, mlp.data());
+  lin_blk(m, pm, xm.data(), L, mlp.data());
   attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data());
   orc_gelu(mlp.data(), (int64_t)L * M, mlp.data());
 #pragma omp parallel for
@@ -754,7 +834,7 @@ static int single_block_one(orc_flux* m, int idx, float* x, const float* vec, co
     memcpy(cat.data() + (size_t)l * (D + M) + D, mlp.data() + (size_t)l * M, sizeof(float) * M);
   }
   std::vector<float> y((size_t)L * D);
-  lin_fwd(l2, cat.data(), L, y.data());
+  lin_blk(m, l2, cat.data(), L, y.data());
   add_gated(x, mod.data() + 2 * D, y.data(), L, D);  // xs + mod_.gate(&output)  (model.rs:661)
   return 0;
 }

@@ -57,6 +57,11 @@ typedef struct orc_flux orc_flux;
 orc_flux* orc_flux_create(int in_channels, int pooled_projection_dim, int joint_attention_dim, int num_attention_heads, int num_layers, int num_single_layers, int guidance_embeds, const int* axes_dim, int theta);
 void orc_flux_destroy(orc_flux*);
 int orc_flux_set_tensor(orc_flux*, const char* name, const float* data, int64_t numel);
+/* fp8 recipe (BASELINE configs[4]; no reference counterpart — parity unpinned, see flux_oracle.cpp) */
+void orc_flux_set_fp8(orc_flux*, int on);
+float orc_e4m3_to_f32(uint8_t code);
+uint8_t orc_f32_to_e4m3(float x);
+void orc_quantize_rows_fp8(const float* x, int rows, int K, uint8_t* out, float* scale);
 /* returns 0 ok, <0 on missing tensor (name printed to stderr) */
 int orc_flux_forward(orc_flux*, const float* img, const float* img_ids, const float* txt, const float* txt_ids, const float* timesteps, const float* y, const float* guidance, int B, int S, int T, float* pred);
 int orc_flux_denoise(orc_flux*, float* img_inout, const float* img_ids, const float* txt, const float* txt_ids, const float* y, const float* guidance, int B, int S, int T, const double* timesteps, int n_steps);

@@ -43,6 +43,12 @@ def lib():
         _lib.orc_t5_create.restype = C.c_void_p
         _lib.orc_t5_create.argtypes = [C.c_int] * 8 + [C.c_float, C.c_int]
         _lib.orc_clip_create.restype = C.c_void_p
+        _lib.orc_e4m3_to_f32.restype = C.c_float
+        _lib.orc_e4m3_to_f32.argtypes = [C.c_uint8]
+        _lib.orc_f32_to_e4m3.restype = C.c_uint8
+        _lib.orc_f32_to_e4m3.argtypes = [C.c_float]
+        _lib.orc_flux_set_fp8.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_flux_set_fp8.restype = None
     return _lib
 
 
@@ -209,6 +215,38 @@ def dequantize_8bit(w, scb, row, col, out_dtype="f32"):
     return out
 
 
+def e4m3_to_f32(code):
+    return float(lib().orc_e4m3_to_f32(int(code)))
+
+
+def f32_to_e4m3(x):
+    return int(lib().orc_f32_to_e4m3(float(x)))
+
+
+def e4m3_table():
+    """The 256 e4m3 values as f32 (NaN at 0x7f / 0xff)."""
+    return np.array([e4m3_to_f32(c) for c in range(256)], np.float32)
+
+
+def quantize_rows_fp8(x):
+    """fp8 recipe of configs[4] (no reference counterpart): per-row e4m3 codes + f32 scale."""
+    x, xp = _f(x)
+    rows, K = x.shape
+    out = np.empty((rows, K), np.uint8)
+    scale = np.empty(rows, np.float32)
+    lib().orc_quantize_rows_fp8(xp, rows, K, out.ctypes.data_as(u8p), scale.ctypes.data_as(f32p))
+    return out, scale
+
+
+def linear_fp8(x, w, b=None):
+    """y = (q(x) q(w)^T) * sx * sw + b with both operands on the row-wise e4m3 recipe, f32 accumulate."""
+    xq, xs = quantize_rows_fp8(x)
+    wq, ws = quantize_rows_fp8(w)
+    tab = e4m3_table()
+    y = linear(tab[xq], tab[wq]) * (xs[:, None] * ws[None, :])
+    return y + (0 if b is None else np.asarray(b, np.float32)[None, :])
+
+
 def quantize_blockwise_4bit(w, blocksize, quant_type):
     w, wp = _f(w)
     n = w.size
@@ -285,6 +323,10 @@ class Flux:
     def load(self, tensors):
         for k, v in tensors.items():
             self.set_tensor(k, v)
+
+    def set_fp8(self, on=True):
+        """Block linears on the fp8 recipe (flux_oracle.cpp: parity unpinned, no reference counterpart)."""
+        lib().orc_flux_set_fp8(self.h, int(bool(on)))
 
     def forward(self, img, img_ids, txt, txt_ids, timesteps, y, guidance=None):
         img, a = _f(img)

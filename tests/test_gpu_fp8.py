@@ -1,0 +1,205 @@
+"""fp8 (OCP e4m3) path — BASELINE configs[4] — through the C-ABI vs the oracle's restatement of the same recipe.
+
+The reference has no fp8 path ("our recipe; no reference"), so parity is against the recipe as
+defined in oracle/flux_oracle.cpp (codec pinned to the OCP table and to torch.float8_e4m3fn in
+tests/test_oracle_fp8.py).  Bars: quantisation bit-exact; fp8 GEMM vs the oracle on the SAME codes
+rel-L2 <= 2e-3 (f32 accumulation order + bf16 output rounding only); model evaluation vs the fp8 oracle
+rel-L2 <= 1e-2 (the bf16 path's bar; bf16 intermediates move a few activations across e4m3 rounding
+boundaries), latents after the Euler loop <= 3e-2; the recipe's own noise (fp8 vs f32 oracle) is printed.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import SMALL_FLUX, bf16_round, dev, flux_inputs, host, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import diffusion_rs_amd as d
+    from diffusion_rs_amd import _lib as L
+    from oracle import oracle as orc
+    return dict(torch=torch, d=d, L=L, lib=L.load(), orc=orc)
+
+
+def gpu_quantize(env, x_bf16):
+    torch, L, lib = env["torch"], env["L"], env["lib"]
+    rows, K = x_bf16.shape
+    q = torch.empty(rows, K, dtype=torch.uint8, device="cuda")
+    s = torch.empty(rows, dtype=torch.float32, device="cuda")
+    L.check(lib.fmi_quantize_rows_fp8(_p(x_bf16), rows, K, _p(q), _p(s), None))
+    torch.cuda.synchronize()
+    return q, s
+
+
+@pytest.mark.parametrize("rows,K", [(1, 8), (5, 136), (33, 3072), (7, 15360), (300, 256), (2, 16384)])
+def test_quantize_rows_bit_exact(env, rows, K):
+    torch, orc = env["torch"], env["orc"]
+    rng = np.random.default_rng(rows * 131 + K)
+    x = rng.standard_normal((rows, K)).astype(np.float32) * (10.0 ** rng.uniform(-3, 3, (rows, 1))).astype(np.float32)
+    if rows > 2:
+        x[1] = 0            # an all-zero token
+        x[2, ::3] *= 1e-4   # values far below the row maximum: e4m3 subnormals and underflow
+    x = bf16_round(x)
+    xd = dev(x, torch.bfloat16)
+    q, s = gpu_quantize(env, xd)
+    rq, rs = orc.quantize_rows_fp8(x)
+    np.testing.assert_array_equal(s.cpu().numpy(), rs)
+    got = q.cpu().numpy()
+    # +0 and -0 are the same number; everything else must be the same code
+    np.testing.assert_array_equal(np.where(got == 0x80, 0, got), np.where(rq == 0x80, 0, rq))
+
+
+def test_quantize_rows_rejects_bad_shapes(env):
+    torch, lib = env["torch"], env["lib"]
+    x = torch.zeros(4, 16392, dtype=torch.bfloat16, device="cuda")
+    q = torch.empty(4, 16392, dtype=torch.uint8, device="cuda")
+    s = torch.empty(4, dtype=torch.float32, device="cuda")
+    assert lib.fmi_quantize_rows_fp8(_p(x), 4, 16392, _p(q), _p(s), None) < 0   # K > 16384
+    assert lib.fmi_quantize_rows_fp8(_p(x), 4, 12, _p(q), _p(s), None) < 0      # K % 8
+    assert lib.fmi_quantize_rows_fp8(_p(x), 0, 64, _p(q), _p(s), None) == 0     # no rows: nothing to do
+    assert lib.fmi_quantize_rows_fp8(None, 4, 64, _p(q), _p(s), None) < 0
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(64, 256, 128, 0), (300, 384, 256, 0), (257, 1024, 1280, 1), (1000, 260, 384, 0), (16, 3072, 1024, 0)])
+def test_linear_fp8_matches_oracle(env, M, N, K, epi):
+    torch, L, lib, orc = env["torch"], env["L"], env["lib"], env["orc"]
+    rng = np.random.default_rng(M + N + K)
+    x = bf16_round(rng.standard_normal((M, K)).astype(np.float32) * (1 + 10 * (rng.random((M, 1)) < 0.1)).astype(np.float32))
+    w = bf16_round((rng.standard_normal((N, K)) * 0.05).astype(np.float32))
+    b = bf16_round(rng.standard_normal(N).astype(np.float32))
+    xd, wd, bd = dev(x, torch.bfloat16), dev(w, torch.bfloat16), dev(b, torch.bfloat16)   # keep the device buffers alive across the call
+    wq, ws = gpu_quantize(env, wd)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.fmi_linear_fp8(_p(xd), _p(wq), _p(ws), _p(bd), _p(y), M, N, K, epi, None))
+    torch.cuda.synchronize()
+    ref = orc.linear_fp8(x, w, b)
+    if epi == 1:
+        ref = orc.gelu(ref)
+    err = rel_l2(host(y), ref)
+    noise = rel_l2(ref, orc.gelu(orc.linear(x, w, b)) if epi == 1 else orc.linear(x, w, b))
+    print(f"linear_fp8 {M}x{N}x{K} epi={epi}: rel-L2 vs fp8 oracle {err:.2e}; fp8 recipe vs f32 linear {noise:.2e}")
+    assert err <= 2e-3
+
+
+def test_linear_fp8_rejects_bad_shapes(env):
+    torch, lib = env["torch"], env["lib"]
+    x = torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda")
+    q = torch.zeros(256, 256, dtype=torch.uint8, device="cuda")
+    s = torch.ones(256, dtype=torch.float32, device="cuda")
+    y = torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda")
+    assert lib.fmi_linear_fp8(_p(x), _p(q), _p(s), None, _p(y), 64, 128, 256, 0, None) < 0   # N <= 128: no fp8 tile shape
+    assert lib.fmi_linear_fp8(_p(x), _p(q), _p(s), None, _p(y), 64, 256, 192, 0, None) < 0   # K % 128
+    assert lib.fmi_linear_fp8(_p(x), _p(q), None, None, _p(y), 64, 256, 256, 0, None) < 0
+    assert lib.fmi_linear_fp8(_p(x), _p(q), _p(s), None, _p(y), 0, 256, 256, 0, None) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(4608, 9216, 3072), (4608, 3072, 15360), (4112, 12288, 3072)])
+def test_fp8_gemm_equals_bf16_gemm_of_dequantised_codes_full_size(env, M, N, K):
+    """Size-independent property at BASELINE shapes (C2 L=4608, C5 L=4112): e4m3 values are exactly representable
+    in bf16, so the fp8 MFMA GEMM must agree with the bf16 MFMA GEMM run on the dequantised codes — the products
+    are exact in both, only the f32 accumulation order differs."""
+    torch, L, lib = env["torch"], env["L"], env["lib"]
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    xq, xs = gpu_quantize(env, x)
+    wq, ws = gpu_quantize(env, w)
+    y8 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.fmi_linear_fp8(_p(x), _p(wq), _p(ws), None, _p(y8), M, N, K, 0, None))
+    xd = xq.view(torch.float8_e4m3fn).to(torch.bfloat16)
+    wd = wq.view(torch.float8_e4m3fn).to(torch.bfloat16)
+    assert torch.equal(xd.float(), xq.view(torch.float8_e4m3fn).float())   # exact in bf16
+    yd = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.fmi_linear_bf16(_p(xd), _p(wd), None, _p(yd), M, N, K, 0, None))
+    torch.cuda.synchronize()
+    # y8 = bf16(acc * xs * ws), yd = bf16(acc): half a bf16 ulp of rounding on each side (<= 2^-7 relative in
+    # total at the bottom of a binade) plus the accumulation difference of the two MFMA instructions (k = 16 vs
+    # k = 64 per instruction, f32 partial sums of ~1e6 in code units: measured up to ~1e-5 of the largest
+    # output, visible only where the sum cancels to ~0) -> 3 * 2^-8 relative + 1e-4 of the largest output.
+    # A misplaced 128-byte K tile would be an error of ~0.2 sigma, three orders above this floor.
+    ref = yd.float() * (xs[:, None] * ws[None, :])
+    diff = (y8.float() - ref).abs()
+    tol = ref.abs() * (3 * 2.0 ** -8) + 1e-4 * ref.abs().max()
+    bad = int((diff > tol).sum())
+    rel = float((y8.float() - ref).norm() / ref.norm())
+    print(f"fp8 vs bf16-of-codes {M}x{N}x{K}: rel-L2 {rel:.2e}, max diff {float(diff.max()):.3e}, outside tolerance: {bad}")
+    if bad:
+        idx = torch.nonzero(diff > tol)[:6]
+        for i, j in idx.tolist():
+            print(f"  [{i},{j}] y8 {float(y8[i, j]):.6e} ref {float(ref[i, j]):.6e} yd {float(yd[i, j]):.6e} scale {float(xs[i] * ws[j]):.4e} max {float(ref.abs().max()):.4e}")
+    assert bad == 0 and rel < 3e-3
+
+
+@pytest.fixture(scope="module")
+def models(env):
+    d, orc = env["d"], env["orc"]
+    sd = d.synth.flux_state_dict_numpy(SMALL_FLUX, seed=0)
+    g8 = d.FluxModel(SMALL_FLUX)
+    g8.load_state_dict(sd)
+    g8.quantize_fp8()
+    gb = d.FluxModel(SMALL_FLUX)
+    gb.load_state_dict(sd)
+    o8 = orc.Flux(SMALL_FLUX)
+    o8.load(sd)
+    o8.set_fp8(True)
+    of = orc.Flux(SMALL_FLUX)
+    of.load(sd)
+    return dict(g8=g8, gb=gb, o8=o8, of=of)
+
+
+@pytest.mark.parametrize("B,S_hw,T", [(1, (8, 12), 40), (2, (6, 6), 64), (1, (16, 16), 77)])
+def test_flux_forward_fp8_matches_fp8_oracle(env, models, B, S_hw, T):
+    torch = env["torch"]
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, B, S_hw, T)
+    t = np.linspace(0.9, 0.4, B).astype(np.float32)
+    g = np.full(B, 3.5, np.float32)
+    args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
+    got = host(models["g8"].forward(*args))
+    ref8 = models["o8"].forward(img, ids, txt, txt_ids, t, y, g)
+    ref = models["of"].forward(img, ids, txt, txt_ids, t, y, g)
+    gotb = host(models["gb"].forward(*args))
+    assert np.isfinite(got).all()
+    e8, ef, eb = rel_l2(got, ref8), rel_l2(got, ref), rel_l2(gotb, ref)
+    print(f"fp8 forward B={B} S={S_hw} T={T}: vs fp8 oracle {e8:.3e}; vs f32 oracle {ef:.3e} (bf16 path: {eb:.3e}); oracle fp8 vs f32 {rel_l2(ref8, ref):.3e}")
+    assert e8 <= 1e-2   # same bar as the bf16 path against its oracle
+    assert ef <= 2e-2   # recipe noise + bf16 noise on this synthetic model (measured 2.8e-3)
+
+
+def test_flux_denoise_fp8(env, models):
+    torch, d = env["torch"], env["d"]
+    B, S_hw, T, steps = 1, (8, 8), 32, 4
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, B, S_hw, T, seed=7)
+    g = np.full(B, 3.5, np.float32)
+    sched = d.SchedulerConfig()
+    ts = sched.get_timesteps(steps, sched.calculate_shift(S_hw[0] * S_hw[1]))
+    ref8 = models["o8"].denoise(img, ids, txt, txt_ids, y, g, ts)
+    args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(y), dev(g), ts)
+    got = host(models["g8"].denoise(*args))
+    again = host(models["g8"].denoise(*args))
+    np.testing.assert_array_equal(got, again)   # deterministic
+    err = rel_l2(got, ref8)
+    print(f"fp8 denoise {steps} steps: rel-L2 vs fp8 oracle {err:.3e}")
+    assert err <= 3e-2
+
+
+def test_fp8_mode_guards(env, models):
+    d = env["d"]
+    sd = d.synth.flux_state_dict_numpy(SMALL_FLUX, seed=0)
+    m = d.FluxModel(SMALL_FLUX)
+    with pytest.raises(d.FmiError):
+        m.quantize_fp8()          # tensors missing
+    m.load_state_dict(sd)
+    m.quantize_fp8()
+    m.quantize_fp8()              # idempotent
+    name = "transformer_blocks.0.attn.to_q.weight"
+    with pytest.raises(d.FmiError):
+        m.set_tensor(name, sd[name])   # weights are frozen once quantised

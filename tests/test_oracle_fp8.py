@@ -1,0 +1,85 @@
+"""The fp8 (OCP e4m3) codec and row-wise recipe of the oracle (BASELINE configs[4]).
+
+The reference has no fp8 path, so there is no reference KAT; the codec is pinned to
+(i) the OCP 8-bit floating point specification's e4m3 definition restated here in three lines of
+Python (bias 7, 3 mantissa bits, subnormals at exponent 0, S.1111.111 = NaN, no infinities, max 448)
+and (ii) torch's independent float8_e4m3fn conversion for every in-range value we probe.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+def spec_value(c):
+    e, m = (c >> 3) & 15, c & 7
+    if e == 15 and m == 7:
+        return float("nan")
+    v = m / 8 * 2.0 ** -6 if e == 0 else (1 + m / 8) * 2.0 ** (e - 7)
+    return -v if c & 0x80 else v
+
+
+def test_e4m3_decode_table_matches_spec():
+    tab = orc.e4m3_table()
+    for c in range(256):
+        s = spec_value(c)
+        if np.isnan(s):
+            assert np.isnan(tab[c])
+        else:
+            assert tab[c] == np.float32(s), c
+    assert tab[0x7e] == 448.0 and tab[0x01] == 2.0 ** -9 and tab[0x08] == 2.0 ** -6
+
+
+def test_e4m3_encode_roundtrip_midpoints_saturation():
+    tab = orc.e4m3_table()
+    for c in range(256):
+        if not np.isnan(tab[c]):
+            assert orc.f32_to_e4m3(float(tab[c])) == c
+    for c in range(0x7e):  # ties go to the even code
+        mid = (float(tab[c]) + float(tab[c + 1])) / 2
+        assert orc.f32_to_e4m3(mid) == (c if c % 2 == 0 else c + 1)
+        assert orc.f32_to_e4m3(-mid) == 0x80 | (c if c % 2 == 0 else c + 1)
+        assert orc.f32_to_e4m3(np.nextafter(np.float32(mid), np.float32(1e9))) == c + 1
+        assert orc.f32_to_e4m3(np.nextafter(np.float32(mid), np.float32(0))) == c
+    assert orc.f32_to_e4m3(1e30) == 0x7e and orc.f32_to_e4m3(-1e30) == 0xfe and orc.f32_to_e4m3(463.9) == 0x7e
+    assert orc.f32_to_e4m3(float("nan")) == 0x7f
+
+
+def test_e4m3_encode_matches_torch_float8():
+    torch = pytest.importorskip("torch")
+    if not hasattr(torch, "float8_e4m3fn"):
+        pytest.skip("torch without float8")
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(4000) * 100, rng.standard_normal(4000) * 0.01, rng.uniform(-448, 448, 4000)]).astype(np.float32)
+    x = x[np.abs(x) <= 448]
+    ref = torch.from_numpy(x).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    got = np.array([orc.f32_to_e4m3(float(v)) for v in x], np.uint8)
+    # -0 / +0 of underflowing values carry the sign in both
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_quantize_rows_recipe():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((7, 256)).astype(np.float32) * np.array([1e-3, 1, 50, 1e4, 0, 3, 1e-20])[:, None].astype(np.float32)
+    q, s = orc.quantize_rows_fp8(x)
+    tab = orc.e4m3_table()
+    am = np.maximum(np.abs(x).max(1), np.float32(1e-30)).astype(np.float32)
+    np.testing.assert_array_equal(s, (am / np.float32(448)).astype(np.float32))
+    assert (q[4] == 0).all() or set(q[4]) <= {0, 0x80}          # zero row stays zero
+    deq = tab[q] * s[:, None]
+    # the row maximum maps to +-448 exactly and the relative error of normal-range values is <= 2^-4
+    for r in (0, 1, 2, 3, 5):
+        k = np.abs(x[r]).argmax()
+        assert abs(tab[q[r, k]]) == 448
+        big = np.abs(x[r]) >= am[r] * 2.0 ** -6 / 448 * 8
+        assert (np.abs(deq[r][big] - x[r][big]) <= np.abs(x[r][big]) * 2.0 ** -4 * 1.0001).all()
+
+
+def test_linear_fp8_close_to_f32():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((40, 256)).astype(np.float32)
+    w = (rng.standard_normal((96, 256)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(96).astype(np.float32)
+    y8, y = orc.linear_fp8(x, w, b), orc.linear(x, w, b)
+    err = np.linalg.norm(y8 - y) / np.linalg.norm(y)
+    assert err < 5e-2, err   # two e4m3 operands: ~2^-4/sqrt(3) relative noise each, averaged over K
