@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence committed under profiles/ (run on the GPU box through gpurun):
-#   tools/profile_round.sh <tag>        e.g. r01c
+#   tools/profile_round.sh <tag>        e.g. r01c      (BENCH_ARGS="--quant fp8" adds bench flags to every pass)
 # 1. kernel trace + stats of the default bench command (whole 50-step image, no CPU baseline)
 # 2./3. FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (2 denoise steps), never combined with traces
 set -e
@@ -9,9 +9,9 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err" || tail -5 "$OUT/kt.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python "$ROOT/bench.py" --no-cpu-baseline $BENCH_ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err" || tail -5 "$OUT/kt.err"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o pmc -- python "$ROOT/bench.py" --no-cpu-baseline --no-profile-pass --denoise-steps 2 --steps 1 --warmup 0 > "$OUT/pmc_$C.log" 2>&1 || tail -5 "$OUT/pmc_$C.log"
+  rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o pmc -- python "$ROOT/bench.py" --no-cpu-baseline $BENCH_ARGS --no-profile-pass --denoise-steps 2 --steps 1 --warmup 0 > "$OUT/pmc_$C.log" 2>&1 || tail -5 "$OUT/pmc_$C.log"
 done
 cd "$ROOT"
 KT=$(find "$OUT/kt" -name "*.db" | head -1)
