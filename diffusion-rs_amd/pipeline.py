@@ -36,6 +36,7 @@ class ModelDType(enum.Enum):  # diffusion_rs_py/src/lib.rs:37-44
     BF16 = 1
     F16 = 2
     F32 = 3
+    F8E4M3 = 4  # extension (not in the reference): DiT block linears on the e4m3 MFMA, DESIGN.md §4.3
 
 
 class Offloading(enum.Enum):  # lib.rs:13-17.  Accepted and ignored: 288 GB of HBM hold everything.
@@ -151,6 +152,8 @@ class Pipeline:
             self._load_checkpoint(source.model_id, getattr(source, "transformer_model_id", None))
         else:
             self._load_checkpoint(source.file, None)
+        if dtype == ModelDType.F8E4M3:
+            self.flux.quantize_fp8()
 
     # Pipeline::load (pipelines/mod.rs:120-236) for a local diffusers directory or a DDUF file:
     # model_index.json -> FluxPipeline only; scheduler / transformer / vae components

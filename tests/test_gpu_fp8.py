@@ -203,3 +203,38 @@ def test_fp8_mode_guards(env, models):
     name = "transformer_blocks.0.attn.to_q.weight"
     with pytest.raises(d.FmiError):
         m.set_tensor(name, sd[name])   # weights are frozen once quantised
+
+
+def test_pipeline_fp8_end_to_end(env, tmp_path):
+    """Pipeline(dtype=ModelDType.F8E4M3): embeddings -> 4-step denoise -> VAE -> u8 vs the oracle pipeline with
+    the fp8 recipe on the DiT blocks; same bar as the bf16 pipeline (|du8| <= 2 on >= 99 % of the pixels)."""
+    torch, d, orc = env["torch"], env["d"], env["orc"]
+    from tests.test_gpu_pipeline import _write_diffusers_dir
+    from tests.util import SMALL_VAE
+    sd = d.synth.flux_state_dict_numpy(SMALL_FLUX, seed=0)
+    vsd = d.synth.vae_state_dict_numpy(SMALL_VAE, seed=0)
+    root = str(tmp_path / "tiny-flux")
+    _write_diffusers_dir(root, sd, vsd)
+    pipe = d.Pipeline(d.ModelSource.ModelId(root), dtype=d.ModelDType.F8E4M3)
+    params = d.DiffusionGenerationParams(height=128, width=192, num_steps=4, guidance_scale=3.5)
+    B, T = 2, 24
+    rng = np.random.default_rng(3)
+    t5 = bf16_round(rng.standard_normal((B, T, SMALL_FLUX["joint_attention_dim"])).astype(np.float32))
+    clip = rng.standard_normal((B, SMALL_FLUX["pooled_projection_dim"])).astype(np.float32)
+    lat = rng.standard_normal((B, 16, 16, 24)).astype(np.float32)
+    u8 = pipe.forward(["a", "b"], params, embeddings=(dev(t5, torch.bfloat16), dev(clip)), latents=dev(lat), output="tensor")
+    torch.cuda.synchronize()
+    om = orc.Flux(SMALL_FLUX)
+    om.load(sd)
+    om.set_fp8(True)
+    ov = orc.Vae(SMALL_VAE)
+    ov.load(vsd)
+    img, ids = orc.pack_latents(lat)
+    ts = pipe.scheduler.get_timesteps(4, pipe.scheduler.calculate_shift(img.shape[1]))
+    img = om.denoise(img, ids, t5, np.zeros((B, T, 3), np.float32), clip, np.full(B, 3.5, np.float32), ts)
+    z = orc.unpack_latents(img, 16, 16, 24) * np.float32(1.0 / SMALL_VAE["scaling_factor"]) + np.float32(SMALL_VAE["shift_factor"])
+    ref = orc.postprocess_u8(ov.decode(z.astype(np.float32)))
+    diff = np.abs(u8.cpu().numpy().astype(np.int32) - ref.astype(np.int32))
+    frac = float((diff <= 2).mean())
+    print(f"fp8 pipeline u8: max |d| {diff.max()}, frac<=2 {frac:.4f}")
+    assert frac >= 0.99
