@@ -38,6 +38,15 @@ int main(int argc, char** argv) {
   std::vector<Shape> shapes = {{4608, 21504, 3072, "single qkv+mlp"}, {4608, 3072, 15360, "single proj_out"}, {4096, 9216, 3072, "double qkv img"},
                                {4096, 12288, 3072, "double mlp1 img"}, {4096, 3072, 12288, "double mlp2 img"}, {4096, 3072, 3072, "double proj img"},
                                {512, 9216, 3072, "double qkv txt"}, {8192, 8192, 8192, "8k cube"}};
+  if (const char* env = getenv("FMI_SHAPES")) {  // "M,N,K;M,N,K;..." replaces the FLUX list
+    shapes.clear();
+    int m, n, k, used = 0;
+    while (sscanf(env, "%d,%d,%d%n", &m, &n, &k, &used) == 3) {
+      shapes.push_back({m, n, k, "custom"});
+      env += used;
+      if (*env == ';') ++env;
+    }
+  }
   int iters = argc > 1 ? atoi(argv[1]) : 10;
   const int pad_a = argc > 2 ? atoi(argv[2]) : 0, pad_w = argc > 3 ? atoi(argv[3]) : 0, pad_o = argc > 4 ? atoi(argv[4]) : 0;  // row-stride padding (elements)
   printf("pads: lda +%d, ldw +%d, ldo +%d elements\n", pad_a, pad_w, pad_o);
@@ -83,7 +92,8 @@ int main(int argc, char** argv) {
     count_mismatch<<<1024, 256>>>(O, O2, (size_t)s.M * p.ldo, d_mis);
     unsigned long long mis = 0;
     hipMemcpy(&mis, d_mis, 8, hipMemcpyDeviceToHost);
-    printf("%-18s M=%5d N=%5d K=%5d  double-buffered %7.1f TF   ping-pong %7.1f TF   mismatching elements %llu%s\n", s.name, s.M, s.N, s.K, tf[0], tf[1], mis,
+    printf("%-18s M=%5d N=%5d K=%5d  tiles %5d  double-buffered %7.1f TF   ping-pong %7.1f TF (%7.1f us)   mismatching elements %llu%s\n", s.name, s.M, s.N, s.K,
+           ((s.M + 255) / 256) * ((s.N + 255) / 256), tf[0], tf[1], 2.0 * s.M * s.N * s.K / tf[1] * 1e-6, mis,
            hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
   }
   return 0;
