@@ -112,6 +112,7 @@ def load():
     lib.fmi_quantize_rows_fp8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fmi_linear_fp8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.fmi_flux_quantize_fp8.argtypes = [C.c_void_p, C.c_void_p]
+    lib.fmi_flux_set_modulation_gemm.argtypes = [C.c_void_p, C.c_int]
     lib.fmi_linear_bnb4_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_void_p]
     lib.fmi_sdpa_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
@@ -144,7 +145,7 @@ def check(rc):
 # every symbol include/flux_mi355x.h declares (tests/test_abi.py checks they are all exported)
 EXPORTED = [
     "fmi_last_error", "fmi_abi_version", "fmi_init", "fmi_device_info", "fmi_flux_default_config", "fmi_flux_create", "fmi_flux_destroy",
-    "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_set_linear_int8", "fmi_flux_set_quant_dense_cache", "fmi_flux_quantize_fp8", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
+    "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_set_linear_int8", "fmi_flux_set_quant_dense_cache", "fmi_flux_set_modulation_gemm", "fmi_flux_quantize_fp8", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
     "fmi_flux_forward", "fmi_flux_denoise", "fmi_flux_set_profiling", "fmi_flux_set_fused_qkv_relayout", "fmi_flux_phase_count", "fmi_flux_phase_name", "fmi_flux_phase_ms",
     "fmi_vae_default_config", "fmi_vae_create", "fmi_vae_destroy", "fmi_vae_set_tensor", "fmi_vae_missing_count", "fmi_vae_missing_name",
     "fmi_vae_scale_factor", "fmi_vae_shift_factor", "fmi_vae_decode", "fmi_vae_encode",

@@ -213,6 +213,7 @@ int launch_dequant_int8_scb_bf16(const int8_t* w, const float* scb, bf16_t* out,
 int launch_timestep_embedding(const float* t, int B, int dim, float* out, hipStream_t stream);
 int launch_cast_to_bf16(const void* src, fmi_dtype dt, bf16_t* dst, int64_t n, hipStream_t stream);
 int launch_cast_to_f32(const void* src, fmi_dtype dt, float* dst, int64_t n, hipStream_t stream);
+int launch_silu_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t stream);
 int launch_euler_update(float* img, const float* pred, float dt, int64_t n, hipStream_t stream);
 int launch_split_rows_f32(const float* src, float* dst, int B, int rows_src_per_b, int row_off, int rows, int D, hipStream_t stream);
 

@@ -90,10 +90,12 @@ struct fmi_flux {
   // 4-bit weights, large-M regime: per-layer streaming dequant into a reusable bf16 scratch
   // all denoise steps' modulation vectors (n_steps*B, n_mod) and vec (n_steps*B, D), see fmi_flux_denoise
   float *mod_steps = nullptr, *vec_steps = nullptr;
+  bf16_t* vec_steps_bf = nullptr;  // silu(vec_steps) in bf16: A operand of the modulation GEMM
   size_t mod_steps_rows = 0;
   bf16_t* wscratch[2] = {nullptr, nullptr};
   size_t wscratch_elems = 0;
   int q_fused_max_rows = 512;  // M below this keeps the fused dequant-GEMM (weight-bandwidth-bound regime)
+  bool mod_gemm = true;  // fmi_flux_denoise: all steps' modulation vectors in one MFMA GEMM (else GEMV passes of 4 rows)
   bool fuse_qkv_relayout = true;  // QkNorm + RoPE + head/transposed relayout in the QKV GEMM's epilogue
   // Quantised block linears at large M: expanded ONCE into the layer's own slot of the bf16 arena (which
   // is laid out for the whole dense model anyway) and reused by every later step, instead of once per GEMM
@@ -711,6 +713,7 @@ extern "C" void fmi_flux_destroy(fmi_flux* m) {
     if (m->wscratch[k]) hipFree(m->wscratch[k]);
   if (m->mod_steps) hipFree(m->mod_steps);
   if (m->vec_steps) hipFree(m->vec_steps);
+  if (m->vec_steps_bf) hipFree(m->vec_steps_bf);
   if (m->fp8_arena) hipFree(m->fp8_arena);
   for (auto& b : m->dbl)
     for (int s = 0; s < 2; ++s)
@@ -961,9 +964,11 @@ extern "C" int fmi_flux_denoise(fmi_flux* m, const fmi_flux_inputs* in, float* i
       FMI_HIP_TRY(hipStreamSynchronize(s));
       if (m->mod_steps) FMI_HIP_TRY(hipFree(m->mod_steps));
       if (m->vec_steps) FMI_HIP_TRY(hipFree(m->vec_steps));
-      m->mod_steps = m->vec_steps = nullptr, m->mod_steps_rows = 0;
+      if (m->vec_steps_bf) FMI_HIP_TRY(hipFree(m->vec_steps_bf));
+      m->mod_steps = m->vec_steps = nullptr, m->vec_steps_bf = nullptr, m->mod_steps_rows = 0;
       FMI_HIP_TRY(hipMalloc((void**)&m->mod_steps, R * nmod * 4));
       FMI_HIP_TRY(hipMalloc((void**)&m->vec_steps, R * (size_t)m->D * 4));
+      FMI_HIP_TRY(hipMalloc((void**)&m->vec_steps_bf, R * (size_t)m->D * 2));
       m->mod_steps_rows = R;
     }
     {
@@ -973,9 +978,17 @@ extern "C" int fmi_flux_denoise(fmi_flux* m, const fmi_flux_inputs* in, float* i
     {
       PhaseTimer pt(m, s, PH_MOD);
       constexpr int GEMV_MAXROWS = 4;  // rows * D * 4 B of x staged in LDS per block (<= 64 KiB)
-      for (size_t r0 = 0; r0 < R; r0 += GEMV_MAXROWS)
-        FMI_TRY(launch_gemv(m->vec_steps + r0 * m->D, m->mod_all.w, m->mod_all.b, m->mod_steps + r0 * nmod, (int)std::min<size_t>(GEMV_MAXROWS, R - r0), (int)nmod,
-                            m->D, 1, 0, s));
+      if (m->mod_gemm && R > GEMV_MAXROWS && m->D % 64 == 0 && nmod % 8 == 0 && R * nmod < (1ull << 31)) {
+        // all rows in ONE pass over the matrix on the MFMA GEMM (silu(vec) rounded to bf16 like every other
+        // GEMM input): the matrix is read once per image instead of once per 4 steps
+        FMI_TRY(launch_silu_to_bf16(m->vec_steps, m->vec_steps_bf, (int64_t)R * m->D, s));
+        GemmProblem p = make_problem(m->mod_all, m->vec_steps_bf, m->D, (int)R, m->mod_steps, (int)nmod, EPI_STORE_F32);
+        FMI_TRY(launch_gemm(&p, 1, s));
+      } else {
+        for (size_t r0 = 0; r0 < R; r0 += GEMV_MAXROWS)
+          FMI_TRY(launch_gemv(m->vec_steps + r0 * m->D, m->mod_all.w, m->mod_all.b, m->mod_steps + r0 * nmod, (int)std::min<size_t>(GEMV_MAXROWS, R - r0),
+                              (int)nmod, m->D, 1, 0, s));
+      }
     }
     mod_steps = m->mod_steps;
   }
@@ -1005,6 +1018,12 @@ extern "C" int fmi_flux_phase_ms(fmi_flux* m, float* ms_out) {
 extern "C" int fmi_flux_set_fused_qkv_relayout(fmi_flux* m, int enable) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
   m->fuse_qkv_relayout = enable != 0;
+  return FMI_OK;
+}
+// fmi_flux_denoise's modulation precompute: 1 (default) one MFMA GEMM over all steps, 0 f32 GEMV passes of 4 rows
+extern "C" int fmi_flux_set_modulation_gemm(fmi_flux* m, int enable) {
+  if (!m) return fail(FMI_ERR_INVALID, "null handle");
+  m->mod_gemm = enable != 0;
   return FMI_OK;
 }
 // keep (1, default) or drop (0: per-call scratch expansion) the expanded bf16 copies of quantised block linears

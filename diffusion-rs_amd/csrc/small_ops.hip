@@ -114,6 +114,13 @@ int launch_cast_to_bf16(const void* src, fmi_dtype dt, bf16_t* dst, int64_t n, h
   FMI_LAUNCH_CHECK();
   return FMI_OK;
 }
+// dst bf16 = silu(src f32): the MFMA form of the modulation projection lin(silu(vec)) (model.rs:244-259)
+int launch_silu_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t stream) {
+  if (n <= 0) return FMI_OK;
+  hipLaunchKernelGGL(map_kernel, map_grid(n), dim3(256), 0, stream, n, [=] __device__(int64_t i) { dst[i] = f32_to_bf16(silu(src[i])); });
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
 int launch_cast_to_f32(const void* src, fmi_dtype dt, float* dst, int64_t n, hipStream_t stream) {
   if (n <= 0) return FMI_OK;
   if (dt == FMI_F32) {

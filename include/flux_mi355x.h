@@ -128,6 +128,10 @@ int fmi_flux_set_linear_int8(fmi_flux*, const char* prefix, const int8_t* weight
  * loop); 0 = expanded into a scratch before every GEMM call.  Small-row calls always use the fused
  * dequant-GEMM on the packed weights. */
 int fmi_flux_set_quant_dense_cache(fmi_flux*, int enable);
+/* fmi_flux_denoise computes every step's modulation vectors (they depend on t, guidance and y only) before
+ * the loop: 1 (default) = one MFMA GEMM (n_steps*B, D) x (n_mod, D)^T with silu(vec) rounded to bf16, the
+ * 6.5 GB modulation matrix read once per image; 0 = f32 GEMV passes of 4 rows (one pass per 4 steps). */
+int fmi_flux_set_modulation_gemm(fmi_flux*, int enable);
 /* fp8 inference mode (BASELINE.json configs[4]; the reference has no fp8 path, SURVEY.md §8d — the recipe
  * is this library's own, restated in oracle/flux_oracle.cpp:orc_quantize_rows_fp8).  Call once after all
  * tensors are set: every DiT block Linear (q|k|v, attention out, MLP, single-block linear1/linear2) is

@@ -187,3 +187,29 @@ def test_fused_qkv_relayout_is_bit_identical(models, B, S_hw, T):
     finally:
         L.check(lib.fmi_flux_set_fused_qkv_relayout(gm.h, 1))
     np.testing.assert_array_equal(fused, plain)
+
+
+@pytest.mark.parametrize("B,steps", [(1, 6), (2, 5)])
+def test_modulation_gemm_matches_gemv_passes(models, B, steps):
+    """fmi_flux_denoise precomputes all steps' modulation vectors: one MFMA GEMM (silu(vec) rounded to bf16, default)
+    vs f32 GEMV passes of 4 rows.  Same weights, f32 accumulate; the only difference is the bf16 rounding of the
+    GEMM's input, far inside the loop's 3e-2 bar against the oracle."""
+    torch, d, gm, om = models["torch"], models["d"], models["gm"], models["om"]
+    from diffusion_rs_amd import _lib as L
+    lib = L.load()
+    S_hw, T = (8, 8), 32
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, B, S_hw, T, seed=11)
+    g = np.full(B, 3.5, np.float32)
+    sched = d.SchedulerConfig()
+    ts = sched.get_timesteps(steps, sched.calculate_shift(S_hw[0] * S_hw[1]))
+    args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(y), dev(g), ts)
+    try:
+        L.check(lib.fmi_flux_set_modulation_gemm(gm.h, 0))
+        a = host(gm.denoise(*args))
+        L.check(lib.fmi_flux_set_modulation_gemm(gm.h, 1))
+        b = host(gm.denoise(*args))
+    finally:
+        L.check(lib.fmi_flux_set_modulation_gemm(gm.h, 1))
+    ref = om.denoise(img, ids, txt, txt_ids, y, g, ts)
+    print(f"modulation GEMM vs GEMV passes: rel-L2 {rel_l2(b, a):.2e}; vs oracle {rel_l2(b, ref):.2e} / {rel_l2(a, ref):.2e}")
+    assert rel_l2(b, a) <= 2e-3 and rel_l2(b, ref) <= 3e-2

@@ -92,7 +92,8 @@ def test_api_mirror_objects():
     assert s2.transformer_model_id == "x/y"
     with pytest.raises(ValueError):
         d.ModelSource.DdufFile("a.dduf").override_transformer_model_id("x")
-    assert [m.name for m in d.ModelDType] == ["Auto", "BF16", "F16", "F32"]
+    assert [m.name for m in d.ModelDType][:4] == ["Auto", "BF16", "F16", "F32"]  # the reference's four (lib.rs:37-44) ...
+    assert [m.name for m in d.ModelDType][4:] == ["F8E4M3"]                      # ... plus this build's fp8 extension
     assert d.Offloading.Full.name == "Full"
 
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """A/B timing of a library toggle inside ONE process on ONE box (box-to-box variance is +-2 %):
     python tools/ab_toggle.py fused_qkv      # fmi_flux_set_fused_qkv_relayout 0 / 1
+    python tools/ab_toggle.py mod_gemm [steps]   # fmi_flux_set_modulation_gemm 0 / 1 (default 50 steps: the precompute is per image)
 FLUX.1-dev at the C2 shape, random weights, 10 denoise steps per measurement, alternating A,B,A,B."""
 import os
 import sys
@@ -25,13 +26,16 @@ def main():
     guidance = torch.full((B,), 3.5, device=dev)
     txt_ids = torch.zeros((B, T, 3), device=dev)
     sched = d.SchedulerConfig()
-    ts = sched.get_timesteps(50, sched.calculate_shift(4096))[:11]
+    nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else (50 if what == "mod_gemm" else 10)
+    ts = sched.get_timesteps(50, sched.calculate_shift(4096))[:nsteps + 1]
     lat = d.randn_latents(B, 16, h, w, seed=3, device=dev)
     img, img_ids = d.pack_latents(lat)
 
     def setmode(v):
         if what == "fused_qkv":
             L.check(lib.fmi_flux_set_fused_qkv_relayout(flux.h, v))
+        elif what == "mod_gemm":
+            L.check(lib.fmi_flux_set_modulation_gemm(flux.h, v))
         else:
             raise SystemExit("unknown toggle")
 
@@ -40,13 +44,13 @@ def main():
         t0 = time.perf_counter()
         out = flux.denoise(img, img_ids, txt, txt_ids, y, guidance, ts)
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / 10 * 1e3, out
+        return (time.perf_counter() - t0) / nsteps * 1e3, out
 
     setmode(1)
     run()
     res = {0: [], 1: []}
     outs = {}
-    for rep in range(4):
+    for rep in range(4 if nsteps <= 10 else 2):
         for v in (0, 1):
             setmode(v)
             ms, out = run()
