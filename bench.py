@@ -213,7 +213,7 @@ def main():
     roof = None
     extra = {}
     if rank == 0 and not args.no_profile_pass:
-        nprof = min(NS, 4)
+        nprof = NS  # the whole loop: the modulation precompute is per image, so a shorter pass would misprice it
         fl = step_flops(S, T, B)
         lat = d.randn_latents(B, 16, h, w, seed=99, device=dev)
         img, img_ids = d.pack_latents(lat)

@@ -39,7 +39,7 @@ struct Dest {  // where a named tensor lands
 };
 
 enum Phase { PH_EMBED = 0, PH_MOD, PH_LN, PH_GEMM_QKV, PH_RELAYOUT, PH_ATTN, PH_GEMM_PROJ, PH_GEMM_MLP, PH_FINAL, PH_COUNT };
-const char* kPhaseNames[PH_COUNT] = {"embed", "modulation_gemv", "layernorm_mod", "gemm_qkv", "qk_norm_rope_vT", "attention",
+const char* kPhaseNames[PH_COUNT] = {"embed", "modulation", "layernorm_mod", "gemm_qkv", "qk_norm_rope_vT", "attention",
                                      "gemm_proj", "gemm_mlp", "final_layer"};
 
 }  // namespace
