@@ -613,7 +613,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
 // Why (ablations on the double-buffered kernel above and on this one, profiles/ + DESIGN.md):
 //   * an LDS-DMA piece needs ~1.1-1.3 us from issue to landed under load, but double buffering
 //     gives a tile only one K-tile period of lead: every K tile ends in a wait for data;
-//   * a CU retires at most one 1-KiB global_load_lds every ~45 clocks (64 KiB per 1.2 us) and a
+//   * a CU gets at most one 1-KiB global_load_lds through every ~45 clocks (64 KiB per 1.2 us: the L2 /
+//     Infinity-Cache delivery rate with 256 CUs pulling, tools/load_rate.hip) and a
 //     wave that issues one while that queue is full stalls IN ORDER — the MFMAs behind it wait too.
 // So: (1) all 160 KiB of LDS hold 5 operand tiles (A ring of 2, W ring of 3) and a tile's
 // fragments are copied to registers in one burst, so its slot is recycled after a fraction of a
