@@ -42,6 +42,20 @@ def test_full_width_blocks_match_oracle():
     err = rel_l2(got, ref)
     print(f"full-width (D=3072) 1+1 blocks: rel-L2 {err:.3e}")
     assert np.isfinite(got).all() and err <= 1e-2
+    # fp8 mode (BASELINE configs[4]) at the same width: K = 3072 / 12288 / 15360 rows of e4m3 against the oracle's recipe
+    gm.quantize_fp8()
+    om.set_fp8(True)
+    ref8 = om.forward(img, ids, txt, txt_ids, t, y, g)
+    got8 = host(gm.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
+    e8, ef, noise = rel_l2(got8, ref8), rel_l2(got8, ref), rel_l2(ref8, ref)
+    print(f"full-width fp8: rel-L2 vs fp8 oracle {e8:.3e}, vs f32 oracle {ef:.3e} (recipe noise {noise:.3e})")
+    # With these synthetic weights (gates ~0.5 at D=3072) the recipe's own quantisation noise is ~5e-2, and the
+    # codes are chaotic in the inputs: the GPU's bf16 intermediates move ~3 % of the activations across an e4m3
+    # rounding boundary (a full 2^-3..2^-4 relative step each), so GPU and oracle are two partially correlated
+    # draws of the same noise.  Bit-exact quantisation and the GEMM on identical codes are pinned per op in
+    # tests/test_gpu_fp8.py; here the bar is statistical: the GPU is no further from the f32 truth than the
+    # oracle's recipe is (+25 %), and closer to the oracle's fp8 result than the recipe noise.
+    assert np.isfinite(got8).all() and ef <= 1.25 * noise and e8 <= noise
     gm.close()
 
 
