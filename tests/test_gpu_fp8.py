@@ -238,3 +238,23 @@ def test_pipeline_fp8_end_to_end(env, tmp_path):
     frac = float((diff <= 2).mean())
     print(f"fp8 pipeline u8: max |d| {diff.max()}, frac<=2 {frac:.4f}")
     assert frac >= 0.99
+
+
+def test_fp8_gemm_run_to_run_determinism_full_size(env):
+    """The fp8 variant shares the ping-pong pipeline's hand-placed waitcnts: a stale LDS tile would show up as a
+    run-to-run difference (this is how the bf16 kernel's one real race was found).  20 launches, bitwise equal."""
+    torch, L, lib = env["torch"], env["L"], env["lib"]
+    M, N, K = 4608, 21504, 3072
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    wq, ws = gpu_quantize(env, w)
+    first = None
+    for i in range(20):
+        y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        L.check(lib.fmi_linear_fp8(_p(x), _p(wq), _p(ws), None, _p(y), M, N, K, 0, None))
+        torch.cuda.synchronize()
+        if first is None:
+            first = y
+        else:
+            assert torch.equal(first, y), f"launch {i} differs"
