@@ -162,6 +162,7 @@ struct GemmProblem {
   const float* w_scale;
 };
 int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream);
+void set_gemm_w4(bool on);        // dense N>128 launches without the fused relayout: the 4-wave 128x128-per-wave kernel
 void set_gemm_pingpong(bool on);  // dense N>128 launches: ping-pong kernel (default) or the double-buffered one
 
 // attention output routing: query rows [0,rows0) -> p0, the rest -> p1 (token-major, head h at

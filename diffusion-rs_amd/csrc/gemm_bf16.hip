@@ -27,6 +27,7 @@
 //     "dequant as an LDS stage" of BASELINE.json's north star.
 //   * CONV: the A-tile row is an output pixel, the K tile a (tap, 64-channel) slice of an NHWC
 //     image; padding taps read a zero line, a nearest-2x upsample is folded into the gather.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -51,6 +52,12 @@ constexpr int GEMM_THREADS = 512;
 constexpr int A_TILE_BYTES = BM * BK * 2;  // 32 KiB
 constexpr int MAX_PROBLEMS = 8;
 
+#ifdef FMI_W4_TRACE
+__device__ long long g_w4_trace[64 * 8];
+#define W4_TR(k) do { if (blockIdx.x < 64 && threadIdx.x == 0) g_w4_trace[blockIdx.x * 8 + (k)] = clock64(); } while (0)
+#else
+#define W4_TR(k) do {} while (0)
+#endif
 struct GemmBatch {
   GemmProblem p[MAX_PROBLEMS];
   int tile_start[MAX_PROBLEMS + 1];
@@ -249,25 +256,28 @@ __device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, f32x
   }
 }
 
-template <int NJ>
-__device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc)[4][NJ], char* smem, int m0, int n0, int wave, int lane) {
-  constexpr int BN = 128 * NJ;
-  if constexpr (NJ == 2) {
-    if (P.qk_qh != nullptr && n0 < 3 * P.qk_D) {
-      qkv_relayout_epilogue(P, acc, smem, m0, n0, wave, lane);
-      return;
-    }
-  }
-  const int wm = wave >> 2, wn = wave & 3;
+// WN = waves along N (4: the 8-wave kernels, wave = wm*4 + wn, 128 x 32*NJ per wave; 2: the 4-wave kernel, 128 x 128 per wave)
+// ACT: -1 = everything decided at run time inside the loops (the 8-wave double-buffered kernels); otherwise the kernel is
+// instantiated per kind and the host picks it: 0 = no activation / no alpha, 1 = GELU, 2 = GELU from a column on,
+// 3 = the remaining kinds at run time (alpha scale, SiLU).  The loops below are fully unrolled (the accumulator array
+// must stay in registers), so a run-time switch inside them multiplies the code of every activation by 32-64
+// iterations: with 128-wide wave tiles the staged path alone was ~90 KB of instructions and ran out of the instruction
+// cache (measured on the 4-wave kernel: 45 000 clocks for 64 LDS writes).
+template <int NJ, int WN, int ACT>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, f32x16 (&acc)[4][NJ], char* smem, int m0, int n0, int wave, int lane) {
+  constexpr int BN = WN * 32 * NJ;
+  const int wm = wave / WN, wn = wave % WN;
   // ---- epilogue: lane holds row m = ..+(lane&31), columns n = ..+8q+4(lane>>5)+{0..3}
   const int epi = P.epi;
   const float alpha = P.alpha;
   const int hl = lane >> 5, l31 = lane & 31;
   // alpha, bias, activation on 4 consecutive columns starting at n
   auto finish = [&](int n, float (&v)[4], bool full) {
-    if (epi == EPI_STORE_F32 || epi == EPI_SCALE_BF16) {
+    if constexpr (ACT == 3 || ACT == -1) {
+      if (epi == EPI_STORE_F32 || epi == EPI_SCALE_BF16) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= alpha;
+        for (int e = 0; e < 4; ++e) v[e] *= alpha;
+      }
     }
     if (P.bias) {
       if (full) {
@@ -280,12 +290,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc
         for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(P.bias[n + e]);
       }
     }
-    if (epi == EPI_GELU_BF16 || (epi == EPI_GELU_FROM_COL && n >= P.gelu_from)) {
+    if constexpr (ACT == -1) {
+      if (epi == EPI_GELU_BF16 || (epi == EPI_GELU_FROM_COL && n >= P.gelu_from)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+      } else if (epi == EPI_SILU_BF16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
+      }
+    } else if constexpr (ACT == 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-    } else if (epi == EPI_SILU_BF16) {
+    } else if constexpr (ACT == 2) {
+      if (n >= P.gelu_from) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+      }
+    } else if constexpr (ACT == 3) {
+      if (epi == EPI_SILU_BF16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
+      }
     }
   };
   const bool f32_out = (epi == EPI_RESID_GATE_F32 || epi == EPI_STORE_F32);
@@ -299,6 +324,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc
                       (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias) & 7) == 0);
   if (staged) {
     __syncthreads();  // every wave is done with the operand tiles
+    if constexpr (NJ == 4) W4_TR(5);
     char* cw = smem + wave * (8192 * NJ);  // wave-private staging region
     const int ncol0 = n0 + wn * 32 * NJ;
     if (!f32_out) {
@@ -316,8 +342,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc
             finish(ncol0 + j * 32 + q * 8 + 4 * hl, v, true);
             const int r = i * 32 + l31, c = j * 8 + q * 2 + hl;
             *reinterpret_cast<uint2*>(cw + r * RB + ((c ^ (r & (NS8 - 1))) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            // 4-wave kernel: the accumulators sit in AGPRs; without a fence the scheduler hoists all 256 reads and spills
+            if constexpr (NJ == 4) __builtin_amdgcn_sched_barrier(0);
           }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (NJ == 4) W4_TR(6);
       constexpr int LPR = RB / 16, RPI = 64 / LPR;  // lanes per row, rows per wave-instruction
       bf16_t* ob = reinterpret_cast<bf16_t*>(P.out);
 #pragma unroll
@@ -328,14 +357,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc
         if (r & 1) d = make_uint4(d.z, d.w, d.x, d.y);  // odd rows hold the slot pair swapped
         const int m = m0 + wm * 128 + r;
         if (m < P.M) *reinterpret_cast<uint4*>(ob + (int64_t)m * P.ldo + ncol0 + ch * 8) = d;
+        if constexpr (NJ == 4) {
+          if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the scheduler's hoisting (register pressure -> spills)
+        }
       }
     } else {
       constexpr int RBF = 128 * NJ;  // bytes per staged row (32*NJ f32)
       constexpr int NS16 = 8 * NJ;   // 16-byte slots per row
       constexpr int LPR = RBF / 16, RPI = 64 / LPR;
       float* of = reinterpret_cast<float*>(P.out);
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
+      // (explicit instantiation instead of a pragma: with 128-wide wave tiles the optimizer refuses to unroll a loop
+      // this large, and a dynamically indexed accumulator array lives in scratch)
+      auto f32_pass = [&](auto pass_tag) {
+        constexpr int pass = decltype(pass_tag)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
@@ -349,6 +383,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc
               finish(ncol0 + j * 32 + q * 8 + 4 * hl, v, true);
               const int r = ii * 32 + l31, c = j * 8 + q * 2 + hl;
               *reinterpret_cast<float4*>(cw + r * RBF + ((c ^ (r & (NS16 - 1))) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+              if constexpr (NJ == 4) __builtin_amdgcn_sched_barrier(0);
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -372,15 +407,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc
             }
           }
         }
-      }
+      };
+      f32_pass(std::integral_constant<int, 0>{});
+      f32_pass(std::integral_constant<int, 1>{});
     }
     return;
   }
   // ---- direct path (ragged N tile, unaligned output, bf16 residual add)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  auto direct_rows = [&](auto i_tag) {
+    constexpr int i = decltype(i_tag)::value;
     const int m = m0 + wm * 128 + i * 32 + l31;
-    if (m >= P.M) continue;
+    if (m >= P.M) return;
     const float* gate = P.gate;
     if (epi == EPI_RESID_GATE_F32 && P.rows_per_batch > 0) gate += (int64_t)(m / P.rows_per_batch) * P.gate_bstride;
 #pragma unroll
@@ -410,7 +447,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc
         }
       }
     }
+  };
+  direct_rows(std::integral_constant<int, 0>{});
+  direct_rows(std::integral_constant<int, 1>{});
+  direct_rows(std::integral_constant<int, 2>{});
+  direct_rows(std::integral_constant<int, 3>{});
+}
+
+template <int NJ, int WN = 4, int ACT = -1>
+__device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc)[4][NJ], char* smem, int m0, int n0, int wave, int lane) {
+  if constexpr (NJ == 2 && WN == 4) {
+    if (P.qk_qh != nullptr && n0 < 3 * P.qk_D) {
+      qkv_relayout_epilogue(P, acc, smem, m0, n0, wave, lane);
+      return;
+    }
   }
+  gemm_epilogue_impl<NJ, WN, ACT>(P, acc, smem, m0, n0, wave, lane);
+}
+// the activation kind a launch group needs (all problems of a group must agree, else the run-time kind 3)
+inline int epilogue_kind(const GemmProblem* p, int n) {
+  auto kind = [](int epi) { return (epi == EPI_STORE_BF16 || epi == EPI_RESID_GATE_F32) ? 0 : epi == EPI_GELU_BF16 ? 1 : epi == EPI_GELU_FROM_COL ? 2 : 3; };
+  const int k = kind(p[0].epi);
+  for (int i = 1; i < n; ++i)
+    if (kind(p[i].epi) != k) return 3;
+  return k;
 }
 
 // MODE 0: dense GEMM, 1: 4-bit weights, 2: implicit-GEMM convolution (NHWC)
@@ -646,7 +706,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
 // which they do: both tiles have the same LDS layout and are read with the same offsets.
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
-template <bool FP8>
+template <bool FP8, int ACT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatch batch) {
   constexpr int NJ = 2, BN = 256;
   constexpr int ES = FP8 ? 1 : 2;  // operand element size
@@ -871,10 +931,255 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
           for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] *= sa[i] * sn[c];
       }
   }
-  gemm_epilogue<NJ>(P, acc, smem, m0, n0, wave, lane);
+  gemm_epilogue<NJ, 4, ACT>(P, acc, smem, m0, n0, wave, lane);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Dense 256x256x64 kernel, 4 waves (one per SIMD), 128 x 128 of C per wave in 256 accumulator registers.
+//
+// Why: the 8-wave kernels give each wave 128 x 64 of C, so per K tile the CU reads (128 + 64) * 64 * 2 B * 8
+// = 192 KiB of fragments out of LDS on top of the 64 KiB the DMA writes into it: 256 KiB at the LDS's
+// 128 B/clk = 2048 clocks, the same as the 2048 MFMA clocks of the tile — the LDS port, not the matrix pipe
+// or the memory side, is what the ping-pong kernel's 2830 clocks per K tile run into.  A 128 x 128 wave tile
+// reads (128 + 128) * 64 * 2 B * 4 = 128 KiB: 25 % less LDS traffic for the same FLOPs.  It needs 256
+// accumulator registers per wave, i.e. the 512-register budget of ONE wave per SIMD, so there is no second
+// wave to hide latencies behind: everything is software-pipelined inside the wave —
+//   * fragments of k-step s+1 are read (inline-asm ds_read_b128, one per MFMA) while the 16 MFMAs of step s
+//     issue; two fragment buffers (64 VGPRs);
+//   * one barrier per K tile, between the MFMA blocks of steps 2 and 3, after this tile's last fragment read:
+//     it frees the tile's LDS slots and publishes tile t+1; the 16 DMA pieces of A(t+2) / W(t+3) and the
+//     step-0 reads of tile t+1 are then issued one per MFMA of step 3.
+// LDS: A ring of 2 + W ring of 3 tiles of 32 KiB (same image, swizzle and DMA pieces as the other kernels).
+// Accumulation order per output element is that of the other kernels: bit-identical results.
+constexpr int W4_THREADS = 256;
+template <bool FP8, int ACT>
+__global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch batch) {
+  constexpr int NJ = 4, BN = 256;
+  constexpr int A_RING = 0, W_RING = 2 * A_TILE_BYTES, TILE = A_TILE_BYTES;
+  constexpr int ES = FP8 ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) char smem[5 * TILE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int total = batch.tile_start[batch.nprob];
+  const int lid = xcd_remap(blockIdx.x, total);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_PROBLEMS; ++i)
+    if (i < batch.nprob && lid >= batch.tile_start[i]) pi = i;
+  const GemmProblem& P = batch.p[pi];
+  const int t_in = lid - batch.tile_start[pi];
+  const int tiles_m = (P.M + BM - 1) / BM;
+  const int tiles_n = (P.N + BN - 1) / BN;
+  constexpr int GH = FMI_GH;
+  const int band = t_in / (GH * tiles_n);
+  const int band_h = min(GH, tiles_m - band * GH);
+  const int tin = t_in - band * GH * tiles_n;
+  const int tn = tin / band_h, tm = band * GH + tin % band_h;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = P.K * ES / (BK * 2);
+
+  f32x16 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int sw = ((lane & 31) >> 1) & 7;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+  uint32_t koff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + (lane >> 5)) ^ sw) << 4;
+  const uint32_t a_row = lds0 + A_RING + (wm * 128 + (lane & 31)) * 128;
+  const uint32_t w_row = lds0 + W_RING + (wn * 128 + (lane & 31)) * 128;
+
+  // DMA pieces of this wave: 1-KiB chunks wave*8 + i of the A tile and of the W tile
+  uint32_t a_off[8], w_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = (wave * 8 + i) * 8 + (lane >> 3);
+    a_off[i] = (uint32_t)((int64_t)min(m0 + r, P.M - 1) * P.lda * ES + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+    w_off[i] = (uint32_t)((int64_t)min(n0 + r, P.N - 1) * P.ldw * ES + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+  }
+  const char* const a_base = reinterpret_cast<const char*>(P.A);
+  const char* const w_base = reinterpret_cast<const char*>(P.W);
+  auto dma_a = [&](int kt, int i) {
+    const char* base = a_base + (int64_t)kt * (BK * 2);
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + a_off[i]), (lds_void*)(smem + A_RING + (kt & 1) * TILE + (wave * 8 + i) * 1024), 16, 0, FMI_AUX_A);
+  };
+  auto dma_w = [&](int kt, int slot, int i) {
+    const char* base = w_base + (int64_t)kt * (BK * 2);
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + w_off[i]), (lds_void*)(smem + W_RING + slot * TILE + (wave * 8 + i) * 1024), 16, 0, FMI_AUX_W);
+  };
+  auto sync_all = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue, in the order the steady-state vmcnt arithmetic expects: A(0), W(0), W(1), A(1)
+  W4_TR(0);
+  const int klast = nk - 1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_a(0, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_w(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_w(min(1, klast), 1, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_a(min(1, klast), i);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  sync_all();
+
+  typedef __attribute__((ext_vector_type(4))) int frag_t;  // 16 bytes: 8 bf16 of one row
+  frag_t xf[4][4], wf[4][4];  // fragment buffer s holds k-step s of a tile (read two steps ahead of its MFMAs)
+  // LDS read addresses: one VGPR per (operand, k-step), rebased once per tile; the row block is the immediate offset
+  uint32_t a_ad[4], w_ad[4];
+  auto rebase = [&](int aslot, int wslot_) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      a_ad[s] = a_row + koff[s] + aslot * TILE;
+      w_ad[s] = w_row + koff[s] + wslot_ * TILE;
+    }
+  };
+#define FMI_W4_RD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+  auto read_frag = [&](int s, int which) {  // k-step s (= buffer s); which: 0..3 = A row block i, 4..7 = W row block j
+    switch (which) {
+      case 0: FMI_W4_RD(xf[s][0], a_ad[s], 0); break;
+      case 1: FMI_W4_RD(xf[s][1], a_ad[s], 4096); break;
+      case 2: FMI_W4_RD(xf[s][2], a_ad[s], 8192); break;
+      case 3: FMI_W4_RD(xf[s][3], a_ad[s], 12288); break;
+      case 4: FMI_W4_RD(wf[s][0], w_ad[s], 0); break;
+      case 5: FMI_W4_RD(wf[s][1], w_ad[s], 4096); break;
+      case 6: FMI_W4_RD(wf[s][2], w_ad[s], 8192); break;
+      default: FMI_W4_RD(wf[s][3], w_ad[s], 12288); break;
+    }
+  };
+  // LDS reads retire in order: with the 8 reads of the following step allowed to be pending, this step's have landed.
+  // The "+v" ties make the fragments depend on the wait so no MFMA is scheduled above it.
+#define FMI_W4_WAIT(N, s)                                                                                                                    \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                                   \
+               : "+v"(xf[s][0]), "+v"(xf[s][1]), "+v"(xf[s][2]), "+v"(xf[s][3]), "+v"(wf[s][0]), "+v"(wf[s][1]), "+v"(wf[s][2]), "+v"(wf[s][3]))
+  auto mfma = [&](int s, int i, int j) {
+#ifndef FMI_W4_NO_MFMA
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[s][j]), __builtin_bit_cast(bf16x8_t, xf[s][i]), acc[i][j], 0, 0, 0);
+#else
+    acc[i][j][0] += __builtin_bit_cast(f32x4, wf[s][j])[0] + __builtin_bit_cast(f32x4, xf[s][i])[1];
+#endif
+  };
+
+  W4_TR(1);
+  // steps 0 and 1 of tile 0
+  rebase(0, 0);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) read_frag(0, w);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) read_frag(1, w);
+  int wslot = 0;  // W slot of tile t = t % 3
+  // Branch-free body: past the end of K the DMA re-fetches the last tile into slots nobody reads again, and the
+  // fragment reads of the "next tile" fetch garbage nobody multiplies; every count below is the same for all t.
+  // (A separate tail loop made hipcc park all 256 accumulators in scratch across the loop boundary.)
+  //   step 0, 1 : reads of steps 2, 3 (every other MFMA); W(t+2) -> slot (t+2)%3, free since barrier(t-1) (every 4th MFMA)
+  //   step 2    : 4 MFMAs; all of this tile's reads are in -> vmcnt(8): A(t+1), W(t+1) landed -> BARRIER(t);
+  //               then reads of tile t+1 step 0; A(t+2) -> slot t&1 (4 pieces)
+  //   step 3    : reads of tile t+1 step 1; A(t+2) (4 pieces)
+  for (int t = 0; t < nk; ++t) {
+    const int wnext = wslot == 2 ? 0 : wslot + 1;   // W slot of tile t+1
+    const int wnn = wnext == 2 ? 0 : wnext + 1;     // W slot of tile t+2
+    const int kt2 = min(t + 2, klast);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s == 0) FMI_W4_WAIT(8, 0); else FMI_W4_WAIT(8, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        mfma(s, q >> 2, q & 3);
+        if ((q & 1) == 0) read_frag(s + 2, q >> 1);
+#ifndef FMI_W4_NO_DMA
+        if ((q & 3) == 1) dma_w(kt2, wnn, (s * 16 + q) >> 2);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    FMI_W4_WAIT(8, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if (q == 4) {
+        FMI_W4_WAIT(0, 3);  // the tile's last reads are in: its LDS slots are free
+#ifndef FMI_W4_NO_DMA
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // oldest first: ..., A(t+1) x8, W(t+2) x8
+#endif
+#ifndef FMI_W4_NO_BARRIER
+        sync_all();
+#endif
+        rebase((t + 1) & 1, wnext);
+      }
+      mfma(2, q >> 2, q & 3);
+      if (q >= 8) read_frag(0, q - 8);
+#ifndef FMI_W4_NO_DMA
+      if (q >= 9 && (q & 1)) dma_a(kt2, (q - 9) >> 1);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      mfma(3, q >> 2, q & 3);
+      if ((q & 1) == 0) read_frag(1, q >> 1);
+#ifndef FMI_W4_NO_DMA
+      if ((q & 3) == 3) dma_a(kt2, 4 + (q >> 2));
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wslot = wnext;
+  }
+  W4_TR(2);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the trailing dummy DMA / reads must not land in the epilogue's staging
+  W4_TR(3);
+#undef FMI_W4_RD
+#undef FMI_W4_WAIT
+  // The wave's 128 x 128 leaves as two 128 x 64 halves through the 8-wave epilogue: half h plays wave (wm, 2*wn + h)
+  // of the 2 x 4 layout (same staging regions, same stores).
+  // Launder the lane id: everything the epilogue derives from it is then computed after the loop instead of being
+  // hoisted above it, kept live across 256 arch VGPRs of loop state, spilled, and reloaded (each reload = vmcnt(0) = the
+  // wave's stores serialised: measured 30 us per tile instead of 12).
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  // The wave's 128 x 128 leaves in two rounds through the 8-wave epilogue: in round r its column half r plays wave
+  // (wm, 2*wn + r) of the 2 x 4 layout (same staging regions, same stores, same arithmetic).  A real loop, not two inlined
+  // copies: the unrolled epilogue is large, and twice that code (or its 128-wide instantiation) runs out of the
+  // instruction cache and, with the accumulators filling the AGPRs, spills (measured 3-4x slower).
+  {
+    f32x16 hacc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][0], hacc[i][1] = acc[i][1];
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < 2; ++r) {
+      gemm_epilogue<2, 4, ACT>(P, hacc, smem, m0, n0, wm * 4 + wn * 2 + r, lane_e);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][2], hacc[i][1] = acc[i][3];
+      asm volatile("" : "+v"(lane_e));  // keep the second round's address math out of the first
+    }
+  }
+  W4_TR(4);
 }
 
 static bool g_pingpong = true;
+// Default OFF.  Stand-alone (tools/gemm_bench) the 4-wave kernel is 3-9 % faster than the ping-pong kernel on the FLUX
+// shapes it is eligible for, bit-identical; inside the denoise loop the step time does not move (74.4-74.6 ms either way,
+// A/B on one box) because the part is power-capped: with the 4-wave kernel in the mix every kernel — including the
+// attention and QKV launches that do not use it — runs ~2-3 % slower.  FMI_GEMM_W4=1 in the environment (or
+// set_gemm_w4) enables it for the eligible launches; see DESIGN.md 4.1.
+static bool g_w4 = [] {
+  const char* e = getenv("FMI_GEMM_W4");
+  return e ? atoi(e) != 0 : false;
+}();
+void set_gemm_w4(bool on) { g_w4 = on; }
 void set_gemm_pingpong(bool on) { g_pingpong = on; }
 
 int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
@@ -919,17 +1224,36 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
     else                                                                                    \
       hipLaunchKernelGGL((gemm_bf16_kernel<MODE, 2>), grid, blk, 0, stream, b);             \
   } while (0)
+  const int act = epilogue_kind(probs, nprob);
+  // 4-wave kernel: its K loop is 7-10 % faster, its two-round epilogue slower — measured break-even (tools/gemm_bench,
+  // FMI_EPI=store|gelu|resid): always for bf16 stores / GELU, for the f32 residual read-modify-write only at long K.
+  // The fused q|k|v relayout epilogue exists for the 8-wave layout only.
+  bool w4_pays = !fp8 && !conv && !quant;
+  for (int i = 0; i < nprob; ++i) {
+    const GemmProblem& p = probs[i];
+    if (p.qk_qh || ((p.epi == EPI_RESID_GATE_F32 || p.epi == EPI_STORE_F32) && p.K < 8192)) w4_pays = false;
+  }
+#define FMI_ACT_LAUNCH(KERNEL, FP8FLAG, THREADS)                                                    \
+  do {                                                                                              \
+    if (act == 0) hipLaunchKernelGGL((KERNEL<FP8FLAG, 0>), grid, dim3(THREADS), 0, stream, b);      \
+    else if (act == 1) hipLaunchKernelGGL((KERNEL<FP8FLAG, 1>), grid, dim3(THREADS), 0, stream, b); \
+    else if (act == 2) hipLaunchKernelGGL((KERNEL<FP8FLAG, 2>), grid, dim3(THREADS), 0, stream, b); \
+    else hipLaunchKernelGGL((KERNEL<FP8FLAG, 3>), grid, dim3(THREADS), 0, stream, b);               \
+  } while (0)
   if (fp8)
-    hipLaunchKernelGGL(gemm_pp_kernel<true>, grid, blk, 0, stream, b);
+    FMI_ACT_LAUNCH(gemm_pp_kernel, true, GEMM_THREADS);
   else if (conv)
     FMI_GEMM_LAUNCH(2);
   else if (quant)
     FMI_GEMM_LAUNCH(1);
+  else if (bn == 256 && g_w4 && w4_pays)
+    FMI_ACT_LAUNCH(gemm_w4_kernel, false, W4_THREADS);
   else if (bn == 256 && g_pingpong)
-    hipLaunchKernelGGL(gemm_pp_kernel<false>, grid, blk, 0, stream, b);
+    FMI_ACT_LAUNCH(gemm_pp_kernel, false, GEMM_THREADS);
   else
     FMI_GEMM_LAUNCH(0);
 #undef FMI_GEMM_LAUNCH
+#undef FMI_ACT_LAUNCH
   FMI_LAUNCH_CHECK();
   return FMI_OK;
 }

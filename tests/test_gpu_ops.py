@@ -290,3 +290,40 @@ def test_empty_and_null_inputs_fail_cleanly(env):
     va = d.AutoEncoderKl(SMALL_VAE)
     with pytest.raises(d.FmiError):
         va.decode(torch.zeros((1, 16, 4, 4), device="cuda"))  # decoder weights missing
+
+
+def test_gemm_4wave_kernel_is_bit_identical(tmp_path):
+    """FMI_GEMM_W4=1 routes eligible dense launches (N > 128, bf16 store / GELU epilogue, or f32 residual at K >= 8192)
+    to the 4-wave 128x128-per-wave kernel (default off: no in-model gain under the power cap).  Same
+    accumulation order as the ping-pong kernel -> the outputs must be bit-identical.  The switch is read when the
+    library loads, so each setting runs in its own process."""
+    import subprocess
+    import sys
+    script = r'''
+import ctypes as C, sys, numpy as np, torch
+sys.path.insert(0, ".")
+from diffusion_rs_amd import _lib as L
+lib = L.load()
+p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+out = {}
+g = torch.Generator(device="cuda").manual_seed(0)
+for (M, N, K, epi) in [(300, 384, 256, 0), (1000, 260, 64, 0), (257, 1024, 1280, 1), (4608, 3072, 3072, 0), (512, 12288, 3072, 1), (4096, 3072, 12288, 0)]:
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.fmi_linear_bf16(p(x), p(w), p(b), p(y), M, N, K, epi, None))
+    torch.cuda.synchronize()
+    out[f"{M}x{N}x{K}e{epi}"] = y.view(torch.int16).cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for v in ("0", "1"):
+        path = str(tmp_path / f"w4_{v}.npz")
+        env = dict(os.environ, FMI_GEMM_W4=v)
+        subprocess.run([sys.executable, "-c", script, path], check=True, cwd=root, env=env, timeout=600)
+        res[v] = np.load(path)
+    for k in res["0"].files:
+        np.testing.assert_array_equal(res["0"][k], res["1"][k], err_msg=k)

@@ -3,6 +3,7 @@
 // Prints TFLOP/s per FLUX shape on random bf16 data (never zero-filled: DVFS, cdna guide rule 25).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../diffusion-rs_amd/csrc/gemm_bf16.hip"
@@ -67,16 +68,35 @@ int main(int argc, char** argv) {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   bf16_t* O2;
-  hipMalloc((void**)&O2, maxO * 2);
+  const char* epi_env = getenv("FMI_EPI");  // store (default) | gelu | resid
+  const int epi_kind = !epi_env ? 0 : !strcmp(epi_env, "gelu") ? 1 : !strcmp(epi_env, "resid") ? 2 : 0;
+  const size_t out_es = epi_kind == 2 ? 4 : 2;
+  hipFree(O);
+  hipMalloc((void**)&O, maxO * out_es);
+  hipMalloc((void**)&O2, maxO * out_es);
+  float* gate;
+  hipMalloc((void**)&gate, 65536 * 4);
+  {
+    std::vector<float> g(65536, 0.5f);
+    hipMemcpy(gate, g.data(), g.size() * 4, hipMemcpyHostToDevice);
+  }
+  bf16_t* bias;
+  hipMalloc((void**)&bias, 65536 * 2);
+  fill_kernel<<<64, 256>>>(bias, 65536, 3u);
+  printf("epilogue: %s\n", epi_kind == 1 ? "bias + GELU -> bf16" : epi_kind == 2 ? "f32 residual += gate * (acc + bias)" : "store bf16");
   unsigned long long* d_mis;
   hipMalloc((void**)&d_mis, 8);
   for (auto& s : shapes) {
     GemmProblem p{};
-    p.A = A, p.W = W, p.out = O, p.M = s.M, p.N = s.N, p.K = s.K, p.lda = s.K + pad_a, p.ldw = s.K + pad_w, p.ldo = s.N + pad_o, p.epi = EPI_STORE_BF16, p.alpha = 1.f;
-    double tf[2];
-    for (int pp = 0; pp < 2; ++pp) {  // double-buffered kernel, then the ping-pong kernel
+    p.A = A, p.W = W, p.out = O, p.M = s.M, p.N = s.N, p.K = s.K, p.lda = s.K + pad_a, p.ldw = s.K + pad_w, p.ldo = s.N + pad_o, p.epi = epi_kind == 1 ? EPI_GELU_BF16 : epi_kind == 2 ? EPI_RESID_GATE_F32 : EPI_STORE_BF16, p.alpha = 1.f;
+    if (epi_kind) p.bias = bias;
+    if (epi_kind == 2) p.gate = gate;
+    double tf[3];
+    for (int pp = 0; pp < 3; ++pp) {  // double-buffered kernel, the ping-pong kernel, the 4-wave kernel
       set_gemm_pingpong(pp != 0);
-      p.out = pp ? O2 : O;
+      set_gemm_w4(pp == 2);
+      p.out = pp == 1 ? O : O2;
+      if (epi_kind == 2) hipMemsetAsync(p.out, 0, (size_t)s.M * p.ldo * 4, nullptr);
       for (int i = 0; i < 2; ++i) launch_gemm(&p, 1, nullptr);
       hipDeviceSynchronize();
       hipEventRecord(e0, nullptr);
@@ -88,12 +108,19 @@ int main(int argc, char** argv) {
       ms /= iters;
       tf[pp] = 2.0 * s.M * s.N * s.K / (ms * 1e-3) / 1e12;
     }
+#ifdef FMI_W4_TRACE
+    {
+      long long h[64 * 8];
+      hipMemcpyFromSymbol(h, HIP_SYMBOL(fmi::g_w4_trace), sizeof(h));
+      for (int b : {0, 7, 33}) printf("   w4 trace block %2d (clock64 ticks): prologue %lld  loop %lld  drain %lld  epilogue %lld (sync %lld, staging %lld, stores %lld)\n", b, h[b * 8 + 1] - h[b * 8 + 0], h[b * 8 + 2] - h[b * 8 + 1], h[b * 8 + 3] - h[b * 8 + 2], h[b * 8 + 4] - h[b * 8 + 3], h[b * 8 + 5] - h[b * 8 + 3], h[b * 8 + 6] - h[b * 8 + 5], h[b * 8 + 4] - h[b * 8 + 6]);
+    }
+#endif
     hipMemset(d_mis, 0, 8);
-    count_mismatch<<<1024, 256>>>(O, O2, (size_t)s.M * p.ldo, d_mis);
+    count_mismatch<<<1024, 256>>>(O, O2, (size_t)s.M * p.ldo * (out_es / 2), d_mis);  // resid: both accumulated the same number of launches
     unsigned long long mis = 0;
     hipMemcpy(&mis, d_mis, 8, hipMemcpyDeviceToHost);
-    printf("%-18s M=%5d N=%5d K=%5d  tiles %5d  double-buffered %7.1f TF   ping-pong %7.1f TF (%7.1f us)   mismatching elements %llu%s\n", s.name, s.M, s.N, s.K,
-           ((s.M + 255) / 256) * ((s.N + 255) / 256), tf[0], tf[1], 2.0 * s.M * s.N * s.K / tf[1] * 1e-6, mis,
+    printf("%-18s M=%5d N=%5d K=%5d  tiles %5d  double-buffered %7.1f TF   ping-pong %7.1f TF (%7.1f us)   4-wave %7.1f TF (%7.1f us)   4-wave vs ping-pong mismatching elements %llu%s\n", s.name, s.M, s.N, s.K,
+           ((s.M + 255) / 256) * ((s.N + 255) / 256), tf[0], tf[1], 2.0 * s.M * s.N * s.K / tf[1] * 1e-6, tf[2], 2.0 * s.M * s.N * s.K / tf[2] * 1e-6, mis,
            hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
   }
   return 0;

@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Yardstick only (not on the product path): what does the vendor library (hipBLASLt behind torch.matmul) reach for the
+FLUX block-linear shapes on this box, next to this library's kernel?  bf16, y = x @ W^T, 20 launches each."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from diffusion_rs_amd import _lib as L  # noqa: E402
+
+lib = L.load()
+shapes = [(4608, 21504, 3072, "single linear1"), (4608, 3072, 15360, "single linear2"), (4096, 9216, 3072, "double qkv img"),
+          (4096, 12288, 3072, "double mlp1 img"), (4096, 3072, 12288, "double mlp2 img"), (4096, 4096, 15360, "256 tiles"), (8192, 8192, 8192, "8k cube")]
+p = lambda t: C.c_void_p(t.data_ptr())
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+for M, N, K, name in shapes:
+    x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    wt = w.t()
+    t_lt = timeit(lambda: torch.matmul(x, wt, out=y))
+    t_me = timeit(lambda: L.check(lib.fmi_linear_bf16(p(x), p(w), None, p(y), M, N, K, 0, None)))
+    fl = 2.0 * M * N * K
+    print(f"{name:18s} M={M:5d} N={N:5d} K={K:5d}   hipBLASLt {fl / t_lt / 1e9:7.1f} TF ({t_lt * 1e3:6.1f} us)   this library {fl / t_me / 1e9:7.1f} TF ({t_me * 1e3:6.1f} us)", flush=True)
