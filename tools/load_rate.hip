@@ -46,9 +46,10 @@ __global__ __launch_bounds__(WAVES * 64) void k(const char* __restrict src, int 
   if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
 }
 
+static int g_scale = 1;
 template <int MODE, int WAVES>
 void run(const char* name, const char* src, size_t ws, int* sink, long long* clk, int ncu) {
-  const int iters = 2000;
+  const int iters = 2000 * g_scale;
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
   hipLaunchKernelGGL((k<MODE, WAVES>), dim3(ncu), dim3(WAVES * 64), 0, 0, src, 50, ws, sink, clk);
@@ -69,7 +70,10 @@ void run(const char* name, const char* src, size_t ws, int* sink, long long* clk
          avg / instr_per_cu, ms * 1e6 / instr_per_cu, 1024.0 / (ms * 1e6 / instr_per_cu), 1024.0 * instr_per_cu * ncu / (ms * 1e-3) / 1e12);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  // load_rate [scale] [ws_kib]: scale multiplies the iteration count (power probes), ws_kib restricts to one working-set size
+  g_scale = argc > 1 ? atoi(argv[1]) : 1;
+  const size_t only_ws = argc > 2 ? (size_t)atoi(argv[2]) << 10 : 0;
   const int ncu = 256;
   const size_t maxws = 4 << 20;
   char* src;
@@ -80,6 +84,7 @@ int main() {
   hipMalloc((void**)&sink, 64);
   hipMalloc((void**)&clk, sizeof(long long) * 1024);
   for (size_t ws : {(size_t)64 << 10, (size_t)512 << 10, (size_t)4 << 20}) {
+    if (only_ws && ws != only_ws) continue;
     run<0, 8>("global_load_dwordx4 -> VGPR", src, ws, sink, clk, ncu);
     run<1, 8>("global_load_lds_dwordx4", src, ws, sink, clk, ncu);
     run<0, 4>("global_load_dwordx4 -> VGPR", src, ws, sink, clk, ncu);
