@@ -277,7 +277,14 @@ __device__ long long g_att_trace[8 * 64];
 #else
 #define ATT_TR(k) do {} while (0)
 #endif
-template <int THR_X16>
+// QK8 = true (fp8 mode of the model): Q and K arrive as OCP e4m3 bytes (rows of 128 B, static scales folded
+// into scale_log2e by the caller) and S^T = K Q^T runs on v_mfma_f32_32x32x64_f8f6f4: 4 MFMAs of 64 clocks per tile instead
+// of 16 of 32.  The K tile is 64 x 128 B (one DMA piece per wave, 16-byte slots XOR-swizzled with row & 7); a lane's
+// operand is the 32 contiguous bytes of its row half, fetched by two ds_read_b128 at the start of the M phase, ahead of
+// the hand-pipelined PV reads.  Softmax, P (bf16) and PV are unchanged.
+typedef __attribute__((ext_vector_type(4))) int att_i32x4;
+typedef __attribute__((ext_vector_type(8))) int att_i32x8;
+template <int THR_X16, bool QK8>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16_t* __restrict Q, const bf16_t* __restrict K,
                                                                        const bf16_t* __restrict Vt, AttnOut out, int H, int Lq, int Lk,
                                                                        int Lkpad, float scale_log2e) {
@@ -299,12 +306,20 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
   const bf16_t* Vb = Vt + (int64_t)bh * HD * Lkpad;
 
   bf16x8_t qf[8];
+  att_i32x8 qq[2];  // QK8: the lane's 32 bytes of each 64-wide d step
   {
     int qr = q0 + l31;
     qr = qr > Lq - 1 ? Lq - 1 : qr;
-    const bf16_t* qp = Q + ((int64_t)bh * Lq + qr) * HD + 8 * hl;
+    if constexpr (QK8) {
+      const uint8_t* qp = reinterpret_cast<const uint8_t*>(Q) + ((int64_t)bh * Lq + qr) * HD + 32 * hl;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * s);
+      for (int s = 0; s < 2; ++s)
+        qq[s] = __builtin_shufflevector(*reinterpret_cast<const att_i32x4*>(qp + 64 * s), *reinterpret_cast<const att_i32x4*>(qp + 64 * s + 16), 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+      const bf16_t* qp = Q + ((int64_t)bh * Lq + qr) * HD + 8 * hl;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * s);
+    }
   }
   f32x16 ot[4];
 #pragma unroll
@@ -318,11 +333,21 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
   //   K tile  [64][128] bf16: row l31, 16-B slot (2s + hl) ^ (lane & 15)  ==  k_off0 ^ (s << 5)
   //   Vt tile [128][64] bf16: row l31, 16-B slot (2c' + hl) ^ ((l31>>1)&7) ==  v_off0 ^ (c' << 5)
   const int k_off0 = l31 * 256 + ((hl ^ (lane & 15)) << 4);
+  //   K tile  [64][128] e4m3 (QK8): row l31, 16-B slots (4s + 2hl + j) ^ (l31 & 7)  ==  k8_off0 ^ (s << 6) ^ (j << 4)
+  const int k8_off0 = l31 * 128 + (((2 * hl) ^ (l31 & 7)) << 4);
   const int v_off0 = l31 * 128 + ((hl ^ ((l31 >> 1) & 7)) << 4);
 
   auto stage_k = [&](int tile) {
     char* kd = smem + (tile & 3) * 16384;
     const int kv0 = tile * ATT_KV;
+    if constexpr (QK8) {  // 64 rows x 128 B = 8 pieces of 8 rows: one per wave
+      const int row = wave * 8 + (lane >> 3);
+      int kr = kv0 + row;
+      kr = kr > Lk - 1 ? Lk - 1 : kr;
+      const uint8_t* src = reinterpret_cast<const uint8_t*>(K) + ((int64_t)bh * Lk + kr) * HD + (((lane & 7) ^ (row & 7)) << 4);
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(kd + wave * 1024), 16, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int chunk = wave * 2 + i;
@@ -366,10 +391,19 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
   for (int u = 0; u < 2; ++u) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[u][r] = 0.f;
+    if constexpr (QK8) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(smem + u * 32 * 256 + (k_off0 ^ (s << 5)));
-      sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc[u], 0, 0, 0);
+      for (int s = 0; s < 2; ++s) {
+        const att_i32x8 kf = __builtin_shufflevector(*reinterpret_cast<const att_i32x4*>(smem + u * 32 * 128 + (k8_off0 ^ (s << 6))),
+                                                     *reinterpret_cast<const att_i32x4*>(smem + u * 32 * 128 + (k8_off0 ^ (s << 6) ^ 16)), 0, 1, 2, 3, 4, 5, 6, 7);
+        sc[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qq[s], sc[u], 0, 0, 0, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(smem + u * 32 * 256 + (k_off0 ^ (s << 5)));
+        sc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc[u], 0, 0, 0);
+      }
     }
   }
   if (g == 1) slot_barrier();  // group 1 runs one slot behind
@@ -441,8 +475,20 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
     {
       const char* vl = smem + VT_RING + (t & 3) * 16384;
       const char* kl = smem + ((t + 1) & 3) * 16384;
-      constexpr int NSTEP = MORE ? 32 : 16;
+      constexpr int NSTEP = (MORE && !QK8) ? 32 : 16;
       bf16x8_t fr[ATT_PF];
+      // QK8: the four K(t+1) operands (2 key blocks x 2 d steps) are requested first; they are older than every PV read, so
+      // the in-order lgkmcnt arithmetic below is unchanged, and they have the whole PV phase to land
+      att_i32x8 kq[2][2];
+      if constexpr (QK8 && MORE) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+            kq[u][s2] = __builtin_shufflevector(*reinterpret_cast<const att_i32x4*>(kl + u * 32 * 128 + (k8_off0 ^ (s2 << 6))),
+                                                *reinterpret_cast<const att_i32x4*>(kl + u * 32 * 128 + (k8_off0 ^ (s2 << 6) ^ 16)), 0, 1, 2, 3, 4, 5, 6, 7);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // Step order: consecutive MFMAs never hit the same accumulator (a dependent 32x32 MFMA cannot
       // issue until the previous one has drained: 4- and 8-long chains ran the phase at half rate).
       // PV steps walk dt fastest (4 accumulators), QK steps walk u fastest (2 accumulators); the
@@ -495,14 +541,26 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
         if (i + ATT_PF < NSTEP) load(i + ATT_PF, fr[i % ATT_PF]);
         __builtin_amdgcn_sched_barrier(0);  // keep the read-ahead distance: one read issued per MFMA
       }
+      if constexpr (QK8 && MORE) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[u][r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) sc[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kq[u][s2], qq[s2], sc[u], 0, 0, 0, 0, 0, 0);
+      }
     }
     ATT_TR(3);
 #ifdef ATT_PP_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
     // everything older than the pieces issued in this tile's V phase must have landed
-    if (t + 3 < ntiles)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (t + 3 < ntiles) {
+      if constexpr (QK8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // K(t+3) is one piece per wave here
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
     else if (t + 2 < ntiles)
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else
@@ -542,16 +600,21 @@ static bool g_att_pingpong = true;
 void set_attention_pingpong(bool on) { g_att_pingpong = on; }
 
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
-                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream) {
+                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8) {
   if (Lq <= 0 || Lk <= 0) return fail(FMI_ERR_INVALID, "attention: empty sequence");
   if (Lkpad % ATT_KV != 0 || Lkpad < Lk) return fail(FMI_ERR_INVALID, "attention: Lkpad must be a multiple of 64 and >= Lk");
   dim3 grid(cdiv(Lq, ATT_QBLK) * B * H);
   const float sl = scale * 1.4426950408889634f;
-  if (g_att_pingpong) {
+  if (qk_fp8) {
     if (rescale_thr_x16 == 0)
-      hipLaunchKernelGGL(attention_pp_kernel<0>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+      hipLaunchKernelGGL((attention_pp_kernel<0, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
     else
-      hipLaunchKernelGGL(attention_pp_kernel<96>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+      hipLaunchKernelGGL((attention_pp_kernel<96, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+  } else if (g_att_pingpong) {
+    if (rescale_thr_x16 == 0)
+      hipLaunchKernelGGL((attention_pp_kernel<0, false>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+    else
+      hipLaunchKernelGGL((attention_pp_kernel<96, false>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
   } else if (rescale_thr_x16 == 0)
     hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
   else

@@ -192,6 +192,28 @@ extern "C" int fmi_sdpa_bf16(const void* q, const void* k, const void* v, void* 
   return rc;
 }
 
+// q, k: e4m3 bytes (B,H,L,128) with any scales folded into `scale` by the caller; v, o bf16 as fmi_sdpa_bf16
+extern "C" int fmi_sdpa_fp8qk(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int d, float scale,
+                             int out_token_major, void* stream) {
+  if (!q || !k || !v || !o) return fail(FMI_ERR_INVALID, "sdpa_fp8qk: null pointer");
+  if (d != 128) return fail(FMI_ERR_UNSUPPORTED, "sdpa_fp8qk: head dim must be 128");
+  hipStream_t s = (hipStream_t)stream;
+  const int Lpad = (Lk + 63) / 64 * 64;
+  bf16_t* vt = nullptr;
+  const size_t vt_bytes = (size_t)B * H * 128 * Lpad * 2;
+  FMI_HIP_TRY(hipMalloc((void**)&vt, vt_bytes));
+  AttnOut ao{};
+  ao.p1 = (bf16_t*)o, ao.ld1 = H * 128, ao.bstride1 = (int64_t)Lq * H * 128, ao.head_major = out_token_major ? 0 : 1;
+  int rc = FMI_OK;
+  if (hipMemsetAsync(vt, 0, vt_bytes, s) != hipSuccess) rc = fail(FMI_ERR_HIP, "sdpa_fp8qk: memset failed");
+  // V (B,H,Lk,128) head-major == B*H "batches" of one head each
+  if (rc == FMI_OK) rc = launch_v_transpose((const bf16_t*)v, 128, (int64_t)Lk * 128, vt, B * H, 1, Lk, 0, Lpad, s);
+  if (rc == FMI_OK) rc = launch_attention_ex((const bf16_t*)q, (const bf16_t*)k, vt, ao, B, H, Lq, Lk, Lpad, scale, 96, s, 1);
+  hipStreamSynchronize(s);
+  hipFree(vt);
+  return rc;
+}
+
 extern "C" int fmi_layernorm_mod(const float* x, const float* scale, const float* shift, void* out_bf16, int rows, int D, float eps, void* stream) {
   if (!x || !out_bf16) return fail(FMI_ERR_INVALID, "layernorm_mod: null pointer");
   return launch_layernorm_mod(x, scale, shift, 0, 0, (bf16_t*)out_bf16, rows, D, eps, (hipStream_t)stream);

@@ -154,6 +154,10 @@ struct GemmProblem {
   const float* qk_pe;  // (B or 1, qk_Ltot, 64, {cos, sin}) f32
   int64_t qk_pe_bstride;
   int qk_H, qk_D, qk_rows, qk_row_off, qk_Ltot, qk_Lpad;
+  // fp8 attention operands (optional, qk_q8 > 0): q / k leave the relayout epilogue as OCP e4m3 bytes, value * qk_q8 /
+  // value * qk_k8 (static scales chosen so that sqrt(128) * max|norm weight| maps to 448), rows of 128 B in the same
+  // head-major order; qk_qh / qk_kh then point to byte buffers.  v is unchanged (bf16).
+  float qk_q8, qk_k8;
   // fp8 operands (optional, fp8 != 0; dense 256-wide N tiles only): A and W point to OCP e4m3 bytes,
   // K / lda / ldw count elements (= bytes, K % 128 == 0), and the f32 accumulator is multiplied by
   // a_scale[m] * w_scale[n] (per-token / per-output-channel dequantisation) before the epilogue.
@@ -177,8 +181,9 @@ struct AttnOut {
   int64_t bstride1;
   int head_major;
 };
+// qk_fp8 != 0: q and k are e4m3 bytes (B,H,L,128), QK^T runs on the fp8 MFMA (scale must already hold 1 / (q scale * k scale))
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
-                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream);
+                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8 = 0);
 void set_attention_pingpong(bool on);  // ping-pong kernel (default) or the single-barrier one
 // flash attention, d = 128.  q,k: (BH, L, 128) bf16; vt: (BH, 128, Lpad) bf16 with the kv axis
 // permuted inside each group of 16 (see attention.hip); out token-major (B, L, H*128) or (BH,L,128)

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <map>
 #include <set>
+#include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -106,6 +108,10 @@ struct fmi_flux {
   bool fp8 = false;
   char* fp8_arena = nullptr;
   size_t fp8_bytes = 0;
+  // fp8 attention operands (QK^T on the fp8 MFMA): static scales per block, 448 / (sqrt(128) * max|norm weight|) — a
+  // QkNorm'ed, rotated head vector has norm sqrt(128) * |w|, so no element can exceed the e4m3 range
+  bool fp8_attn = true;
+  std::vector<float> q8_dbl, k8_dbl, q8_sgl, k8_sgl;
 };
 
 namespace {
@@ -335,9 +341,14 @@ GemmProblem make_problem(const Dense& d, const bf16_t* A, int lda, int Mrows, vo
 }
 // Fused relayout epilogue of a [q|k|v](|mlp) projection (GemmProblem::qk_*); returns false if this
 // shape must take the stand-alone kernels (positions not 16-aligned, model width not 256-aligned).
-bool with_qkv_relayout(fmi_flux* m, GemmProblem& p, const bf16_t* nq, const bf16_t* nk, int64_t pe_bs, int rows, int row_off, int Ltot) {
+bool can_fuse_relayout(const fmi_flux* m, int Mrows, int rows, int row_off) {
+  return m->fuse_qkv_relayout && m->D % 256 == 0 && rows % 16 == 0 && row_off % 16 == 0 && Mrows % 16 == 0;
+}
+bool with_qkv_relayout(fmi_flux* m, GemmProblem& p, const bf16_t* nq, const bf16_t* nk, int64_t pe_bs, int rows, int row_off, int Ltot, float q8 = 0.f,
+                       float k8 = 0.f) {
   auto& w = m->ws;
-  if (!m->fuse_qkv_relayout || m->D % 256 || rows % 16 || row_off % 16 || p.M % 16 || p.N < 256) return false;
+  if (!can_fuse_relayout(m, p.M, rows, row_off) || p.N < 256) return false;
+  p.qk_q8 = q8, p.qk_k8 = k8;
   p.qk_qh = w.Qh, p.qk_kh = w.Kh, p.qk_vt = w.Vt;
   p.qk_wq = nq, p.qk_wk = nk;
   p.qk_pe = w.pe, p.qk_pe_bstride = pe_bs;
@@ -500,7 +511,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     const float* mt = mod + bw.mod_off[1];
     bf16_t* xm_txt = w.xm;
     bf16_t* xm_img = w.xm + (size_t)B * T * D;
-    bool fused_img = false, fused_txt = false;
+    bool fused_img = false, fused_txt = false, qk8 = false;
     {
       PhaseTimer pt(m, s, PH_LN);
       if (fp8) {
@@ -519,8 +530,11 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       p[1] = fp8 ? make_problem_fp8(m, bw.qkv[1], 0, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16)
                  : make_problem(bw.qkv[1], xm_txt, D, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16);
       // joint order [txt, img] (model.rs:540-542): txt tokens at positions [0,T), img at [T,T+S)
-      fused_img = with_qkv_relayout(m, p[0], bw.nq[0], bw.nk[0], pe_bs, S, T, L);
-      fused_txt = with_qkv_relayout(m, p[1], bw.nq[1], bw.nk[1], pe_bs, T, 0, L);
+      // fp8 attention operands only when BOTH streams take the fused epilogue (the stand-alone kernels write bf16)
+      qk8 = fp8 && m->fp8_attn && can_fuse_relayout(m, B * S, S, T) && can_fuse_relayout(m, B * T, T, 0);
+      const float q8 = qk8 ? m->q8_dbl[i] : 0.f, k8 = qk8 ? m->k8_dbl[i] : 0.f;
+      fused_img = with_qkv_relayout(m, p[0], bw.nq[0], bw.nk[0], pe_bs, S, T, L, q8, k8);
+      fused_txt = with_qkv_relayout(m, p[1], bw.nq[1], bw.nk[1], pe_bs, T, 0, L, q8, k8);
       FMI_TRY(gemm2(m, p, 2, s));
     }
     if (!(fused_img && fused_txt)) {
@@ -540,7 +554,8 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       AttnOut o{};
       o.p0 = w.attn_txt, o.rows0 = T, o.ld0 = D, o.bstride0 = (int64_t)T * D;
       o.p1 = w.attn_img, o.ld1 = D, o.bstride1 = (int64_t)S * D;
-      FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, att_scale, m->attn_thr, s));
+      const float sc = qk8 ? att_scale / (m->q8_dbl[i] * m->k8_dbl[i]) : att_scale;
+      FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0));
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
@@ -598,6 +613,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     auto& bw = m->sgl[i];
     const float* mo = mod + bw.mod_off;  // shift, scale, gate
     bool fused = false;
+    const bool qk8 = fp8 && m->fp8_attn && can_fuse_relayout(m, B * L, L, 0);
     {
       PhaseTimer pt(m, s, PH_LN);
       if (fp8)
@@ -611,7 +627,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       GemmProblem p = fp8 ? make_problem_fp8(m, bw.w1, 0, B * L, w.big, ldbig, EPI_GELU_FROM_COL)
                           : make_problem(bw.w1, w.xm, D, B * L, w.big, ldbig, EPI_GELU_FROM_COL);
       p.gelu_from = 3 * D;
-      fused = with_qkv_relayout(m, p, bw.nq, bw.nk, pe_bs, L, 0, L);
+      fused = with_qkv_relayout(m, p, bw.nq, bw.nk, pe_bs, L, 0, L, qk8 ? m->q8_sgl[i] : 0.f, qk8 ? m->k8_sgl[i] : 0.f);
       FMI_TRY(gemm2(m, &p, 1, s));
     }
     if (!fused) {
@@ -626,7 +642,8 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       AttnOut o{};
       o.p0 = nullptr, o.rows0 = 0;
       o.p1 = w.big + 2 * D, o.ld1 = ldbig, o.bstride1 = (int64_t)L * ldbig;
-      FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, att_scale, m->attn_thr, s));
+      const float sc = qk8 ? att_scale / (m->q8_sgl[i] * m->k8_sgl[i]) : att_scale;
+      FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0));
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
@@ -1063,12 +1080,52 @@ extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) {
     FMI_TRY(launch_quantize_rows_fp8(d->w, d->K, d->N, d->K, d->w8, d->w8_scale, s));
   }
   FMI_HIP_TRY(hipStreamSynchronize(s));
+  {  // static e4m3 scales of the attention operands from the QkNorm weights (see fmi_flux::fp8_attn)
+    auto wmax = [&](const bf16_t* dev, float* out) -> int {
+      uint16_t h[128];
+      FMI_HIP_TRY(hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost));
+      float mx = 0.f;
+      for (int i = 0; i < 128; ++i) {
+        uint32_t u = (uint32_t)h[i] << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        mx = std::max(mx, std::fabs(f));
+      }
+      *out = mx;
+      return FMI_OK;
+    };
+    auto scale_of = [](float mx) { return 448.0f / (11.3137085f * std::max(mx, 1e-20f)); };  // sqrt(128)
+    m->q8_dbl.assign(m->dbl.size(), 0.f), m->k8_dbl.assign(m->dbl.size(), 0.f);
+    m->q8_sgl.assign(m->sgl.size(), 0.f), m->k8_sgl.assign(m->sgl.size(), 0.f);
+    for (size_t i = 0; i < m->dbl.size(); ++i) {
+      float a, b, c, d;
+      FMI_TRY(wmax(m->dbl[i].nq[0], &a));
+      FMI_TRY(wmax(m->dbl[i].nq[1], &b));
+      FMI_TRY(wmax(m->dbl[i].nk[0], &c));
+      FMI_TRY(wmax(m->dbl[i].nk[1], &d));
+      m->q8_dbl[i] = scale_of(std::max(a, b));  // both streams feed one attention call: one scale
+      m->k8_dbl[i] = scale_of(std::max(c, d));
+    }
+    for (size_t i = 0; i < m->sgl.size(); ++i) {
+      float a, c;
+      FMI_TRY(wmax(m->sgl[i].nq, &a));
+      FMI_TRY(wmax(m->sgl[i].nk, &c));
+      m->q8_sgl[i] = scale_of(a), m->k8_sgl[i] = scale_of(c);
+    }
+  }
   if (m->ws.base) {  // the fp8 workspace has two more buffers: rebuild on the next call
     FMI_HIP_TRY(hipFree(m->ws.base));
     m->ws.base = nullptr;
     m->ws.bytes = 0;
   }
   m->fp8 = true;
+  return FMI_OK;
+}
+// fp8 mode only: 1 (default) = q and k leave the fused relayout epilogue as e4m3 and QK^T runs on the fp8 MFMA whenever
+// both streams of a block take that epilogue (token counts multiples of 16); 0 = bf16 attention operands
+extern "C" int fmi_flux_set_fp8_attention(fmi_flux* m, int enable) {
+  if (!m) return fail(FMI_ERR_INVALID, "null handle");
+  m->fp8_attn = enable != 0;
   return FMI_OK;
 }
 // 4-bit dispatch threshold (rows): below it the fused dequant-GEMM runs, at or above it dequant-once + dense

@@ -207,15 +207,27 @@ __device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, f32x
         const float cs[4] = {c01.x, c01.z, c23.x, c23.z};
         const float sn[4] = {c01.y, c01.w, c23.y, c23.w};
         const float inv = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
-        uint32_t o[4];
+        float rr8[8];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const float x0 = v[2 * p] * inv * bf16_to_f32(we[2 * p]);
           const float x1 = v[2 * p + 1] * inv * bf16_to_f32(we[2 * p + 1]);
-          o[p] = pack_bf16x2(cs[p] * x0 - sn[p] * x1, sn[p] * x0 + cs[p] * x1);
+          rr8[2 * p] = cs[p] * x0 - sn[p] * x1;
+          rr8[2 * p + 1] = sn[p] * x0 + cs[p] * x1;
         }
-        bf16_t* dst = osel + (((int64_t)b * P.qk_H + head0 + hh) * P.qk_Ltot + pos) * 128 + sub * 8;
-        *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+        const int64_t row = ((int64_t)b * P.qk_H + head0 + hh) * P.qk_Ltot + pos;
+        if (P.qk_q8 > 0.f) {  // fp8 attention operands: e4m3(value * static scale), 8 bytes per lane
+          const float sc8 = part == 0 ? P.qk_q8 : P.qk_k8;
+          int lo = 0, hi = 0;
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[0] * sc8, rr8[1] * sc8, lo, false);
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[2] * sc8, rr8[3] * sc8, lo, true);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[4] * sc8, rr8[5] * sc8, hi, false);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[6] * sc8, rr8[7] * sc8, hi, true);
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(osel) + row * 128 + sub * 8) = make_uint2((uint32_t)lo, (uint32_t)hi);
+        } else {
+          bf16_t* dst = osel + row * 128 + sub * 8;
+          *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(rr8[0], rr8[1]), pack_bf16x2(rr8[2], rr8[3]), pack_bf16x2(rr8[4], rr8[5]), pack_bf16x2(rr8[6], rr8[7]));
+        }
       }
     }
   } else {

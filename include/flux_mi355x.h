@@ -140,6 +140,11 @@ int fmi_flux_set_modulation_gemm(fmi_flux*, int enable);
  * (AdaLN-modulate) or by one row pass (attention output, GELU(MLP)).  Attention, the residual stream,
  * modulation, embedders and the final layer stay bf16/f32.  Not combinable with bnb-quantised linears. */
 int fmi_flux_quantize_fp8(fmi_flux*, void* stream);
+/* fp8 mode, attention operands: 1 (default) = q and k leave the fused QKV epilogue as e4m3 with static per-block
+ * scales 448 / (sqrt(128) * max|QkNorm weight|) (no element of a normalised, rotated head vector can exceed them) and
+ * QK^T runs on the fp8 MFMA; P and V stay bf16.  Applies when both streams of a block take the fused epilogue (token
+ * counts and offsets multiples of 16, model width a multiple of 256), else that block uses bf16 operands.  0 = always bf16. */
+int fmi_flux_set_fp8_attention(fmi_flux*, int enable);
 int fmi_flux_missing_count(const fmi_flux*);
 const char* fmi_flux_missing_name(const fmi_flux*, int i);
 /* Bytes of HBM held by the model (weights + current workspace). */
@@ -358,6 +363,10 @@ int fmi_linear_fp8(const void* x, const uint8_t* wq, const float* w_scale, const
  * token-major (B,L,H*d) when `out_token_major`, else (B,H,L,d).
  * == backend::ops::sdpa fallback (ops.rs:247-262) without materialising the scores. */
 int fmi_sdpa_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
+                  int Lk, int d, float scale, int out_token_major, void* stream);
+/* Same with q and k as OCP e4m3 bytes (B,H,L,128): QK^T on the fp8 MFMA, softmax / P / V in f32 / bf16 as above.
+ * `scale` must include 1 / (q scale * k scale).  The fp8-mode attention of fmi_flux_* (fmi_flux_set_fp8_attention). */
+int fmi_sdpa_fp8qk(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
                   int Lk, int d, float scale, int out_token_major, void* stream);
 /* LayerNorm(eps, no affine) then x*(1+scale)+shift: x (rows,D) f32 -> out bf16;
  * scale/shift f32 (D) (layer_norm helper model.rs:33-38 + ModulationOut::scale_shift :218-221).

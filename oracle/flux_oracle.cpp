@@ -618,6 +618,7 @@ struct Fp8Weight {
 };
 struct orc_flux {
   int fp8 = 0;  // block linears on the fp8 recipe above
+  int fp8_attn = 0;  // q, k of the attention quantised to e4m3 with static scales (see attention())
   std::map<const float*, Fp8Weight> fp8_w;
   int in_channels, pooled_dim, joint_dim, heads, n_double, n_single, guidance;
   int axes[3], theta;
@@ -656,6 +657,7 @@ extern "C" orc_flux* orc_flux_create(int in_channels, int pooled_projection_dim,
 }
 extern "C" void orc_flux_destroy(orc_flux* m) { delete m; }
 extern "C" void orc_flux_set_fp8(orc_flux* m, int on) { m->fp8 = on; }
+extern "C" void orc_flux_set_fp8_attention(orc_flux* m, int on) { m->fp8_attn = on; }
 extern "C" int orc_flux_set_tensor(orc_flux* m, const char* name, const float* data, int64_t numel) {
   m->t[name] = std::vector<float>(data, data + numel);
   m->fp8_w.clear();
@@ -719,10 +721,19 @@ void to_heads(const float* x, int rows, int H, int d, float* out, int row_off, i
     for (int h = 0; h < H; ++h) memcpy(out + ((int64_t)h * Ltot + row_off + r) * d, x + ((int64_t)r * H + h) * d, sizeof(float) * d);
 }
 // attention(), model.rs:97-102: rope on q,k; sdpa in f32 (model.rs:40-50); (H,L,d)->(L,H*d)
-void attention(const float* q, const float* k, const float* v, const float* pe, int H, int L, int d, float* out_tok) {
+// q8 / k8 > 0 (fp8 recipe, no reference counterpart): the rotated q and k are replaced by e4m3(value * scale) / scale
+// with the static scales 448 / (sqrt(d) * max|QkNorm weight|) before the scores are formed; P and V are untouched.
+void attention(const float* q, const float* k, const float* v, const float* pe, int H, int L, int d, float* out_tok, float q8 = 0.f, float k8 = 0.f) {
   std::vector<float> qr((size_t)H * L * d), kr((size_t)H * L * d), o((size_t)H * L * d);
   orc_apply_rope(q, pe, H, L, d, qr.data());
   orc_apply_rope(k, pe, H, L, d, kr.data());
+  if (q8 > 0.f) {
+#pragma omp parallel for
+    for (int64_t i = 0; i < (int64_t)H * L * d; ++i) {
+      qr[i] = orc_e4m3_to_f32(orc_f32_to_e4m3(qr[i] * q8)) / q8;
+      kr[i] = orc_e4m3_to_f32(orc_f32_to_e4m3(kr[i] * k8)) / k8;
+    }
+  }
   float scale = (float)(1.0 / sqrt((double)d));
   orc_sdpa(qr.data(), kr.data(), v, 1, H, L, L, d, scale, o.data());
 #pragma omp parallel for
@@ -766,6 +777,17 @@ void add_gated(float* x, const float* gate, const float* y, int rows, int D) {
 }
 }  // namespace
 
+static float fp8_attn_scale(const orc_flux* m, const std::string& a, const std::string& b, int d) {
+  float mx = 0.f;
+  for (const std::string& n : {a, b}) {
+    if (n.empty()) continue;
+    const float* w = m->get(n + ".weight", d);
+    if (!w) return 0.f;
+    for (int i = 0; i < d; ++i) mx = std::max(mx, fabsf(w[i]));
+  }
+  return 448.0f / (sqrtf((float)d) * std::max(mx, 1e-20f));
+}
+
 // DoubleStreamBlock::forward, model.rs:523-565 (one batch element).
 static int double_block_one(orc_flux* m, int idx, float* img, float* txt, const float* vec, const float* pe, int S, int T) {
   const int D = m->D, H = m->heads, d = D / H, M = m->M, L = S + T;
@@ -782,7 +804,12 @@ static int double_block_one(orc_flux* m, int idx, float* img, float* txt, const 
   if (!qkv(m, p + "attn.", "add_q_proj", "add_k_proj", "add_v_proj", "norm_added_q", "norm_added_k", tm.data(), T, 0, L, Q.data(), K.data(), V.data())) return -1;
   // cat([txt, img], seq) is realised by the row offsets above (model.rs:540-542)
   std::vector<float> attn((size_t)L * D);
-  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data());
+  float q8 = 0.f, k8 = 0.f;
+  if (m->fp8 && m->fp8_attn) {
+    q8 = fp8_attn_scale(m, p + "attn.norm_q", p + "attn.norm_added_q", d);
+    k8 = fp8_attn_scale(m, p + "attn.norm_k", p + "attn.norm_added_k", d);
+  }
+  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8);
   const float* txt_attn = attn.data();
   const float* img_attn = attn.data() + (size_t)T * D;
   Lin ip = get_lin(m, p + "attn.to_out.0", D, D), tp = get_lin(m, p + "attn.to_add_out", D, D);
@@ -826,7 +853,12 @@ static int single_block_one(orc_flux* m, int idx, float* x, const float* vec, co
   if (!pm.ok() || !l2.ok()) return -1;
   std::vector<float> cat((size_t)L * (D + M)), mlp((size_t)L * M), attn((size_t)L * D);
   lin_blk(m, pm, xm.data(), L, mlp.data());
-  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data());
+  float q8 = 0.f, k8 = 0.f;
+  if (m->fp8 && m->fp8_attn) {
+    q8 = fp8_attn_scale(m, p + "attn.norm_q", "", d);
+    k8 = fp8_attn_scale(m, p + "attn.norm_k", "", d);
+  }
+  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8);
   orc_gelu(mlp.data(), (int64_t)L * M, mlp.data());
 #pragma omp parallel for
   for (int l = 0; l < L; ++l) {  // Tensor::cat(&[attn, mlp.gelu()], 2)  (model.rs:660)

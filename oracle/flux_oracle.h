@@ -59,6 +59,7 @@ void orc_flux_destroy(orc_flux*);
 int orc_flux_set_tensor(orc_flux*, const char* name, const float* data, int64_t numel);
 /* fp8 recipe (BASELINE configs[4]; no reference counterpart — parity unpinned, see flux_oracle.cpp) */
 void orc_flux_set_fp8(orc_flux*, int on);
+void orc_flux_set_fp8_attention(orc_flux*, int on); /* with set_fp8: q, k of the attention on e4m3 with static scales */
 float orc_e4m3_to_f32(uint8_t code);
 uint8_t orc_f32_to_e4m3(float x);
 void orc_quantize_rows_fp8(const float* x, int rows, int K, uint8_t* out, float* scale);

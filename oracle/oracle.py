@@ -49,6 +49,8 @@ def lib():
         _lib.orc_f32_to_e4m3.argtypes = [C.c_float]
         _lib.orc_flux_set_fp8.argtypes = [C.c_void_p, C.c_int]
         _lib.orc_flux_set_fp8.restype = None
+        _lib.orc_flux_set_fp8_attention.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_flux_set_fp8_attention.restype = None
     return _lib
 
 
@@ -324,9 +326,12 @@ class Flux:
         for k, v in tensors.items():
             self.set_tensor(k, v)
 
-    def set_fp8(self, on=True):
-        """Block linears on the fp8 recipe (flux_oracle.cpp: parity unpinned, no reference counterpart)."""
+    def set_fp8(self, on=True, attention=False):
+        """Block linears on the fp8 recipe (flux_oracle.cpp: parity unpinned, no reference counterpart); attention=True
+        also puts q and k of the attention on e4m3 with the static scales (what the library does when both streams of a
+        block take the fused QKV epilogue: token counts / offsets multiples of 16)."""
         lib().orc_flux_set_fp8(self.h, int(bool(on)))
+        lib().orc_flux_set_fp8_attention(self.h, int(bool(on and attention)))
 
     def forward(self, img, img_ids, txt, txt_ids, timesteps, y, guidance=None):
         img, a = _f(img)

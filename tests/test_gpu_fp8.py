@@ -151,20 +151,29 @@ def models(env):
     o8 = orc.Flux(SMALL_FLUX)
     o8.load(sd)
     o8.set_fp8(True)
+    o8a = orc.Flux(SMALL_FLUX)   # + q, k of the attention on e4m3: what the library does for 16-aligned token counts
+    o8a.load(sd)
+    o8a.set_fp8(True, attention=True)
     of = orc.Flux(SMALL_FLUX)
     of.load(sd)
-    return dict(g8=g8, gb=gb, o8=o8, of=of)
+    return dict(g8=g8, gb=gb, o8=o8, o8a=o8a, of=of)
 
 
-@pytest.mark.parametrize("B,S_hw,T", [(1, (8, 12), 40), (2, (6, 6), 64), (1, (16, 16), 77)])
+def _aligned(S_hw, T):
+    S = S_hw[0] * S_hw[1]
+    return S % 16 == 0 and T % 16 == 0
+
+
+@pytest.mark.parametrize("B,S_hw,T", [(1, (8, 12), 40), (2, (6, 6), 64), (1, (16, 16), 77), (1, (8, 8), 32), (2, (8, 16), 48)])
 def test_flux_forward_fp8_matches_fp8_oracle(env, models, B, S_hw, T):
+    # the last two shapes have 16-aligned token counts: every block takes the fused QKV epilogue and QK^T runs in fp8
     torch = env["torch"]
     img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, B, S_hw, T)
     t = np.linspace(0.9, 0.4, B).astype(np.float32)
     g = np.full(B, 3.5, np.float32)
     args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
     got = host(models["g8"].forward(*args))
-    ref8 = models["o8"].forward(img, ids, txt, txt_ids, t, y, g)
+    ref8 = models["o8a" if _aligned(S_hw, T) else "o8"].forward(img, ids, txt, txt_ids, t, y, g)
     ref = models["of"].forward(img, ids, txt, txt_ids, t, y, g)
     gotb = host(models["gb"].forward(*args))
     assert np.isfinite(got).all()
@@ -181,7 +190,7 @@ def test_flux_denoise_fp8(env, models):
     g = np.full(B, 3.5, np.float32)
     sched = d.SchedulerConfig()
     ts = sched.get_timesteps(steps, sched.calculate_shift(S_hw[0] * S_hw[1]))
-    ref8 = models["o8"].denoise(img, ids, txt, txt_ids, y, g, ts)
+    ref8 = models["o8a"].denoise(img, ids, txt, txt_ids, y, g, ts)   # (8, 8) / 32: aligned -> fp8 QK^T
     args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(y), dev(g), ts)
     got = host(models["g8"].denoise(*args))
     again = host(models["g8"].denoise(*args))
@@ -258,3 +267,60 @@ def test_fp8_gemm_run_to_run_determinism_full_size(env):
             first = y
         else:
             assert torch.equal(first, y), f"launch {i} differs"
+
+
+def test_fp8_attention_toggle(env, models):
+    """fmi_flux_set_fp8_attention(0) keeps bf16 attention operands in fp8 mode: the result then matches the oracle
+    without the attention recipe, and differs (slightly) from the default fp8-QK^T result."""
+    torch, L, lib = env["torch"], env["L"], env["lib"]
+    B, S_hw, T = 1, (8, 8), 32
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, B, S_hw, T, seed=5)
+    t = np.array([0.7], np.float32)
+    g = np.array([3.5], np.float32)
+    args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
+    g8 = models["g8"]
+    on = host(g8.forward(*args))
+    try:
+        L.check(lib.fmi_flux_set_fp8_attention(g8.h, 0))
+        off = host(g8.forward(*args))
+    finally:
+        L.check(lib.fmi_flux_set_fp8_attention(g8.h, 1))
+    r_on = models["o8a"].forward(img, ids, txt, txt_ids, t, y, g)
+    r_off = models["o8"].forward(img, ids, txt, txt_ids, t, y, g)
+    print(f"fp8 attention on: {rel_l2(on, r_on):.2e} vs its oracle; off: {rel_l2(off, r_off):.2e}; on vs off {rel_l2(on, off):.2e}; oracle on vs off {rel_l2(r_on, r_off):.2e}")
+    assert rel_l2(on, r_on) <= 1e-2 and rel_l2(off, r_off) <= 1e-2
+    assert not np.array_equal(on, off)
+
+
+@pytest.mark.parametrize("B,H,L", [(1, 2, 64), (2, 3, 200), (1, 2, 333), (1, 24, 4608), (2, 24, 4112)])
+def test_sdpa_fp8qk_equals_bf16_sdpa_on_the_same_codes(env, B, H, L):
+    """QK^T on the fp8 MFMA vs the bf16 attention kernel fed the dequantised codes (e4m3 values are exact in bf16, the
+    products exact in both): only the accumulation order of the 128-long dot products differs, far below the softmax's
+    sensitivity.  The last two shapes are BASELINE's C2 and C5 attention shapes.  The bf16 kernel itself is pinned to
+    the oracle in tests/test_gpu_ops.py."""
+    torch, L_, lib = env["torch"], env["L"], env["lib"]
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + L)
+    q = torch.randn(B, H, L, 128, device="cuda", generator=g)
+    k = torch.randn(B, H, L, 128, device="cuda", generator=g)
+    v = torch.randn(B, H, L, 128, device="cuda", generator=g).to(torch.bfloat16)
+    QS = KS = 448.0 / (128 ** 0.5 * 1.5)
+    q8 = (q * QS).clamp(-448, 448).to(torch.float8_e4m3fn)
+    k8 = (k * KS).clamp(-448, 448).to(torch.float8_e4m3fn)
+    qd, kd = q8.to(torch.bfloat16), k8.to(torch.bfloat16)
+    assert torch.equal(qd.float(), q8.float())
+    scale = (1.0 / 128 ** 0.5) / (QS * KS)
+    o8 = torch.empty(B, L, H * 128, device="cuda", dtype=torch.bfloat16)
+    ob = torch.empty_like(o8)
+    L_.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o8), B, H, L, L, 128, scale, 1, None))
+    L_.check(lib.fmi_sdpa_bf16(_p(qd), _p(kd), _p(v), _p(ob), B, H, L, L, 128, scale, 1, None))
+    torch.cuda.synchronize()
+    assert torch.isfinite(o8.float()).all()
+    diff = (o8.float() - ob.float()).abs()
+    rel = float((o8.float() - ob.float()).norm() / ob.float().norm())
+    print(f"sdpa fp8-QK vs bf16 on the same codes B={B} H={H} L={L}: rel-L2 {rel:.2e}, max |d| {float(diff.max()):.3e}")
+    assert rel <= 3e-3 and float(diff.max()) <= 0.05
+    # run-to-run determinism (hand-placed waitcnts)
+    o8b = torch.empty_like(o8)
+    L_.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o8b), B, H, L, L, 128, scale, 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(o8, o8b)
