@@ -1,0 +1,109 @@
+"""Seeded shape fuzzing of the two hot kernels through the C-ABI against plain PyTorch f32 on the same device
+(ragged M / N, every K-tile count parity, tiny and tile-straddling sizes): the fixed shapes of the other tests all
+sit on friendly boundaries.  Tolerances are the op-level ones of DESIGN.md §5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from diffusion_rs_amd import _lib as L
+    return torch, L, L.load()
+
+
+def test_linear_bf16_random_shapes(env):
+    torch, L, lib = env
+    rng = np.random.default_rng(2024)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    worst = 0.0
+    for it in range(48):
+        M = int(rng.choice([1, 7, 31, 64, 129, 255, 256, 257, 300, 511, 777, 1024, 1500]))
+        N = int(rng.choice([4, 12, 64, 100, 128, 132, 256, 260, 384, 500, 768, 1000, 1284])) // 4 * 4
+        K = 64 * int(rng.integers(1, 21))
+        epi = int(rng.integers(0, 3))            # none / gelu / silu
+        bias = bool(rng.integers(0, 2))
+        x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16) if bias else None
+        y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        L.check(lib.fmi_linear_bf16(_p(x), _p(w), _p(b), _p(y), M, N, K, epi, None))
+        ref = x.float() @ w.float().t()
+        if bias:
+            ref = ref + b.float()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref, approximate="tanh")
+        elif epi == 2:
+            ref = torch.nn.functional.silu(ref)
+        torch.cuda.synchronize()
+        assert torch.isfinite(y.float()).all(), (M, N, K, epi)
+        err = float((y.float() - ref).norm() / ref.norm().clamp_min(1e-20))
+        worst = max(worst, err)
+        assert err <= 4e-3, (M, N, K, epi, bias, err)
+    print(f"48 random bf16 linears: worst rel-L2 {worst:.2e}")
+
+
+def test_linear_fp8_random_shapes(env):
+    torch, L, lib = env
+    rng = np.random.default_rng(7)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    worst = 0.0
+    for it in range(32):
+        M = int(rng.choice([1, 8, 33, 64, 200, 256, 257, 640, 1000]))
+        N = int(rng.choice([132, 256, 260, 384, 512, 1000, 1284])) // 4 * 4
+        K = 128 * int(rng.integers(1, 13))
+        epi = int(rng.integers(0, 2))
+        x = (torch.randn(M, K, device="cuda", generator=g) * float(10 ** rng.uniform(-2, 2))).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+        wq = torch.empty(N, K, dtype=torch.uint8, device="cuda")
+        ws = torch.empty(N, dtype=torch.float32, device="cuda")
+        xq = torch.empty(M, K, dtype=torch.uint8, device="cuda")
+        xs = torch.empty(M, dtype=torch.float32, device="cuda")
+        L.check(lib.fmi_quantize_rows_fp8(_p(w), N, K, _p(wq), _p(ws), None))
+        L.check(lib.fmi_quantize_rows_fp8(_p(x), M, K, _p(xq), _p(xs), None))
+        y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        L.check(lib.fmi_linear_fp8(_p(x), _p(wq), _p(ws), _p(b), _p(y), M, N, K, epi, None))
+        # reference: the same codes in f32
+        ref = (xq.view(torch.float8_e4m3fn).float() @ wq.view(torch.float8_e4m3fn).float().t()) * (xs[:, None] * ws[None, :]) + b.float()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref, approximate="tanh")
+        torch.cuda.synchronize()
+        assert torch.isfinite(y.float()).all(), (M, N, K, epi)
+        err = float((y.float() - ref).norm() / ref.norm().clamp_min(1e-20))
+        worst = max(worst, err)
+        assert err <= 4e-3, (M, N, K, epi, err)
+    print(f"32 random fp8 linears: worst rel-L2 {worst:.2e}")
+
+
+def test_sdpa_random_shapes(env):
+    torch, L, lib = env
+    rng = np.random.default_rng(99)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    worst = 0.0
+    for it in range(20):
+        B, H = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+        Lq = int(rng.choice([1, 17, 63, 64, 65, 127, 200, 256, 257, 500, 777]))
+        Lk = int(rng.choice([1, 5, 63, 64, 65, 130, 192, 333, 512, 700])) if rng.integers(0, 2) else Lq
+        q = torch.randn(B, H, Lq, 128, device="cuda", generator=g).to(torch.bfloat16)
+        k = torch.randn(B, H, Lk, 128, device="cuda", generator=g).to(torch.bfloat16)
+        v = torch.randn(B, H, Lk, 128, device="cuda", generator=g).to(torch.bfloat16)
+        o = torch.full((B, Lq, H * 128), float("nan"), device="cuda", dtype=torch.bfloat16)
+        scale = 1.0 / 128 ** 0.5
+        L.check(lib.fmi_sdpa_bf16(_p(q), _p(k), _p(v), _p(o), B, H, Lq, Lk, 128, scale, 1, None))
+        att = torch.softmax((q.float() @ k.float().transpose(-1, -2)) * scale, -1) @ v.float()
+        ref = att.transpose(1, 2).reshape(B, Lq, H * 128)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o.float()).all(), (B, H, Lq, Lk)
+        err = float((o.float() - ref).norm() / ref.norm())
+        worst = max(worst, err)
+        assert err <= 6e-3, (B, H, Lq, Lk, err)
+    print(f"20 random attentions: worst rel-L2 {worst:.2e}")
