@@ -11,7 +11,9 @@
 
 namespace fmi {
 
-// one 256-thread block per row; x f32 (re-read from L1/L2 for the second pass), out bf16
+// one 256-thread block per row; x f32, out bf16.  REG = true (D <= 4096): the row stays in registers between the
+// statistics and the normalisation (same per-thread element order as the two-pass form: identical results).
+template <bool REG>
 __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restrict x, const float* __restrict scale,
                                                             const float* __restrict shift, int mod_bstride, int rows_per_batch,
                                                             bf16_t* __restrict out, int D, float eps) {
@@ -19,11 +21,26 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
   const int row = blockIdx.x;
   const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
   const int nv = D >> 2;
+  constexpr int MAXV = 4;
+  float4 keep[MAXV];
   float s = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < nv; i += 256) {
-    const float4 v = xr[i];
-    s += (v.x + v.y) + (v.z + v.w);
-    s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  if constexpr (REG) {
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+      const int i = threadIdx.x + c * 256;
+      if (i < nv) {
+        const float4 v = xr[i];
+        keep[c] = v;
+        s += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < nv; i += 256) {
+      const float4 v = xr[i];
+      s += (v.x + v.y) + (v.z + v.w);
+      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
   }
   s = wave_sum(s);
   s2 = wave_sum(s2);
@@ -42,8 +59,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
   const float4* sc = scale ? reinterpret_cast<const float4*>(scale + (int64_t)batch * mod_bstride) : nullptr;
   const float4* sh = shift ? reinterpret_cast<const float4*>(shift + (int64_t)batch * mod_bstride) : nullptr;
   uint2* o = reinterpret_cast<uint2*>(out + (int64_t)row * D);
-  for (int i = threadIdx.x; i < nv; i += 256) {
-    const float4 v = xr[i];
+  auto emit = [&](int i, const float4 v) {
     float a = (v.x - mean) * inv_std, b = (v.y - mean) * inv_std, c = (v.z - mean) * inv_std, d = (v.w - mean) * inv_std;
     if (sc) {
       const float4 k = sc[i];
@@ -60,6 +76,15 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
       d += k.w;
     }
     o[i] = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+  };
+  if constexpr (REG) {
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+      const int i = threadIdx.x + c * 256;
+      if (i < nv) emit(i, keep[c]);
+    }
+  } else {
+    for (int i = threadIdx.x; i < nv; i += 256) emit(i, xr[i]);
   }
 }
 
@@ -67,7 +92,10 @@ int launch_layernorm_mod(const float* x, const float* scale, const float* shift,
                          int rows, int D, float eps, hipStream_t stream) {
   if (rows <= 0) return FMI_OK;
   if (D % 4) return fail(FMI_ERR_INVALID, "layernorm_mod: D must be a multiple of 4");
-  hipLaunchKernelGGL(layernorm_mod_kernel, dim3(rows), dim3(256), 0, stream, x, scale, shift, mod_bstride, rows_per_batch, out, D, eps);
+  if (D <= 4096)
+    hipLaunchKernelGGL(layernorm_mod_kernel<true>, dim3(rows), dim3(256), 0, stream, x, scale, shift, mod_bstride, rows_per_batch, out, D, eps);
+  else
+    hipLaunchKernelGGL(layernorm_mod_kernel<false>, dim3(rows), dim3(256), 0, stream, x, scale, shift, mod_bstride, rows_per_batch, out, D, eps);
   FMI_LAUNCH_CHECK();
   return FMI_OK;
 }
