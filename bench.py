@@ -190,14 +190,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def energy_uj():
+        # socket energy counter of this rank's GPU (rocm-smi, ~0.3 s per call: read outside the timed region)
+        try:
+            import re
+            import subprocess
+            o = subprocess.run(["rocm-smi", "--showenergycounter"], capture_output=True, text=True, timeout=20).stdout
+            m = re.findall(r"GPU\[(\d+)\]\s*:\s*Accumulated Energy \(uJ\):\s*([\d.]+)", o)
+            d_ = {int(k): float(v) for k, v in m}
+            return d_.get(local_rank)
+        except Exception:
+            return None
+
     for i in range(args.warmup):
         u8 = one_image(i)
+    barrier()
+    e_start = energy_uj() if rank == 0 else None
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         u8 = one_image(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    e_end = energy_uj() if rank == 0 else None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -212,6 +227,10 @@ def main():
     # ---------------- profiled pass: per-phase hipEvent timing on the launch stream
     roof = None
     extra = {}
+    if e_start is not None and e_end is not None and e_end > e_start:
+        # includes ~0.3 s of idle (two rocm-smi calls) around the timed region: a <= 1 % overestimate per image
+        extra["energy_j_per_image_rank0"] = round((e_end - e_start) / 1e6 / (args.steps * B), 1)
+        extra["avg_power_w_rank0"] = round((e_end - e_start) / 1e6 / elapsed, 1)
     if rank == 0 and not args.no_profile_pass:
         nprof = NS  # the whole loop: the modulation precompute is per image, so a shorter pass would misprice it
         fl = step_flops(S, T, B)
