@@ -398,25 +398,46 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, f32x16 
               if constexpr (NJ == 4) __builtin_amdgcn_sched_barrier(0);
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int NIT = 64 / RPI;
+        const int ch = lane % LPR, n = ncol0 + ch * 4;
+        if (epi == EPI_RESID_GATE_F32) {
+          // residual read-modify-write: the loads of GRP rows are issued back to back, then consumed — one HBM / L2 round
+          // trip per GRP rows instead of one per row (the compiler otherwise waits vmcnt(0) in front of every store: measured
+          // ~16 us per tile, all of it latency)
+          constexpr int GRP = NIT < 8 ? NIT : 8;
 #pragma unroll
-        for (int it = 0; it < 64 / RPI; ++it) {
-          const int r = it * RPI + lane / LPR, ch = lane % LPR;
-          const float4 v = *reinterpret_cast<const float4*>(cw + r * RBF + ((ch ^ (r & (NS16 - 1))) << 4));
-          const int m = m0 + wm * 128 + pass * 64 + r, n = ncol0 + ch * 4;
-          if (m < P.M) {
-            float* o = of + (int64_t)m * P.ldo + n;
-            if (epi == EPI_RESID_GATE_F32) {
+          for (int g0 = 0; g0 < NIT; g0 += GRP) {
+            float4 xr[GRP], gg[GRP];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+              const int r = (g0 + u) * RPI + lane / LPR;
+              const int m = min(m0 + wm * 128 + pass * 64 + r, P.M - 1);  // clamped, not predicated: no branch between the loads
               const float* gate = P.gate + (P.rows_per_batch > 0 ? (int64_t)(m / P.rows_per_batch) * P.gate_bstride : 0);
-              const float4 g = *reinterpret_cast<const float4*>(gate + n);
-              float4 x = *reinterpret_cast<float4*>(o);
-              x.x += g.x * v.x;
-              x.y += g.y * v.y;
-              x.z += g.z * v.z;
-              x.w += g.w * v.w;
-              *reinterpret_cast<float4*>(o) = x;
-            } else {
-              *reinterpret_cast<float4*>(o) = v;
+              gg[u] = *reinterpret_cast<const float4*>(gate + n);
+              xr[u] = *reinterpret_cast<const float4*>(of + (int64_t)m * P.ldo + n);
             }
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+              const int r = (g0 + u) * RPI + lane / LPR;
+              const int m = m0 + wm * 128 + pass * 64 + r;
+              const float4 v = *reinterpret_cast<const float4*>(cw + r * RBF + ((ch ^ (r & (NS16 - 1))) << 4));
+              if (m < P.M) {
+                float4 x = xr[u];
+                x.x += gg[u].x * v.x;
+                x.y += gg[u].y * v.y;
+                x.z += gg[u].z * v.z;
+                x.w += gg[u].w * v.w;
+                *reinterpret_cast<float4*>(of + (int64_t)m * P.ldo + n) = x;
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int r = it * RPI + lane / LPR;
+            const float4 v = *reinterpret_cast<const float4*>(cw + r * RBF + ((ch ^ (r & (NS16 - 1))) << 4));
+            const int m = m0 + wm * 128 + pass * 64 + r;
+            if (m < P.M) *reinterpret_cast<float4*>(of + (int64_t)m * P.ldo + n) = v;
           }
         }
       };

@@ -58,11 +58,15 @@ int main(int argc, char** argv) {
     maxO = std::max(maxO, (size_t)s.M * (s.N + 512));
   }
   bf16_t *A, *W, *O;
+  // FMI_COLD_W=n: rotate over n weight buffers so every launch streams its W from HBM (as in the model, where a weight
+  // matrix is used once per denoise step) instead of finding it in the 256 MiB Infinity Cache from the previous launch
+  const int ncold = getenv("FMI_COLD_W") ? std::max(1, atoi(getenv("FMI_COLD_W"))) : 1;
   hipMalloc((void**)&A, maxA * 2);
-  hipMalloc((void**)&W, maxW * 2);
+  hipMalloc((void**)&W, maxW * 2 * ncold);
+  printf("weight buffers: %d\n", ncold);
   hipMalloc((void**)&O, maxO * 2);
   fill_kernel<<<2048, 256>>>(A, maxA, 1u);
-  fill_kernel<<<2048, 256>>>(W, maxW, 2u);
+  fill_kernel<<<2048, 256>>>(W, maxW * ncold, 2u);
   hipDeviceSynchronize();
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
@@ -100,7 +104,11 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 2; ++i) launch_gemm(&p, 1, nullptr);
       hipDeviceSynchronize();
       hipEventRecord(e0, nullptr);
-      for (int i = 0; i < iters; ++i) launch_gemm(&p, 1, nullptr);
+      for (int i = 0; i < iters; ++i) {
+        p.W = W + (size_t)(i % ncold) * maxW;
+        launch_gemm(&p, 1, nullptr);
+      }
+      p.W = W;
       hipEventRecord(e1, nullptr);
       hipEventSynchronize(e1);
       float ms = 0;
