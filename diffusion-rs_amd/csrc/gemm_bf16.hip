@@ -1203,14 +1203,12 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
 }
 
 static bool g_pingpong = true;
-// Default OFF.  Stand-alone (tools/gemm_bench) the 4-wave kernel is 3-9 % faster than the ping-pong kernel on the FLUX
-// shapes it is eligible for, bit-identical; inside the denoise loop the step time does not move (74.4-74.6 ms either way,
-// A/B on one box) because the part is power-capped: with the 4-wave kernel in the mix every kernel — including the
-// attention and QKV launches that do not use it — runs ~2-3 % slower.  FMI_GEMM_W4=1 in the environment (or
-// set_gemm_w4) enables it for the eligible launches; see DESIGN.md 4.1.
+// Default ON for the launches `w4_pays` selects below (the residual-update GEMMs: proj, mlp2, linear2).  Bit-identical
+// to the ping-pong kernel; in the denoise loop -0.45 ms per step and -2.3 % joules per image (alternating A/B on one
+// box).  FMI_GEMM_W4=0 in the environment (or set_gemm_w4(false)) sends everything to the 8-wave kernel.
 static bool g_w4 = [] {
   const char* e = getenv("FMI_GEMM_W4");
-  return e ? atoi(e) != 0 : false;
+  return e ? atoi(e) != 0 : true;
 }();
 void set_gemm_w4(bool on) { g_w4 = on; }
 void set_gemm_pingpong(bool on) { g_pingpong = on; }
@@ -1259,12 +1257,13 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   } while (0)
   const int act = epilogue_kind(probs, nprob);
   // 4-wave kernel: its K loop is 7-10 % faster, its two-round epilogue slower — measured break-even (tools/gemm_bench,
-  // FMI_EPI=store|gelu|resid): always for bf16 stores / GELU, for the f32 residual read-modify-write only at long K.
+  // FMI_EPI=store|gelu|resid on the FLUX shapes): the f32 residual read-modify-write launches at every K (proj -5 %,
+  // mlp2 -10 %, linear2 -7 %), everything else from K = 8192 on (mlp1 + GELU at K = 3072 is a wash).
   // The fused q|k|v relayout epilogue exists for the 8-wave layout only.
   bool w4_pays = !fp8 && !conv && !quant;
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem& p = probs[i];
-    if (p.qk_qh || ((p.epi == EPI_RESID_GATE_F32 || p.epi == EPI_STORE_F32) && p.K < 8192)) w4_pays = false;
+    if (p.qk_qh || (p.epi != EPI_RESID_GATE_F32 && p.K < 8192)) w4_pays = false;
   }
 #define FMI_ACT_LAUNCH(KERNEL, FP8FLAG, THREADS)                                                    \
   do {                                                                                              \

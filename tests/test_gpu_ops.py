@@ -293,10 +293,9 @@ def test_empty_and_null_inputs_fail_cleanly(env):
 
 
 def test_gemm_4wave_kernel_is_bit_identical(tmp_path):
-    """FMI_GEMM_W4=1 routes eligible dense launches (N > 128, bf16 store / GELU epilogue, or f32 residual at K >= 8192)
-    to the 4-wave 128x128-per-wave kernel (default off: no in-model gain under the power cap).  Same
-    accumulation order as the ping-pong kernel -> the outputs must be bit-identical.  The switch is read when the
-    library loads, so each setting runs in its own process."""
+    """Eligible dense launches (N > 128: the f32 residual epilogue, or any epilogue at K >= 8192) go to the 4-wave
+    128x128-per-wave kernel unless FMI_GEMM_W4=0.  Same accumulation order as the ping-pong kernel -> the
+    outputs must be bit-identical.  The switch is read when the library loads, so each setting runs in its own process."""
     import subprocess
     import sys
     script = r'''
@@ -307,7 +306,7 @@ lib = L.load()
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 out = {}
 g = torch.Generator(device="cuda").manual_seed(0)
-for (M, N, K, epi) in [(300, 384, 256, 0), (1000, 260, 64, 0), (257, 1024, 1280, 1), (4608, 3072, 3072, 0), (512, 12288, 3072, 1), (4096, 3072, 12288, 0)]:
+for (M, N, K, epi) in [(300, 384, 256, 0), (1000, 260, 64, 0), (257, 1024, 1280, 1), (4608, 3072, 3072, 0), (512, 12288, 3072, 1), (4096, 3072, 12288, 0), (300, 512, 8192, 1), (257, 260, 8256, 0)]:
     x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
     b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
