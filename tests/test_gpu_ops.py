@@ -314,6 +314,15 @@ for (M, N, K, epi) in [(300, 384, 256, 0), (1000, 260, 64, 0), (257, 1024, 1280,
     L.check(lib.fmi_linear_bf16(p(x), p(w), p(b), p(y), M, N, K, epi, None))
     torch.cuda.synchronize()
     out[f"{M}x{N}x{K}e{epi}"] = y.view(torch.int16).cpu().numpy()
+# the residual-update GEMMs of a small FLUX (f32 read-modify-write epilogue, grouped img + txt launches)
+import diffusion_rs_amd as d
+from tests.util import SMALL_FLUX, dev, flux_inputs, host
+gm = d.FluxModel(SMALL_FLUX)
+gm.load_state_dict(d.synth.flux_state_dict_numpy(SMALL_FLUX, seed=0))
+img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, 2, (8, 12), 40)
+t = np.array([0.8, 0.5], np.float32)
+g3 = np.full(2, 3.5, np.float32)
+out["flux_forward"] = host(gm.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g3)))
 np.savez(sys.argv[1], **out)
 '''
     import os
