@@ -255,7 +255,7 @@ def main():
         peak = 5000.0 if fp8 else 2500.0
         if fp8:
             traffic = None  # the PMC summary on file is the bf16 kernel's
-        roof = {"bound": "mfma", "kernel": "gemm_pp_kernel<fp8> (e4m3 MFMA GEMM, all block linears)" if fp8 else "gemm_pp_kernel (bf16 MFMA GEMM, all block linears)",
+        roof = {"bound": "mfma", "kernel": "gemm_pp_kernel<fp8> (e4m3 MFMA GEMM, all block linears)" if fp8 else "gemm_pp_kernel + gemm_w4_kernel (bf16 MFMA GEMM: the 152 block-linear launches of a step, 76 on each)",
                 "achieved": round(ach, 1), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "peak_note": "2500 = dense bf16 MFMA peak at 2.4 GHz; a register-only MFMA loop (tools/mfma_peak.hip) sustains 2020 on this part (power cap, ~1.95 GHz)",
