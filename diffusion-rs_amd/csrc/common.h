@@ -61,7 +61,9 @@ __device__ __forceinline__ float gelu_tanh(float v) {
   float u = k * v * (1.0f + 0.044715f * v * v);
   // tanh(u) = 1 - 2/(exp(2u)+1); saturates cleanly for large |u|
   float e = __expf(2.0f * u);
-  float t = 1.0f - 2.0f / (e + 1.0f);
+  // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions): the GELU of a 256 x 256 tile is 128 of
+  // these per lane in the GEMM epilogue; the error is far below the bf16 rounding of the result
+  float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
   return 0.5f * v * (1.0f + t);
 }
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
