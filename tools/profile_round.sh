@@ -24,3 +24,5 @@ tail -1 "$OUT/bench_under_rocprof.json" > "$OUT/${TAG}_bench_under_rocprof.json"
 head -12 "$OUT/${TAG}_kernel_stats.txt"
 head -6 "$OUT/${TAG}_pmc_fetch_size.txt"
 head -6 "$OUT/${TAG}_pmc_write_size.txt"
+# the rocpd databases are tens of MB each and gpurun merges at most 64 MiB back: keep only the summaries unless asked
+[ -n "$KEEP_DB" ] || rm -rf "$OUT/kt" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE"
