@@ -5,7 +5,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 PKG := diffusion-rs_amd
 CSRC := $(PKG)/csrc
-HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value -Wno-unused-result -ffp-contract=on
+HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value -Wno-unused-result -ffp-contract=on
 SRCS := $(wildcard $(CSRC)/*.hip)
 OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 LIB := $(PKG)/libflux_mi355x.so
@@ -15,7 +15,7 @@ lib: $(LIB)
 oracle:
 	$(MAKE) -C oracle -s
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/flux_mi355x.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h include/flux_mi355x.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -83,6 +83,7 @@ def load():
     lib.fmi_vae_shift_factor.restype = C.c_double
     lib.fmi_unpack_latents.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     lib.fmi_randn.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.fmi_philox_u32.argtypes = lib.fmi_randn.argtypes
     lib.fmi_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.fmi_free.argtypes = [C.c_void_p]
     lib.fmi_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -91,6 +92,11 @@ def load():
     lib.fmi_vae_set_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
     lib.fmi_flux_set_linear_bnb4.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.fmi_flux_set_linear_int8.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.fmi_flux_state_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.fmi_flux_state_adopt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.fmi_flux_state_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.fmi_flux_set_quant_dense_cache.argtypes = [C.c_void_p, C.c_int]
+    lib.fmi_flux_set_attention_rescale_threshold.argtypes = [C.c_void_p, C.c_int]
     lib.fmi_flux_forward.argtypes = [C.c_void_p, C.POINTER(FluxInputs), C.c_void_p, C.c_void_p]
     for enc in ("t5", "clip"):
         getattr(lib, f"fmi_{enc}_set_tensor").argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
@@ -144,17 +150,17 @@ def check(rc):
         raise FmiError(f"fmi status {rc}: {load().fmi_last_error().decode(errors='replace')}")
 
 
-# every symbol include/flux_mi355x.h declares (tests/test_abi.py checks they are all exported)
+# every symbol include/flux_mi355x.h declares (tests/test_host_logic.py::test_library_exports_every_header_symbol checks they are all exported)
 EXPORTED = [
     "fmi_last_error", "fmi_abi_version", "fmi_init", "fmi_device_info", "fmi_flux_default_config", "fmi_flux_create", "fmi_flux_destroy",
-    "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_set_linear_int8", "fmi_flux_set_quant_dense_cache", "fmi_flux_set_modulation_gemm", "fmi_flux_quantize_fp8", "fmi_flux_set_fp8_attention", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
+    "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_set_linear_int8", "fmi_flux_set_quant_dense_cache", "fmi_set_bnb4_onewave_min_rows", "fmi_flux_set_attention_rescale_threshold", "fmi_flux_state_buffer_count", "fmi_flux_state_export", "fmi_flux_state_adopt", "fmi_flux_state_buffer", "fmi_flux_set_modulation_gemm", "fmi_flux_quantize_fp8", "fmi_flux_set_fp8_attention", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
     "fmi_flux_forward", "fmi_flux_denoise", "fmi_flux_set_profiling", "fmi_flux_set_fused_qkv_relayout", "fmi_flux_phase_count", "fmi_flux_phase_name", "fmi_flux_phase_ms",
     "fmi_vae_default_config", "fmi_vae_create", "fmi_vae_destroy", "fmi_vae_set_tensor", "fmi_vae_missing_count", "fmi_vae_missing_name",
     "fmi_vae_scale_factor", "fmi_vae_shift_factor", "fmi_vae_decode", "fmi_vae_encode",
     "fmi_t5_default_config", "fmi_t5_create", "fmi_t5_destroy", "fmi_t5_set_tensor", "fmi_t5_missing_count", "fmi_t5_missing_name",
     "fmi_t5_size_in_bytes", "fmi_t5_forward", "fmi_clip_default_config", "fmi_clip_create", "fmi_clip_destroy", "fmi_clip_set_tensor",
     "fmi_clip_missing_count", "fmi_clip_missing_name", "fmi_clip_size_in_bytes", "fmi_clip_forward", "fmi_pack_latents", "fmi_unpack_latents", "fmi_postprocess_u8",
-    "fmi_randn", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_layernorm_mod",
+    "fmi_randn", "fmi_philox_u32", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_layernorm_mod",
     "fmi_groupnorm_nhwc", "fmi_conv2d_nhwc",
     "dequantize_blockwise_f32_int8", "dequantize_blockwise_f32_fp4", "dequantize_blockwise_f32_nf4", "dequantize_blockwise_f16_int8",
     "dequantize_blockwise_f16_fp4", "dequantize_blockwise_f16_nf4", "dequantize_blockwise_bf16_int8", "dequantize_blockwise_bf16_fp4",

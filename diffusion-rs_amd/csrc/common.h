@@ -25,6 +25,19 @@ int fail(fmi_status st, const std::string& msg);
     if (_rc != FMI_OK) return _rc; \
   } while (0)
 #define FMI_LAUNCH_CHECK() FMI_HIP_TRY(hipGetLastError())
+// A handle remembers the device it was created on; every entry point makes it the calling thread's current device
+// (hipSetDevice is per thread, and the Python front door calls from whichever thread holds the pipeline lock).
+inline int current_device() {
+  int d = 0;
+  hipGetDevice(&d);
+  return d;
+}
+inline int use_device_ordinal(int dev) {
+  int cur = -1;
+  FMI_HIP_TRY(hipGetDevice(&cur));
+  if (cur != dev) FMI_HIP_TRY(hipSetDevice(dev));
+  return FMI_OK;
+}
 
 // ---------------------------------------------------------------- bf16 helpers (device)
 typedef uint16_t bf16_t;  // raw bits
@@ -169,7 +182,8 @@ struct GemmProblem {
 };
 int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream);
 void set_gemm_w4(bool on);        // dense N>128 launches without the fused relayout: the 4-wave 128x128-per-wave kernel
-void set_gemm_pingpong(bool on);  // dense N>128 launches: ping-pong kernel (default) or the double-buffered one
+void set_gemm_pingpong(bool on);
+void set_gemm_w4q_min_rows(int rows);  // 4-bit weights: M from which the one-wave-per-SIMD fused dequant-GEMM runs (default 256)  // dense N>128 launches: ping-pong kernel (default) or the double-buffered one
 
 // attention output routing: query rows [0,rows0) -> p0, the rest -> p1 (token-major, head h at
 // column h*128); or head-major (B,H,Lq,128) in p1.

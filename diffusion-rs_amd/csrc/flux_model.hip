@@ -1,12 +1,18 @@
-// flux_model.hip — host side of the FLUX DiT: weight arena, diffusers-name resolution, and the
+// flux_model.hip — host side of the FLUX DiT: weight arenas, diffusers-name resolution, and the
 // kernel schedule of Flux::forward (diffusion_rs_core/src/models/flux/model.rs:790-833) and
 // Sampler::sample (pipelines/sampling.rs:25-48).
 //
-// Memory plan (MI355X, 288 GB HBM3E): one bf16 weight arena (23.8 GB for FLUX.1) holding FUSED
-// matrices — [q|k|v] per stream of a double block, [q|k|v|proj_mlp] per single block, and ONE
-// (344*D, D) matrix with every modulation linear of the model so all AdaLN vectors of a step
-// come from a single weight-streaming GEMV.  Activations live in a per-(B,S,T) workspace that is
-// allocated once and reused by every step; nothing is allocated inside a step.
+// Memory plan (MI355X, 288 GB HBM3E): weights live in four arenas holding FUSED matrices — [q|k|v] per stream of a
+// double block, [q|k|v|proj_mlp] per single block, and ONE (344*D, D) matrix with every modulation linear of the
+// model so all AdaLN vectors of an image come from a single weight-streaming GEMM:
+//   BASE    embedders, final projection, QkNorm weights, every bias            (always allocated, ~0.3 GB)
+//   MOD     the modulation matrix in bf16 (6.5 GB)                             (allocated when a dense part arrives)
+//   BLOCKS  the block linears in bf16 (17.0 GB)                                (allocated when a dense part arrives)
+//   Q4      the same matrices as bitsandbytes nf4 / fp4 codes + f32 absmax     (allocated when a 4-bit part arrives)
+// so a bf16 checkpoint occupies 23.8 GB and an nf4 one 6.7 GB — no bf16 duplicate of a quantised layer is resident
+// unless the caller asks for the expanded cache (fmi_flux_set_quant_dense_cache).  The arenas are also the unit of
+// the multi-GPU weight broadcast (fmi_flux_state_*).  Activations live in a per-(B,S,T) workspace that is allocated
+// once and reused by every step; nothing is allocated inside a step.
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -21,20 +27,40 @@ using namespace fmi;
 
 namespace {
 
+enum ArenaId { AR_BASE = 0, AR_MOD, AR_BLOCKS, AR_Q4, AR_COUNT };
+struct Arena {
+  char* base = nullptr;
+  size_t bytes = 0;  // layout size
+};
+enum PartState : uint8_t { PS_UNSET = 0, PS_FP4 = 1, PS_NF4 = 2, PS_INT8 = 3, PS_DENSE = 100 };
+
 struct Dense {  // one (possibly fused) Linear: W (N,K) bf16 row-major, bias (N) bf16
-  bf16_t* w = nullptr;
-  bf16_t* b = nullptr;
+  bf16_t* w = nullptr;  // null until the arena `ar` is allocated
+  bf16_t* b = nullptr;  // BASE arena
   int N = 0, K = 0;
-  // optional 4-bit form (bitsandbytes nf4/fp4), replaces w
-  uint8_t* wq = nullptr;
+  int ar = AR_BASE;
+  size_t w_off = 0, q_off = 0, am_off = 0;  // byte offsets in `ar` / in Q4 (packed codes, absmax sized for blocksize 64)
+  // quantised form, used instead of w when q_type != 0 (set by finalize(): every part holds the same kind)
+  uint8_t* wq = nullptr;   // Q4 arena (4-bit) or its own allocation (int8)
   float* absmax = nullptr;
-  int q_type = 0, q_blocksize = 0;
+  bool q_own = false;
+  int q_type = 0, q_blocksize = 0;  // 1 fp4, 2 nf4, 3 LLM.int8 (wq = int8 (N,K), absmax = SCB (N))
   // optional fp8 form (fmi_flux_quantize_fp8): e4m3 (N,K) + per-output-channel f32 scale, used instead of w
   uint8_t* w8 = nullptr;
   float* w8_scale = nullptr;
+  // the named Linears this matrix is made of (rows r0 .. r0+rows) and what each was loaded as
+  struct Part {
+    int r0, rows;
+    uint8_t state;
+    int blocksize;
+  };
+  std::vector<Part> parts;
 };
 
 struct Dest {  // where a named tensor lands
+  Dense* d;    // weight / bias of part `part` of a Dense, or null: `ptr` directly (QkNorm weights)
+  int part;
+  bool bias;
   void* ptr;
   int64_t numel;
   int rows, cols;  // expected shape (cols == 0 -> 1-D of `rows`)
@@ -49,9 +75,11 @@ const char* kPhaseNames[PH_COUNT] = {"embed", "modulation", "layernorm_mod", "ge
 struct fmi_flux {
   fmi_flux_config cfg;
   int D, M, H;
-  // arena
-  char* arena = nullptr;
-  size_t arena_bytes = 0, arena_used = 0;
+  int device = 0;
+  Arena arena[AR_COUNT];
+  size_t cursor[AR_COUNT] = {0, 0, 0, 0};  // layout cursors
+  std::vector<Dense*> fused;  // every Dense whose parts can arrive quantised (block linears + the modulation matrix), fixed order
+  bool finalized = false;
   // weights
   Dense img_in, txt_in, time1, time2, guid1, guid2, vecin1, vecin2, final_proj;
   Dense mod_all;  // (n_mod, D)
@@ -79,7 +107,7 @@ struct fmi_flux {
     char* base = nullptr;
     size_t bytes = 0;
     float *x_img, *x_txt, *x, *vec, *mod, *temb, *h1, *yf, *pe, *img_f32, *pred_tmp, *tv;
-    bf16_t *img_bf, *txt_bf, *xm, *qkv_img, *qkv_txt, *big, *Qh, *Kh, *Vt, *attn_img, *attn_txt, *hid;
+    bf16_t *img_bf, *txt_bf, *xm, *qkv_img, *qkv_txt, *big, *Qh, *Kh, *Vt, *attn_img, *attn_txt, *hid, *vec_bf;
     uint8_t* a8 = nullptr;  // fp8 mode: the current GEMM input, rows [txt | img], (B*L, <= D+M) e4m3
     float* a8s = nullptr;   //           its per-token scales (B*L)
     int Lpad = 0;
@@ -96,13 +124,12 @@ struct fmi_flux {
   size_t mod_steps_rows = 0;
   bf16_t* wscratch[2] = {nullptr, nullptr};
   size_t wscratch_elems = 0;
-  int q_fused_max_rows = 512;  // M below this keeps the fused dequant-GEMM (weight-bandwidth-bound regime)
   bool mod_gemm = true;  // fmi_flux_denoise: all steps' modulation vectors in one MFMA GEMM (else GEMV passes of 4 rows)
   bool fuse_qkv_relayout = true;  // QkNorm + RoPE + head/transposed relayout in the QKV GEMM's epilogue
-  // Quantised block linears at large M: expanded ONCE into the layer's own slot of the bf16 arena (which
-  // is laid out for the whole dense model anyway) and reused by every later step, instead of once per GEMM
-  // call into the scratch (28 GB of traffic per denoise step for an nf4 FLUX.1-dev).
-  bool dense_cache = true;
+  // Quantised block linears: by default the fused dequant-GEMM reads the packed codes on every call (gemm_w4q.h).
+  // Opt-in cache (fmi_flux_set_quant_dense_cache): expand ONCE into the layer's slot of the BLOCKS arena — allocated
+  // on first use, 17 GB more — and run the dense kernels; LLM.int8 layers without the cache expand per call into a scratch.
+  bool dense_cache = false;
   std::set<const void*> dense_ready;
   // fp8 mode (fmi_flux_quantize_fp8)
   bool fp8 = false;
@@ -118,80 +145,128 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-template <typename T>
-T* arena_take(fmi_flux* m, size_t count) {
-  size_t off = align_up(m->arena_used, 256);
-  m->arena_used = off + count * sizeof(T);
-  return reinterpret_cast<T*>(m->arena + off);
+size_t arena_take(fmi_flux* m, int ar, size_t bytes) {
+  const size_t off = align_up(m->cursor[ar], 256);
+  m->cursor[ar] = off + bytes;
+  return off;
+}
+// Allocate arena `ar` (zero-filled) on first need and resolve the pointers of every matrix laid out in it.
+int ensure_arena(fmi_flux* m, int ar) {
+  Arena& a = m->arena[ar];
+  if (a.base || a.bytes == 0) return FMI_OK;
+  hipError_t e = hipMalloc((void**)&a.base, a.bytes);
+  if (e != hipSuccess) return fail(FMI_ERR_NOMEM, "flux: hipMalloc of " + std::to_string(a.bytes) + " bytes (weight arena " + std::to_string(ar) + ") failed: " + hipGetErrorString(e));
+  FMI_HIP_TRY(hipMemset(a.base, 0, a.bytes));
+  for (Dense* d : m->fused) {
+    if (ar == d->ar) d->w = reinterpret_cast<bf16_t*>(a.base + d->w_off);
+    if (ar == AR_Q4 && !d->q_own) {
+      d->wq = reinterpret_cast<uint8_t*>(a.base + d->q_off);
+      d->absmax = reinterpret_cast<float*>(a.base + d->am_off);
+    }
+  }
+  return FMI_OK;
 }
 
-// two passes: pass 0 counts bytes (arena == nullptr), pass 1 hands out pointers
-void layout_dense(fmi_flux* m, Dense& d, int N, int K, bool bias = true) {
+// Layout pass (offsets only; BASE pointers are resolved by the caller once that arena exists).
+void layout_dense(fmi_flux* m, Dense& d, int N, int K, int ar, bool bias = true) {
   d.N = N;
   d.K = K;
-  d.w = arena_take<bf16_t>(m, (size_t)N * K);
-  d.b = bias ? arena_take<bf16_t>(m, (size_t)N) : nullptr;
+  d.ar = ar;
+  d.w_off = arena_take(m, ar, (size_t)N * K * 2);
+  d.b = bias ? reinterpret_cast<bf16_t*>(arena_take(m, AR_BASE, (size_t)N * 2) + 1) : nullptr;  // offset + 1, rebased below
+  if (ar != AR_BASE) {
+    d.q_off = arena_take(m, AR_Q4, (size_t)N * K / 2);
+    d.am_off = arena_take(m, AR_Q4, (size_t)N * K / 64 * 4);
+    m->fused.push_back(&d);
+  }
 }
 
 void reg(fmi_flux* m, const std::string& name, void* ptr, int rows, int cols) {
-  Dest d{ptr, (int64_t)rows * (cols ? cols : 1), rows, cols};
+  Dest d{nullptr, 0, false, ptr, (int64_t)rows * (cols ? cols : 1), rows, cols};
   m->names[name] = d;
   m->missing.insert(name);
 }
 // register W/bias of a Linear that occupies rows [r0, r0+rows) of a fused Dense
 void reg_lin(fmi_flux* m, const std::string& prefix, Dense& d, int r0, int rows) {
-  reg(m, prefix + ".weight", d.w + (size_t)r0 * d.K, rows, d.K);
-  if (d.b) reg(m, prefix + ".bias", d.b + r0, rows, 0);
+  const int part = (int)d.parts.size();
+  d.parts.push_back({r0, rows, PS_UNSET, 0});
+  m->names[prefix + ".weight"] = Dest{&d, part, false, nullptr, (int64_t)rows * d.K, rows, d.K};
+  m->missing.insert(prefix + ".weight");
+  if (d.b) {
+    m->names[prefix + ".bias"] = Dest{&d, part, true, d.b + r0, rows, rows, 0};
+    m->missing.insert(prefix + ".bias");
+  }
 }
 
 void build_layout(fmi_flux* m) {
   const fmi_flux_config& c = m->cfg;
   const int D = m->D, M = m->M;
-  m->arena_used = 0;
-  m->names.clear();
-  m->missing.clear();
-  layout_dense(m, m->img_in, D, c.in_channels);
-  layout_dense(m, m->txt_in, D, c.joint_attention_dim);
-  layout_dense(m, m->time1, D, 256);
-  layout_dense(m, m->time2, D, D);
+  layout_dense(m, m->img_in, D, c.in_channels, AR_BASE);
+  layout_dense(m, m->txt_in, D, c.joint_attention_dim, AR_BASE);
+  layout_dense(m, m->time1, D, 256, AR_BASE);
+  layout_dense(m, m->time2, D, D, AR_BASE);
   if (c.guidance_embeds) {
-    layout_dense(m, m->guid1, D, 256);
-    layout_dense(m, m->guid2, D, D);
+    layout_dense(m, m->guid1, D, 256, AR_BASE);
+    layout_dense(m, m->guid2, D, D, AR_BASE);
   }
-  layout_dense(m, m->vecin1, D, c.pooled_projection_dim);
-  layout_dense(m, m->vecin2, D, D);
-  layout_dense(m, m->final_proj, c.in_channels, D);
+  layout_dense(m, m->vecin1, D, c.pooled_projection_dim, AR_BASE);
+  layout_dense(m, m->vecin2, D, D, AR_BASE);
+  layout_dense(m, m->final_proj, c.in_channels, D, AR_BASE);
   m->n_mod = (int64_t)c.num_layers * 12 * D + (int64_t)c.num_single_layers * 3 * D + 2 * D;
-  layout_dense(m, m->mod_all, (int)m->n_mod, D);
+  layout_dense(m, m->mod_all, (int)m->n_mod, D, AR_MOD);
   m->dbl.resize(c.num_layers);
   m->sgl.resize(c.num_single_layers);
   int64_t moff = 0;
+  std::vector<bf16_t**> norm_ptrs;  // QkNorm weights: BASE offsets (+1) stored in the pointer until the arena exists
+  auto take_norm = [&](bf16_t*& p) {
+    p = reinterpret_cast<bf16_t*>(arena_take(m, AR_BASE, 128 * 2) + 1);
+    norm_ptrs.push_back(&p);
+  };
   for (int i = 0; i < c.num_layers; ++i) {
     auto& b = m->dbl[i];
     for (int s = 0; s < 2; ++s) {
-      layout_dense(m, b.qkv[s], 3 * D, D);
-      layout_dense(m, b.proj[s], D, D);
-      layout_dense(m, b.mlp1[s], M, D);
-      layout_dense(m, b.mlp2[s], D, M);
-      b.nq[s] = arena_take<bf16_t>(m, 128);
-      b.nk[s] = arena_take<bf16_t>(m, 128);
+      layout_dense(m, b.qkv[s], 3 * D, D, AR_BLOCKS);
+      layout_dense(m, b.proj[s], D, D, AR_BLOCKS);
+      layout_dense(m, b.mlp1[s], M, D, AR_BLOCKS);
+      layout_dense(m, b.mlp2[s], D, M, AR_BLOCKS);
+      take_norm(b.nq[s]);
+      take_norm(b.nk[s]);
       b.mod_off[s] = moff;
       moff += 6 * D;
     }
   }
   for (int i = 0; i < c.num_single_layers; ++i) {
     auto& b = m->sgl[i];
-    layout_dense(m, b.w1, 3 * D + M, D);
-    layout_dense(m, b.w2, D, D + M);
-    b.nq = arena_take<bf16_t>(m, 128);
-    b.nk = arena_take<bf16_t>(m, 128);
+    layout_dense(m, b.w1, 3 * D + M, D, AR_BLOCKS);
+    layout_dense(m, b.w2, D, D + M, AR_BLOCKS);
+    take_norm(b.nq);
+    take_norm(b.nk);
     b.mod_off = moff;
     moff += 3 * D;
   }
   m->mod_final_off = moff;
+  for (int a = 0; a < AR_COUNT; ++a) m->arena[a].bytes = align_up(m->cursor[a], 256) + 256;
+}
 
-  if (!m->arena) return;  // counting pass
-  // ---- names (diffusers names looked up by Flux::new, model.rs:165-772)
+// BASE exists: turn the stored offsets into pointers and register the diffusers names looked up by Flux::new (model.rs:165-772)
+void resolve_base_and_names(fmi_flux* m) {
+  const fmi_flux_config& c = m->cfg;
+  const int D = m->D, M = m->M;
+  char* base = m->arena[AR_BASE].base;
+  auto fix = [&](bf16_t*& p) {
+    if (p) p = reinterpret_cast<bf16_t*>(base + (reinterpret_cast<uintptr_t>(p) - 1));
+  };
+  std::vector<Dense*> small = {&m->img_in, &m->txt_in, &m->time1, &m->time2, &m->vecin1, &m->vecin2, &m->final_proj};
+  if (c.guidance_embeds) small.push_back(&m->guid1), small.push_back(&m->guid2);
+  for (Dense* d : small) {
+    d->w = reinterpret_cast<bf16_t*>(base + d->w_off);
+    fix(d->b);
+  }
+  for (Dense* d : m->fused) fix(d->b);
+  for (auto& b : m->dbl)
+    for (int s = 0; s < 2; ++s) fix(b.nq[s]), fix(b.nk[s]);
+  for (auto& b : m->sgl) fix(b.nq), fix(b.nk);
+
   reg_lin(m, "x_embedder", m->img_in, 0, D);
   reg_lin(m, "context_embedder", m->txt_in, 0, D);
   reg_lin(m, "time_text_embed.timestep_embedder.linear_1", m->time1, 0, D);
@@ -236,6 +311,52 @@ void build_layout(fmi_flux* m) {
     reg(m, p + "attn.norm_k.weight", b.nk, 128, 0);
     reg_lin(m, p + "proj_out", b.w2, 0, D);
   }
+}
+
+// 4-bit / int8 rows [r0, r0+rows) of `d` -> bf16 rows of d.w (the stand-alone kernels of bnb_dequant.hip)
+int dequant_rows(Dense& d, int r0, int rows, int kind, int blocksize, hipStream_t s) {
+  const int64_t n = (int64_t)rows * d.K;
+  if (n >= (1ll << 31)) return fail(FMI_ERR_UNSUPPORTED, "flux: quantised linear too large");
+  bf16_t* dst = d.w + (size_t)r0 * d.K;
+  if (kind == PS_INT8) return launch_dequant_int8_scb_bf16(reinterpret_cast<const int8_t*>(d.wq) + (size_t)r0 * d.K, d.absmax + r0, dst, d.K, n, s);
+  const uint8_t* src = d.wq + (size_t)r0 * d.K / 2;
+  const float* am = d.absmax + (size_t)r0 * d.K / blocksize;
+  if (kind == PS_NF4) dequantize_blockwise_bf16_nf4(nullptr, src, am, dst, blocksize, (int)n, s);
+  else dequantize_blockwise_bf16_fp4(nullptr, src, am, dst, blocksize, (int)n, s);
+  return FMI_OK;
+}
+
+// Decide how every fused matrix is multiplied: all parts the same quantised kind -> that kind (packed form only);
+// all dense -> dense; a mixture (e.g. a checkpoint that quantises to_q but not to_v) -> the quantised parts are
+// expanded into the dense arena once and the matrix is dense.
+int finalize(fmi_flux* m) {
+  if (m->finalized) return FMI_OK;
+  for (Dense* d : m->fused) {
+    bool any_dense = false, uniform = true;
+    const uint8_t k0 = d->parts.empty() ? (uint8_t)PS_DENSE : d->parts[0].state;
+    const int bs0 = d->parts.empty() ? 0 : d->parts[0].blocksize;
+    for (auto& pt : d->parts) {
+      if (pt.state == PS_DENSE) any_dense = true;
+      if (pt.state != k0 || pt.blocksize != bs0) uniform = false;
+    }
+    if (uniform && !any_dense) {
+      d->q_type = k0, d->q_blocksize = bs0;
+      continue;
+    }
+    if (!uniform) {
+      FMI_TRY(ensure_arena(m, d->ar));
+      for (auto& pt : d->parts)
+        if (pt.state != PS_DENSE) {
+          FMI_TRY(dequant_rows(*d, pt.r0, pt.rows, pt.state, pt.blocksize, nullptr));
+          pt.state = PS_DENSE, pt.blocksize = 0;
+        }
+      FMI_HIP_TRY(hipDeviceSynchronize());
+    }
+    d->q_type = 0, d->q_blocksize = 0;
+  }
+  m->dense_ready.clear();
+  m->finalized = true;
+  return FMI_OK;
 }
 
 int ensure_workspace(fmi_flux* m, int B, int S, int T) {
@@ -283,6 +404,7 @@ int ensure_workspace(fmi_flux* m, int B, int S, int T) {
   add((void**)&w.attn_img, (size_t)B * S * D * 2);
   add((void**)&w.attn_txt, (size_t)B * T * D * 2);
   add((void**)&w.hid, (size_t)B * L * M * 2);
+  add((void**)&w.vec_bf, (size_t)B * D * 2);
   if (m->fp8) {
     add((void**)&w.a8, (size_t)B * L * (D + M));
     add((void**)&w.a8s, (size_t)B * L * 4);
@@ -348,6 +470,7 @@ bool with_qkv_relayout(fmi_flux* m, GemmProblem& p, const bf16_t* nq, const bf16
                        float k8 = 0.f) {
   auto& w = m->ws;
   if (!can_fuse_relayout(m, p.M, rows, row_off) || p.N < 256) return false;
+  if (p.q_type && !m->dense_cache) return false;  // packed weights run on the one-wave-per-SIMD kernel: relayout by the stand-alone kernels
   p.qk_q8 = q8, p.qk_k8 = k8;
   p.qk_qh = w.Qh, p.qk_kh = w.Kh, p.qk_vt = w.Vt;
   p.qk_wq = nq, p.qk_wk = nk;
@@ -360,62 +483,54 @@ void with_gate(GemmProblem& p, const float* gate, int rows_per_batch, int bstrid
   p.rows_per_batch = rows_per_batch;
   p.gate_bstride = bstride;
 }
-// 4-bit weights: the fused dequant-GEMM re-expands a weight tile once per M tile, which wins while
-// the GEMM is weight-bandwidth-bound (few M tiles) and loses when it is MFMA-bound (at M = 4608 the
-// fused kernel ran at 456 TFLOP/s vs ~1000 dense).  Above `q_fused_max_rows` rows the weight is
-// dequantised ONCE per call into a reusable bf16 scratch (0.5 B read + 2 B written per weight,
-// HBM-streaming) and the dense MFMA kernel runs — BnbLinear::forward's "dequantize_w then matmul"
-// (bitsandbytes/mod.rs:301-312) without allocating or leaving the device.
-int densify(fmi_flux* m, GemmProblem* p, int n, hipStream_t s) {
+// Quantised linears (BnbLinear::forward, bitsandbytes/mod.rs:293-312: "dequantize_w then matmul"):
+//   nf4 / fp4  -> the fused dequant-GEMM reads the packed codes (launch_gemm picks the kernel by M), nothing is expanded;
+//                 with the dense cache on, the matrix is expanded once into its slot of the BLOCKS / MOD arena instead;
+//   LLM.int8   -> expanded (w * SCB / 127) into the arena slot (cache on) or, per call, into a reusable scratch.
+int densify(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s) {
   for (int i = 0; i < n && i < 2; ++i) {
-    // q_type 3 = LLM.int8 (SCB): no fused kernel, always expanded (BnbLinear::Int8 forward, mod.rs:293-300)
-    if (!p[i].q_type || (p[i].q_type != 3 && p[i].M < m->q_fused_max_rows)) continue;
+    Dense* d = dn[i];
+    if (!d || !p[i].q_type) continue;
+    if (p[i].q_type != 3 && !m->dense_cache) continue;  // fused 4-bit path
     const size_t elems = (size_t)p[i].N * p[i].K;
-    if (m->dense_cache && p[i].W && p[i].ldw == p[i].K) {
-      bf16_t* slot = const_cast<bf16_t*>(p[i].W);
-      if (!m->dense_ready.count(slot)) {
-        if (elems >= (1ull << 31)) return fail(FMI_ERR_UNSUPPORTED, "densify: weight too large");
-        if (p[i].q_type == 3)
-          FMI_TRY(launch_dequant_int8_scb_bf16(reinterpret_cast<const int8_t*>(p[i].Wq), p[i].absmax, slot, p[i].K, (int64_t)elems, s));
-        else if (p[i].q_type == 2)
-          dequantize_blockwise_bf16_nf4(nullptr, p[i].Wq, p[i].absmax, slot, p[i].q_blocksize, (int)elems, s);
-        else
-          dequantize_blockwise_bf16_fp4(nullptr, p[i].Wq, p[i].absmax, slot, p[i].q_blocksize, (int)elems, s);
-        m->dense_ready.insert(slot);
-      }
-      p[i].Wq = nullptr, p[i].absmax = nullptr, p[i].q_type = 0, p[i].q_blocksize = 0;
-      continue;
-    }
-    if (elems > m->wscratch_elems || !m->wscratch[0]) {
-      const size_t want = std::max(elems, (size_t)(3 * m->D + m->M) * (size_t)m->D);  // largest fused weight of the model
-      FMI_HIP_TRY(hipDeviceSynchronize());
-      for (int k = 0; k < 2; ++k) {
-        if (m->wscratch[k]) FMI_HIP_TRY(hipFree(m->wscratch[k]));
-        FMI_HIP_TRY(hipMalloc((void**)&m->wscratch[k], want * sizeof(bf16_t)));
-      }
-      m->wscratch_elems = want;
-    }
     if (elems >= (1ull << 31)) return fail(FMI_ERR_UNSUPPORTED, "densify: weight too large");
-    if (p[i].q_type == 3)
+    if (m->dense_cache) {
+      FMI_TRY(ensure_arena(m, d->ar));
+      if (!m->dense_ready.count(d)) {
+        FMI_TRY(dequant_rows(*d, 0, d->N, d->q_type, d->q_blocksize, s));
+        m->dense_ready.insert(d);
+      }
+      p[i].W = d->w;
+    } else {
+      if (elems > m->wscratch_elems || !m->wscratch[0]) {
+        const size_t want = std::max(elems, (size_t)(3 * m->D + m->M) * (size_t)m->D);  // largest fused weight of the model
+        FMI_HIP_TRY(hipDeviceSynchronize());
+        for (int k = 0; k < 2; ++k) {
+          if (m->wscratch[k]) FMI_HIP_TRY(hipFree(m->wscratch[k]));
+          FMI_HIP_TRY(hipMalloc((void**)&m->wscratch[k], want * sizeof(bf16_t)));
+        }
+        m->wscratch_elems = want;
+      }
       FMI_TRY(launch_dequant_int8_scb_bf16(reinterpret_cast<const int8_t*>(p[i].Wq), p[i].absmax, m->wscratch[i], p[i].K, (int64_t)elems, s));
-    else if (p[i].q_type == 2)
-      dequantize_blockwise_bf16_nf4(nullptr, p[i].Wq, p[i].absmax, m->wscratch[i], p[i].q_blocksize, (int)elems, s);
-    else
-      dequantize_blockwise_bf16_fp4(nullptr, p[i].Wq, p[i].absmax, m->wscratch[i], p[i].q_blocksize, (int)elems, s);
-    p[i].W = m->wscratch[i];
+      p[i].W = m->wscratch[i];
+    }
     p[i].ldw = p[i].K;
     p[i].Wq = nullptr, p[i].absmax = nullptr, p[i].q_type = 0, p[i].q_blocksize = 0;
   }
   return FMI_OK;
 }
-// launch 1 or 2 problems; quantised and dense problems cannot share a grid
-int gemm2(fmi_flux* m, GemmProblem* p, int n, hipStream_t s) {
-  FMI_TRY(densify(m, p, n, s));
+// launch 1 or 2 problems (dn[i] = the weight matrix of problem i); quantised and dense problems cannot share a grid
+int gemm2(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s) {
+  FMI_TRY(densify(m, p, dn, n, s));
   if (n == 2 && (p[0].q_type != 0) != (p[1].q_type != 0)) {
     FMI_TRY(launch_gemm(p, 1, s));
     return launch_gemm(p + 1, 1, s);
   }
   return launch_gemm(p, n, s);
+}
+int gemm1(fmi_flux* m, GemmProblem& p, Dense& d, hipStream_t s) {
+  Dense* dn[1] = {&d};
+  return gemm2(m, &p, dn, 1, s);
 }
 
 struct PhaseTimer {
@@ -439,8 +554,10 @@ struct PhaseTimer {
 int check_ready(fmi_flux* m) {
   if (!m->missing.empty())
     return fail(FMI_ERR_STATE, "flux: " + std::to_string(m->missing.size()) + " tensors not set, first: " + *m->missing.begin());
-  return FMI_OK;
+  return finalize(m);
 }
+// the handle's device becomes the calling thread's current device (hipSetDevice is per thread)
+int use_device(const fmi_flux* m) { return use_device_ordinal(m->device); }
 
 // Everything of Flux::forward that does not depend on the timestep: input casts + RoPE table.
 int prepare_static(fmi_flux* m, const fmi_flux_inputs* in, hipStream_t s) {
@@ -495,12 +612,19 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     GemmProblem p[2];
     p[0] = make_problem(m->img_in, w.img_bf, C, B * S, w.x_img, D, EPI_STORE_F32);
     p[1] = make_problem(m->txt_in, w.txt_bf, c.joint_attention_dim, B * T, w.x_txt, D, EPI_STORE_F32);
-    FMI_TRY(gemm2(m, p, 2, s));
+    Dense* dn[2] = {&m->img_in, &m->txt_in};
+    FMI_TRY(gemm2(m, p, dn, 2, s));
   }
   if (!mod_pre) {
     // every Modulation1/2 + LastLayer.ada_ln of the model in one GEMV: lin(silu(vec)) (model.rs:244-299,695-698)
     PhaseTimer pt(m, s, PH_MOD);
-    FMI_TRY(launch_gemv(w.vec, m->mod_all.w, m->mod_all.b, w.mod, B, nmod, D, 1, 0, s));
+    if (m->mod_all.q_type) {  // quantised modulation matrix: bf16(silu(vec)) through the fused dequant-GEMM
+      FMI_TRY(launch_silu_to_bf16(w.vec, w.vec_bf, (int64_t)B * D, s));
+      GemmProblem p = make_problem(m->mod_all, w.vec_bf, D, B, w.mod, nmod, EPI_STORE_F32);
+      FMI_TRY(gemm1(m, p, m->mod_all, s));
+    } else {
+      FMI_TRY(launch_gemv(w.vec, m->mod_all.w, m->mod_all.b, w.mod, B, nmod, D, 1, 0, s));
+    }
   }
   const float* const mod = mod_pre ? mod_pre : w.mod;
 
@@ -535,7 +659,8 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       const float q8 = qk8 ? m->q8_dbl[i] : 0.f, k8 = qk8 ? m->k8_dbl[i] : 0.f;
       fused_img = with_qkv_relayout(m, p[0], bw.nq[0], bw.nk[0], pe_bs, S, T, L, q8, k8);
       fused_txt = with_qkv_relayout(m, p[1], bw.nq[1], bw.nk[1], pe_bs, T, 0, L, q8, k8);
-      FMI_TRY(gemm2(m, p, 2, s));
+      Dense* dn[2] = {&bw.qkv[0], &bw.qkv[1]};
+      FMI_TRY(gemm2(m, p, dn, 2, s));
     }
     if (!(fused_img && fused_txt)) {
       PhaseTimer pt(m, s, PH_RELAYOUT);
@@ -570,7 +695,8 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       p[1] = fp8 ? make_problem_fp8(m, bw.proj[1], 0, B * T, w.x_txt, D, EPI_RESID_GATE_F32)
                  : make_problem(bw.proj[1], w.attn_txt, D, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
       with_gate(p[1], mt + 2 * D, T, nmod);
-      FMI_TRY(gemm2(m, p, 2, s));
+      Dense* dn[2] = {&bw.proj[0], &bw.proj[1]};
+      FMI_TRY(gemm2(m, p, dn, 2, s));
     }
     {
       PhaseTimer pt(m, s, PH_LN);
@@ -589,7 +715,8 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       GemmProblem p[2];
       p[0] = fp8 ? make_problem_fp8(m, bw.mlp1[0], BT, B * S, hid_img, Mh, EPI_GELU_BF16) : make_problem(bw.mlp1[0], xm_img, D, B * S, hid_img, Mh, EPI_GELU_BF16);
       p[1] = fp8 ? make_problem_fp8(m, bw.mlp1[1], 0, B * T, hid_txt, Mh, EPI_GELU_BF16) : make_problem(bw.mlp1[1], xm_txt, D, B * T, hid_txt, Mh, EPI_GELU_BF16);
-      FMI_TRY(gemm2(m, p, 2, s));
+      Dense* dn1[2] = {&bw.mlp1[0], &bw.mlp1[1]};
+      FMI_TRY(gemm2(m, p, dn1, 2, s));
       if (fp8) {  // hid is (B*L, M) with the txt rows first, like a8
         FMI_TRY(launch_quantize_rows_fp8(w.hid, Mh, B * L, Mh, w.a8, w.a8s, s));
       }
@@ -599,7 +726,8 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       p[1] = fp8 ? make_problem_fp8(m, bw.mlp2[1], 0, B * T, w.x_txt, D, EPI_RESID_GATE_F32)
                  : make_problem(bw.mlp2[1], hid_txt, Mh, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
       with_gate(p[1], mt + 5 * D, T, nmod);
-      FMI_TRY(gemm2(m, p, 2, s));
+      Dense* dn2[2] = {&bw.mlp2[0], &bw.mlp2[1]};
+      FMI_TRY(gemm2(m, p, dn2, 2, s));
     }
   }
 
@@ -628,7 +756,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
                           : make_problem(bw.w1, w.xm, D, B * L, w.big, ldbig, EPI_GELU_FROM_COL);
       p.gelu_from = 3 * D;
       fused = with_qkv_relayout(m, p, bw.nq, bw.nk, pe_bs, L, 0, L, qk8 ? m->q8_sgl[i] : 0.f, qk8 ? m->k8_sgl[i] : 0.f);
-      FMI_TRY(gemm2(m, &p, 1, s));
+      FMI_TRY(gemm1(m, p, bw.w1, s));
     }
     if (!fused) {
       PhaseTimer pt(m, s, PH_RELAYOUT);
@@ -651,7 +779,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       GemmProblem p = fp8 ? make_problem_fp8(m, bw.w2, 0, B * L, w.x, D, EPI_RESID_GATE_F32)
                           : make_problem(bw.w2, w.big + 2 * D, ldbig, B * L, w.x, D, EPI_RESID_GATE_F32);
       with_gate(p, mo + 2 * D, L, nmod);
-      FMI_TRY(gemm2(m, &p, 1, s));
+      FMI_TRY(gemm1(m, p, bw.w2, s));
     }
   }
 
@@ -663,7 +791,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       FMI_TRY(launch_layernorm_mod(w.x + ((size_t)b * L + T) * D, mf + (size_t)b * nmod, mf + (size_t)b * nmod + D, 0, 0,
                                    w.xm + (size_t)b * S * D, S, D, 1e-6f, s));
     GemmProblem p = make_problem(m->final_proj, w.xm, D, B * S, pred, C, EPI_STORE_F32);
-    FMI_TRY(gemm2(m, &p, 1, s));
+    FMI_TRY(gemm1(m, p, m->final_proj, s));
   }
   return FMI_OK;
 }
@@ -673,6 +801,7 @@ int check_inputs(fmi_flux* m, const fmi_flux_inputs* in) {
   if (in->B <= 0 || in->S <= 0 || in->T <= 0) return fail(FMI_ERR_INVALID, "flux: B, S, T must be positive");
   if (in->B > 8) return fail(FMI_ERR_UNSUPPORTED, "flux: batch > 8 per device not supported (shard across GPUs)");
   if (!in->img_ids || !in->txt || !in->txt_ids || !in->y) return fail(FMI_ERR_INVALID, "flux: null input tensor");
+  FMI_TRY(use_device(m));
   return check_ready(m);
 }
 
@@ -702,19 +831,16 @@ extern "C" int fmi_flux_create(const fmi_flux_config* cfg, fmi_model_dtype dtype
     return fail(FMI_ERR_INVALID, "flux_create: in_channels and joint_attention_dim must be multiples of 64, pooled dim of 8");
   fmi_flux* m = new fmi_flux();
   m->cfg = *cfg;
+  hipGetDevice(&m->device);
   m->H = cfg->num_attention_heads;
   m->D = m->H * 128;  // HIDDEN_SIZE (model.rs:17) generalised as heads * pe_dim
   m->M = 4 * m->D;    // MLP_RATIO (model.rs:16)
-  build_layout(m);    // counting pass
-  m->arena_bytes = align_up(m->arena_used, 256) + 256;
-  hipError_t e = hipMalloc((void**)&m->arena, m->arena_bytes);
-  if (e != hipSuccess) {
-    size_t need = m->arena_bytes;
-    delete m;
-    return fail(FMI_ERR_NOMEM, "flux_create: hipMalloc of " + std::to_string(need) + " bytes failed: " + hipGetErrorString(e));
-  }
-  hipMemset(m->arena, 0, m->arena_bytes);
   build_layout(m);
+  if (ensure_arena(m, AR_BASE) != FMI_OK) {
+    delete m;
+    return FMI_ERR_NOMEM;
+  }
+  resolve_base_and_names(m);
   hipEventCreate(&m->ev0);
   hipEventCreate(&m->ev1);
   *out = m;
@@ -723,23 +849,19 @@ extern "C" int fmi_flux_create(const fmi_flux_config* cfg, fmi_model_dtype dtype
 
 extern "C" void fmi_flux_destroy(fmi_flux* m) {
   if (!m) return;
+  use_device(m);
   hipDeviceSynchronize();
   if (m->ws.base) hipFree(m->ws.base);
-  if (m->arena) hipFree(m->arena);
+  for (int a = 0; a < AR_COUNT; ++a)
+    if (m->arena[a].base) hipFree(m->arena[a].base);
   for (int k = 0; k < 2; ++k)
     if (m->wscratch[k]) hipFree(m->wscratch[k]);
   if (m->mod_steps) hipFree(m->mod_steps);
   if (m->vec_steps) hipFree(m->vec_steps);
   if (m->vec_steps_bf) hipFree(m->vec_steps_bf);
   if (m->fp8_arena) hipFree(m->fp8_arena);
-  for (auto& b : m->dbl)
-    for (int s = 0; s < 2; ++s)
-      for (Dense* d : {&b.qkv[s], &b.proj[s], &b.mlp1[s], &b.mlp2[s]}) {
-        if (d->wq) hipFree(d->wq);
-        if (d->absmax) hipFree(d->absmax);
-      }
-  for (auto& b : m->sgl)
-    for (Dense* d : {&b.w1, &b.w2}) {
+  for (Dense* d : m->fused)
+    if (d->q_own) {
       if (d->wq) hipFree(d->wq);
       if (d->absmax) hipFree(d->absmax);
     }
@@ -767,76 +889,52 @@ extern "C" int fmi_flux_set_tensor(fmi_flux* m, const char* name, const void* da
                                      std::to_string(d.rows) + (d.cols ? "," + std::to_string(d.cols) : "") + ")");
   }
   if (dtype != FMI_F32 && dtype != FMI_F16 && dtype != FMI_BF16) return fail(FMI_ERR_INVALID, "flux_set_tensor: dtype must be F32/F16/BF16");
+  FMI_TRY(use_device(m));
+  void* dst = d.ptr;
+  if (d.d && !d.bias) {  // a weight part of a (fused) matrix: its arena is allocated on first need
+    FMI_TRY(ensure_arena(m, d.d->ar));
+    dst = d.d->w + (size_t)d.d->parts[d.part].r0 * d.d->K;
+  }
   const size_t esz = dtype == FMI_F32 ? 4 : 2;
   if (dtype == FMI_BF16) {
-    FMI_HIP_TRY(hipMemcpy(d.ptr, data, numel * 2, hipMemcpyDefault));
+    FMI_HIP_TRY(hipMemcpy(dst, data, numel * 2, hipMemcpyDefault));
   } else {
     void* tmp = nullptr;
     FMI_HIP_TRY(hipMalloc(&tmp, numel * esz));
     hipError_t e = hipMemcpy(tmp, data, numel * esz, hipMemcpyDefault);
-    int rc = e == hipSuccess ? launch_cast_to_bf16(tmp, dtype, (bf16_t*)d.ptr, numel, nullptr) : fail(FMI_ERR_HIP, hipGetErrorString(e));
+    int rc = e == hipSuccess ? launch_cast_to_bf16(tmp, dtype, (bf16_t*)dst, numel, nullptr) : fail(FMI_ERR_HIP, hipGetErrorString(e));
     hipDeviceSynchronize();
     hipFree(tmp);
     if (rc) return rc;
+  }
+  if (d.d && !d.bias) {
+    d.d->parts[d.part].state = PS_DENSE, d.d->parts[d.part].blocksize = 0;
+    m->dense_ready.erase(d.d);
+    m->finalized = false;
   }
   m->missing.erase(name);
   return FMI_OK;
 }
 
 namespace {
-Dense* find_dense(fmi_flux* m, const std::string& prefix, int* row0) {
-  // only the MFMA-GEMM linears of the blocks take the fused 4-bit path
-  *row0 = 0;
-  const int D = m->D;
-  auto parse = [&](const char* head, int* idx, std::string* rest) {
-    const size_t hl = strlen(head);
-    if (prefix.compare(0, hl, head) != 0) return false;
-    size_t dot = prefix.find('.', hl);
-    if (dot == std::string::npos) return false;
-    *idx = atoi(prefix.substr(hl, dot - hl).c_str());
-    *rest = prefix.substr(dot + 1);
-    return true;
-  };
-  int idx;
-  std::string rest;
-  if (parse("transformer_blocks.", &idx, &rest) && idx >= 0 && idx < (int)m->dbl.size()) {
-    auto& b = m->dbl[idx];
-    const char* qn[2][3] = {{"attn.to_q", "attn.to_k", "attn.to_v"}, {"attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj"}};
-    for (int s = 0; s < 2; ++s) {
-      for (int j = 0; j < 3; ++j)
-        if (rest == qn[s][j]) {
-          *row0 = j * D;
-          return &b.qkv[s];
-        }
-    }
-    if (rest == "attn.to_out.0") return &b.proj[0];
-    if (rest == "attn.to_add_out") return &b.proj[1];
-    if (rest == "ff.net.0.proj") return &b.mlp1[0];
-    if (rest == "ff_context.net.0.proj") return &b.mlp1[1];
-    if (rest == "ff.net.2") return &b.mlp2[0];
-    if (rest == "ff_context.net.2") return &b.mlp2[1];
-  }
-  if (parse("single_transformer_blocks.", &idx, &rest) && idx >= 0 && idx < (int)m->sgl.size()) {
-    auto& b = m->sgl[idx];
-    if (rest == "attn.to_q") return &b.w1;
-    if (rest == "attn.to_k") {
-      *row0 = D;
-      return &b.w1;
-    }
-    if (rest == "attn.to_v") {
-      *row0 = 2 * D;
-      return &b.w1;
-    }
-    if (rest == "proj_mlp") {
-      *row0 = 3 * D;
-      return &b.w1;
-    }
-    if (rest == "proj_out") return &b.w2;
-  }
-  return nullptr;
+// a quantised Linear that is not a fused GEMM matrix (embedders, final projection): expanded once into the BASE arena
+template <typename F>
+int expand_small(fmi_flux* m, const Dest& dst, const void* q, size_t qbytes, const float* sc, size_t scbytes, F&& run) {
+  void *dq = nullptr, *ds = nullptr;
+  FMI_HIP_TRY(hipMalloc(&dq, qbytes));
+  FMI_HIP_TRY(hipMalloc(&ds, scbytes));
+  hipError_t e = hipMemcpy(dq, q, qbytes, hipMemcpyDefault);
+  if (e == hipSuccess) e = hipMemcpy(ds, sc, scbytes, hipMemcpyDefault);
+  int rc = e == hipSuccess ? run(dq, (const float*)ds, dst.d->w + (size_t)dst.d->parts[dst.part].r0 * dst.d->K) : fail(FMI_ERR_HIP, hipGetErrorString(e));
+  hipDeviceSynchronize();
+  hipFree(dq);
+  hipFree(ds);
+  return rc;
 }
 }  // namespace
 
+// bitsandbytes 4-bit Linear (BnbLinear::Nf4Fp4, bitsandbytes/mod.rs:137-239): packed codes (out*in/2 bytes, high nibble
+// first) + f32 absmax per `blocksize` weights.  Block linears and modulation linears keep this form (Q4 arena).
 extern "C" int fmi_flux_set_linear_bnb4(fmi_flux* m, const char* prefix, const uint8_t* packed, const float* absmax, int blocksize,
                                         int quant_type, int out_features, int in_features) {
   if (!m || !prefix || !packed || !absmax) return fail(FMI_ERR_INVALID, "set_linear_bnb4: null argument");
@@ -844,94 +942,74 @@ extern "C" int fmi_flux_set_linear_bnb4(fmi_flux* m, const char* prefix, const u
   if (quant_type != 1 && quant_type != 2) return fail(FMI_ERR_INVALID, "set_linear_bnb4: quant_type must be 1 (fp4) or 2 (nf4)");
   if (blocksize % 64 || blocksize <= 0 || in_features % blocksize)
     return fail(FMI_ERR_UNSUPPORTED, "set_linear_bnb4: blocksize must be a multiple of 64 dividing in_features");
-  int row0 = 0;
-  Dense* d = find_dense(m, prefix, &row0);
+  FMI_TRY(use_device(m));
   const std::string wname = std::string(prefix) + ".weight";
-  if (!d) {
-    // not a block GEMM linear (embedders, modulation): dequantise once into the dense arena
-    auto it = m->names.find(wname);
-    if (it == m->names.end()) return fail(FMI_ERR_INVALID, std::string("set_linear_bnb4: unknown linear '") + prefix + "'");
-    const Dest& dst = it->second;
-    if (dst.rows != out_features || dst.cols != in_features) return fail(FMI_ERR_INVALID, "set_linear_bnb4: shape mismatch for " + wname);
-    const int64_t n = (int64_t)out_features * in_features;
-    uint8_t* dq = nullptr;
-    float* da = nullptr;
-    FMI_HIP_TRY(hipMalloc((void**)&dq, n / 2));
-    FMI_HIP_TRY(hipMalloc((void**)&da, n / blocksize * 4));
-    FMI_HIP_TRY(hipMemcpy(dq, packed, n / 2, hipMemcpyDefault));
-    FMI_HIP_TRY(hipMemcpy(da, absmax, n / blocksize * 4, hipMemcpyDefault));
-    if (quant_type == 2)
-      dequantize_blockwise_bf16_nf4(nullptr, dq, da, dst.ptr, blocksize, (int)n, nullptr);
-    else
-      dequantize_blockwise_bf16_fp4(nullptr, dq, da, dst.ptr, blocksize, (int)n, nullptr);
-    hipDeviceSynchronize();
-    hipFree(dq);
-    hipFree(da);
+  auto it = m->names.find(wname);
+  if (it == m->names.end() || !it->second.d) return fail(FMI_ERR_INVALID, std::string("set_linear_bnb4: unknown linear '") + prefix + "'");
+  const Dest& dst = it->second;
+  Dense* d = dst.d;
+  if (dst.rows != out_features || dst.cols != in_features) return fail(FMI_ERR_INVALID, "set_linear_bnb4: shape mismatch for " + wname);
+  const size_t n = (size_t)out_features * in_features;
+  if (d->ar == AR_BASE) {
+    if (n >= (1ull << 31)) return fail(FMI_ERR_UNSUPPORTED, "set_linear_bnb4: linear too large");
+    FMI_TRY(expand_small(m, dst, packed, n / 2, absmax, n / blocksize * 4, [&](void* dq, const float* da, bf16_t* out) {
+      if (quant_type == 2) dequantize_blockwise_bf16_nf4(nullptr, (const uint8_t*)dq, da, out, blocksize, (int)n, nullptr);
+      else dequantize_blockwise_bf16_fp4(nullptr, (const uint8_t*)dq, da, out, blocksize, (int)n, nullptr);
+      return (int)FMI_OK;
+    }));
     m->missing.erase(wname);
     return FMI_OK;
   }
-  if (in_features != d->K || row0 + out_features > d->N) return fail(FMI_ERR_INVALID, "set_linear_bnb4: shape mismatch for " + wname);
-  if (d->q_type == 3) return fail(FMI_ERR_UNSUPPORTED, "set_linear_bnb4: this fused projection already holds int8 parts");
-  if (d->q_type && (d->q_type != quant_type || d->q_blocksize != blocksize))
-    return fail(FMI_ERR_UNSUPPORTED, "set_linear_bnb4: all parts of a fused projection must share quant type and blocksize");
-  if (!d->wq) {
-    FMI_HIP_TRY(hipMalloc((void**)&d->wq, (size_t)d->N * d->K / 2));
-    FMI_HIP_TRY(hipMalloc((void**)&d->absmax, (size_t)d->N * d->K / blocksize * 4));
-    FMI_HIP_TRY(hipMemset(d->wq, 0x77, (size_t)d->N * d->K / 2));  // nf4 code 7 = 0.0
-    FMI_HIP_TRY(hipMemset(d->absmax, 0, (size_t)d->N * d->K / blocksize * 4));
-  }
-  d->q_type = quant_type;
-  d->q_blocksize = blocksize;
-  m->dense_ready.erase(d->w);
-  const size_t n = (size_t)out_features * in_features;
-  FMI_HIP_TRY(hipMemcpy(d->wq + (size_t)row0 * d->K / 2, packed, n / 2, hipMemcpyDefault));
-  FMI_HIP_TRY(hipMemcpy(d->absmax + (size_t)row0 * d->K / blocksize, absmax, n / blocksize * 4, hipMemcpyDefault));
+  if (d->q_own) return fail(FMI_ERR_UNSUPPORTED, "set_linear_bnb4: this fused projection already holds int8 parts");
+  FMI_TRY(ensure_arena(m, AR_Q4));
+  Dense::Part& pt = d->parts[dst.part];
+  FMI_HIP_TRY(hipMemcpy(d->wq + (size_t)pt.r0 * d->K / 2, packed, n / 2, hipMemcpyDefault));
+  FMI_HIP_TRY(hipMemcpy(d->absmax + (size_t)pt.r0 * d->K / blocksize, absmax, n / blocksize * 4, hipMemcpyDefault));
+  pt.state = (uint8_t)quant_type, pt.blocksize = blocksize;
+  m->dense_ready.erase(d);
+  m->finalized = false;
   m->missing.erase(wname);
   return FMI_OK;
 }
 
 // LLM.int8 linears (BnbLinear::Int8, bitsandbytes/mod.rs:104-134): weight i8 (out,in) + SCB f32 (out).
 // forward = dequantize_8bit (w * SCB[row] / 127, dequant.cu:205-214) then matmul (mod.rs:293-300):
-// block linears keep the int8 weight and are expanded into the bf16 scratch right before their GEMM.
+// fused matrices keep the int8 weight and are expanded right before their GEMM (or once, with the dense cache).
 extern "C" int fmi_flux_set_linear_int8(fmi_flux* m, const char* prefix, const int8_t* weight, const float* scb, int out_features, int in_features) {
   if (!m || !prefix || !weight || !scb) return fail(FMI_ERR_INVALID, "set_linear_int8: null argument");
   if (m->fp8) return fail(FMI_ERR_STATE, "set_linear_int8: the model was quantised to fp8");
-  int row0 = 0;
-  Dense* d = find_dense(m, prefix, &row0);
+  FMI_TRY(use_device(m));
   const std::string wname = std::string(prefix) + ".weight";
+  auto it = m->names.find(wname);
+  if (it == m->names.end() || !it->second.d) return fail(FMI_ERR_INVALID, std::string("set_linear_int8: unknown linear '") + prefix + "'");
+  const Dest& dst = it->second;
+  Dense* d = dst.d;
+  if (dst.rows != out_features || dst.cols != in_features) return fail(FMI_ERR_INVALID, "set_linear_int8: shape mismatch for " + wname);
   const int64_t n = (int64_t)out_features * in_features;
-  if (!d) {  // embedders / modulation: expand once into the dense arena
-    auto it = m->names.find(wname);
-    if (it == m->names.end()) return fail(FMI_ERR_INVALID, std::string("set_linear_int8: unknown linear '") + prefix + "'");
-    const Dest& dst = it->second;
-    if (dst.rows != out_features || dst.cols != in_features) return fail(FMI_ERR_INVALID, "set_linear_int8: shape mismatch for " + wname);
-    int8_t* dq = nullptr;
-    float* ds = nullptr;
-    FMI_HIP_TRY(hipMalloc((void**)&dq, n));
-    FMI_HIP_TRY(hipMalloc((void**)&ds, (size_t)out_features * 4));
-    FMI_HIP_TRY(hipMemcpy(dq, weight, n, hipMemcpyDefault));
-    FMI_HIP_TRY(hipMemcpy(ds, scb, (size_t)out_features * 4, hipMemcpyDefault));
-    int rc = launch_dequant_int8_scb_bf16(dq, ds, (bf16_t*)dst.ptr, in_features, n, nullptr);
-    hipDeviceSynchronize();
-    hipFree(dq);
-    hipFree(ds);
-    if (rc) return rc;
+  if (d->ar == AR_BASE) {
+    FMI_TRY(expand_small(m, dst, weight, (size_t)n, scb, (size_t)out_features * 4, [&](void* dq, const float* ds, bf16_t* out) {
+      return launch_dequant_int8_scb_bf16((const int8_t*)dq, ds, out, in_features, n, nullptr);
+    }));
     m->missing.erase(wname);
     return FMI_OK;
   }
-  if (in_features != d->K || row0 + out_features > d->N) return fail(FMI_ERR_INVALID, "set_linear_int8: shape mismatch for " + wname);
-  if (d->q_type && d->q_type != 3) return fail(FMI_ERR_UNSUPPORTED, "set_linear_int8: all parts of a fused projection must share the quantisation type");
-  if (!d->wq) {
-    FMI_HIP_TRY(hipMalloc((void**)&d->wq, (size_t)d->N * d->K));
-    FMI_HIP_TRY(hipMalloc((void**)&d->absmax, (size_t)d->N * 4));
-    FMI_HIP_TRY(hipMemset(d->wq, 0, (size_t)d->N * d->K));
-    FMI_HIP_TRY(hipMemset(d->absmax, 0, (size_t)d->N * 4));
+  for (auto& pt : d->parts)
+    if (pt.state == PS_FP4 || pt.state == PS_NF4) return fail(FMI_ERR_UNSUPPORTED, "set_linear_int8: this fused projection already holds 4-bit parts");
+  if (!d->q_own) {  // int8 matrices own their storage (1 B per weight: they do not fit the 4-bit arena's slots)
+    uint8_t* wq = nullptr;
+    float* sc = nullptr;
+    FMI_HIP_TRY(hipMalloc((void**)&wq, (size_t)d->N * d->K));
+    FMI_HIP_TRY(hipMalloc((void**)&sc, (size_t)d->N * 4));
+    FMI_HIP_TRY(hipMemset(wq, 0, (size_t)d->N * d->K));
+    FMI_HIP_TRY(hipMemset(sc, 0, (size_t)d->N * 4));
+    d->wq = wq, d->absmax = sc, d->q_own = true;
   }
-  d->q_type = 3;
-  d->q_blocksize = 0;
-  m->dense_ready.erase(d->w);
-  FMI_HIP_TRY(hipMemcpy(d->wq + (size_t)row0 * d->K, weight, n, hipMemcpyDefault));
-  FMI_HIP_TRY(hipMemcpy(d->absmax + row0, scb, (size_t)out_features * 4, hipMemcpyDefault));
+  Dense::Part& pt = d->parts[dst.part];
+  FMI_HIP_TRY(hipMemcpy(d->wq + (size_t)pt.r0 * d->K, weight, n, hipMemcpyDefault));
+  FMI_HIP_TRY(hipMemcpy(d->absmax + pt.r0, scb, (size_t)out_features * 4, hipMemcpyDefault));
+  pt.state = PS_INT8, pt.blocksize = 0;
+  m->dense_ready.erase(d);
+  m->finalized = false;
   m->missing.erase(wname);
   return FMI_OK;
 }
@@ -943,7 +1021,77 @@ extern "C" const char* fmi_flux_missing_name(const fmi_flux* m, int i) {
   mm->missing_list.assign(m->missing.begin(), m->missing.end());
   return mm->missing_list[i].c_str();
 }
-extern "C" size_t fmi_flux_size_in_bytes(const fmi_flux* m) { return m ? m->arena_bytes + m->ws.bytes + m->fp8_bytes : 0; }
+extern "C" size_t fmi_flux_size_in_bytes(const fmi_flux* m) {
+  if (!m) return 0;
+  size_t b = m->ws.bytes + m->fp8_bytes + 2 * m->wscratch_elems * 2 + m->mod_steps_rows * ((size_t)m->n_mod * 4 + (size_t)m->D * 6);
+  for (int a = 0; a < AR_COUNT; ++a)
+    if (m->arena[a].base) b += m->arena[a].bytes;
+  for (const Dense* d : m->fused)
+    if (d->q_own) b += (size_t)d->N * d->K + (size_t)d->N * 4;
+  return b;
+}
+
+// ---- weight state as a handful of flat device buffers: the unit of the multi-GPU weight broadcast.
+// Rank 0 loads a checkpoint as usual; fmi_flux_state_export describes which arenas exist and how every fused matrix is
+// stored; the other ranks fmi_flux_state_adopt that description (allocating the same arenas, marking every tensor as
+// present) and then receive the bytes of buffers 0 .. fmi_flux_state_buffer_count()-1 — four RCCL broadcasts instead
+// of one per tensor.  LLM.int8 matrices own separate allocations and are not covered (FMI_ERR_UNSUPPORTED: load per rank).
+extern "C" int fmi_flux_state_buffer_count(void) { return AR_COUNT; }
+extern "C" int fmi_flux_state_export(fmi_flux* m, uint8_t* blob_host, size_t cap, size_t* len) {
+  if (!m || !len) return fail(FMI_ERR_INVALID, "state_export: null argument");
+  FMI_TRY(use_device(m));
+  FMI_TRY(check_ready(m));
+  if (m->fp8) return fail(FMI_ERR_UNSUPPORTED, "state_export: export before fmi_flux_quantize_fp8 (every rank quantises its own copy)");
+  const size_t need = 8 + AR_COUNT + 5 * m->fused.size();
+  *len = need;
+  if (!blob_host) return FMI_OK;
+  if (cap < need) return fail(FMI_ERR_INVALID, "state_export: buffer too small");
+  uint8_t* o = blob_host;
+  memcpy(o, "FMIS", 4);
+  const uint32_t nf = (uint32_t)m->fused.size();
+  memcpy(o + 4, &nf, 4);
+  o += 8;
+  for (int a = 0; a < AR_COUNT; ++a) *o++ = m->arena[a].base ? 1 : 0;
+  for (const Dense* d : m->fused) {
+    if (d->q_own) return fail(FMI_ERR_UNSUPPORTED, "state_export: LLM.int8 matrices are not part of the flat weight state");
+    *o++ = (uint8_t)d->q_type;
+    const uint32_t bs = (uint32_t)d->q_blocksize;
+    memcpy(o, &bs, 4);
+    o += 4;
+  }
+  return FMI_OK;
+}
+extern "C" int fmi_flux_state_adopt(fmi_flux* m, const uint8_t* blob_host, size_t len) {
+  if (!m || !blob_host) return fail(FMI_ERR_INVALID, "state_adopt: null argument");
+  FMI_TRY(use_device(m));
+  uint32_t nf = 0;
+  if (len < 8 || memcmp(blob_host, "FMIS", 4)) return fail(FMI_ERR_INVALID, "state_adopt: bad blob");
+  memcpy(&nf, blob_host + 4, 4);
+  if (nf != m->fused.size() || len != 8 + AR_COUNT + 5 * (size_t)nf) return fail(FMI_ERR_INVALID, "state_adopt: the blob describes a different model configuration");
+  const uint8_t* o = blob_host + 8;
+  for (int a = 0; a < AR_COUNT; ++a)
+    if (*o++) FMI_TRY(ensure_arena(m, a));
+  for (Dense* d : m->fused) {
+    const int qt = *o++;
+    uint32_t bs = 0;
+    memcpy(&bs, o, 4);
+    o += 4;
+    if (qt == 3 || d->q_own) return fail(FMI_ERR_UNSUPPORTED, "state_adopt: LLM.int8 matrices are not part of the flat weight state");
+    d->q_type = qt, d->q_blocksize = (int)bs;
+    for (auto& pt : d->parts) pt.state = qt ? (uint8_t)qt : (uint8_t)PS_DENSE, pt.blocksize = (int)bs;
+    if (qt ? !m->arena[AR_Q4].base : !m->arena[d->ar].base) return fail(FMI_ERR_INVALID, "state_adopt: blob is inconsistent (matrix stored in an arena that is not present)");
+  }
+  m->missing.clear();
+  m->dense_ready.clear();
+  m->finalized = true;
+  return FMI_OK;
+}
+extern "C" int fmi_flux_state_buffer(fmi_flux* m, int index, void** ptr, size_t* bytes) {
+  if (!m || !ptr || !bytes || index < 0 || index >= AR_COUNT) return fail(FMI_ERR_INVALID, "state_buffer: bad argument");
+  *ptr = m->arena[index].base;
+  *bytes = m->arena[index].base ? m->arena[index].bytes : 0;
+  return FMI_OK;
+}
 
 extern "C" int fmi_flux_forward(fmi_flux* m, const fmi_flux_inputs* in, float* pred_out, void* stream) {
   FMI_TRY(check_inputs(m, in));
@@ -995,12 +1143,12 @@ extern "C" int fmi_flux_denoise(fmi_flux* m, const fmi_flux_inputs* in, float* i
     {
       PhaseTimer pt(m, s, PH_MOD);
       constexpr int GEMV_MAXROWS = 4;  // rows * D * 4 B of x staged in LDS per block (<= 64 KiB)
-      if (m->mod_gemm && R > GEMV_MAXROWS && m->D % 64 == 0 && nmod % 8 == 0 && R * nmod < (1ull << 31)) {
+      if (m->mod_all.q_type || (m->mod_gemm && R > GEMV_MAXROWS && m->D % 64 == 0 && nmod % 8 == 0 && R * nmod < (1ull << 31))) {
         // all rows in ONE pass over the matrix on the MFMA GEMM (silu(vec) rounded to bf16 like every other
         // GEMM input): the matrix is read once per image instead of once per 4 steps
         FMI_TRY(launch_silu_to_bf16(m->vec_steps, m->vec_steps_bf, (int64_t)R * m->D, s));
         GemmProblem p = make_problem(m->mod_all, m->vec_steps_bf, m->D, (int)R, m->mod_steps, (int)nmod, EPI_STORE_F32);
-        FMI_TRY(launch_gemm(&p, 1, s));
+        FMI_TRY(gemm1(m, p, m->mod_all, s));
       } else {
         for (size_t r0 = 0; r0 < R; r0 += GEMV_MAXROWS)
           FMI_TRY(launch_gemv(m->vec_steps + r0 * m->D, m->mod_all.w, m->mod_all.b, m->mod_steps + r0 * nmod, (int)std::min<size_t>(GEMV_MAXROWS, R - r0),
@@ -1053,6 +1201,7 @@ extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int enable) {
 // fp8 mode: quantise every block Linear once (bf16 arena -> e4m3 + per-output-channel scale); see the header.
 extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
+  FMI_TRY(use_device(m));
   FMI_TRY(check_ready(m));
   if (m->fp8) return FMI_OK;
   std::vector<Dense*> lin;
@@ -1063,7 +1212,7 @@ extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) {
     for (Dense* d : {&b.w1, &b.w2}) lin.push_back(d);
   size_t bytes = 0;
   for (Dense* d : lin) {
-    if (d->q_type) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: model holds bitsandbytes-quantised linears; load a bf16 checkpoint");
+    if (d->q_type || !d->w) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: model holds bitsandbytes-quantised linears; load a bf16 checkpoint");
     if (d->K % 128 || d->N <= 128 || d->K > 16384) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: needs in_features % 128 == 0 (<= 16384) and out_features > 128");
     bytes += align_up((size_t)d->N * d->K, 256) + align_up((size_t)d->N * 4, 256);
   }
@@ -1128,10 +1277,11 @@ extern "C" int fmi_flux_set_fp8_attention(fmi_flux* m, int enable) {
   m->fp8_attn = enable != 0;
   return FMI_OK;
 }
-// 4-bit dispatch threshold (rows): below it the fused dequant-GEMM runs, at or above it dequant-once + dense
-extern "C" int fmi_flux_set_bnb4_fused_max_rows(fmi_flux* m, int rows) {
-  if (!m) return fail(FMI_ERR_INVALID, "null handle");
-  m->q_fused_max_rows = rows;
+// 4-bit weights, process-wide: number of rows from which the one-wave-per-SIMD fused dequant-GEMM (gemm_w4q.h) runs
+// instead of the two-workgroups-per-CU one (default 256)
+extern "C" int fmi_set_bnb4_onewave_min_rows(int rows) {
+  if (rows < 1) return fail(FMI_ERR_INVALID, "set_bnb4_onewave_min_rows: rows must be positive");
+  set_gemm_w4q_min_rows(rows);
   return FMI_OK;
 }
 // test hook: 0 = rescale every tile, else deferred-rescale threshold (default)

@@ -34,30 +34,12 @@
 
 namespace fmi {
 
-// cache-policy bits of the A / W LDS-DMA streams (0 = default, 2 = nt); tuning knobs
-#ifndef FMI_AUX_A
-#define FMI_AUX_A 0
-#endif
-#ifndef FMI_AUX_W
-#define FMI_AUX_W 0
-#endif
-#ifndef FMI_PP_EARLY
-#define FMI_PP_EARLY 0  // ping-pong kernel: MFMA pairs issued after the slot-closing barrier (measured: 0 is best, 2-8 cost 4-6 %)
-#endif
-#ifndef FMI_GH
-#define FMI_GH 8  // tile-rows per band of the tile order (see the kernel)
-#endif
+constexpr int TILE_BAND = 8;  // tile-rows per band of the tile order (see the kernels; 8 measured best)
 constexpr int BM = 256, BK = 64;
 constexpr int GEMM_THREADS = 512;
 constexpr int A_TILE_BYTES = BM * BK * 2;  // 32 KiB
 constexpr int MAX_PROBLEMS = 8;
 
-#ifdef FMI_W4_TRACE
-__device__ long long g_w4_trace[64 * 8];
-#define W4_TR(k) do { if (blockIdx.x < 64 && threadIdx.x == 0) g_w4_trace[blockIdx.x * 8 + (k)] = clock64(); } while (0)
-#else
-#define W4_TR(k) do {} while (0)
-#endif
 struct GemmBatch {
   GemmProblem p[MAX_PROBLEMS];
   int tile_start[MAX_PROBLEMS + 1];
@@ -326,9 +308,6 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, f32x16 
     }
   };
   const bool f32_out = (epi == EPI_RESID_GATE_F32 || epi == EPI_STORE_F32);
-#ifdef FMI_ABLATE_NO_EPI
-  if (alpha != 12345.f) return;  // ablation: skip the stores but keep the accumulators live
-#endif
   // Staged path: the C tile goes through LDS (free after the K loop) and leaves as whole 128-B
   // (bf16) / 256-B (f32) row segments with 16-B stores.  Direct per-lane stores touch 32 partial
   // cache lines per instruction and cost ~30 us per tile with nothing else resident on the CU.
@@ -336,7 +315,6 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, f32x16 
                       (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias) & 7) == 0);
   if (staged) {
     __syncthreads();  // every wave is done with the operand tiles
-    if constexpr (NJ == 4) W4_TR(5);
     char* cw = smem + wave * (8192 * NJ);  // wave-private staging region
     const int ncol0 = n0 + wn * 32 * NJ;
     if (!f32_out) {
@@ -358,7 +336,6 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, f32x16 
             if constexpr (NJ == 4) __builtin_amdgcn_sched_barrier(0);
           }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if constexpr (NJ == 4) W4_TR(6);
       constexpr int LPR = RB / 16, RPI = 64 / LPR;  // lanes per row, rows per wave-instruction
       bf16_t* ob = reinterpret_cast<bf16_t*>(P.out);
 #pragma unroll
@@ -531,7 +508,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   const int tiles_n = (P.N + BN - 1) / BN;
   // Logical ids walk bands of GH tile-rows column by column, so the ~32 tiles an XCD runs at any
   // time form a compact GH x 4 patch: 12 distinct A/W panels per K step instead of 20 (L2 hits).
-  constexpr int GH = FMI_GH;
+  constexpr int GH = TILE_BAND;
   const int band = t / (GH * tiles_n);
   const int band_h = min(GH, tiles_m - band * GH);
   const int tin = t - band * GH * tiles_n;
@@ -642,9 +619,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   // One 1-KiB piece (8 rows) of tile `kt` into buffer `buf`: pieces 0..3 are A, the rest W.
   auto dma_piece = [&](int kt, int d, int buf) {
     if (d < 4)
-      __builtin_amdgcn_global_load_lds((glb_void*)(a_src[d] + kt * BK), (lds_void*)(bufA(buf) + (wave * 4 + d) * 1024), 16, 0, FMI_AUX_A);
+      __builtin_amdgcn_global_load_lds((glb_void*)(a_src[d] + kt * BK), (lds_void*)(bufA(buf) + (wave * 4 + d) * 1024), 16, 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((glb_void*)(w_src[d - 4] + kt * BK), (lds_void*)(bufW(buf) + (wave * CPWN + d - 4) * 1024), 16, 0, FMI_AUX_W);
+      __builtin_amdgcn_global_load_lds((glb_void*)(w_src[d - 4] + kt * BK), (lds_void*)(bufW(buf) + (wave * CPWN + d - 4) * 1024), 16, 0, 0);
   };
   // Dense GEMM: the DMA pieces of tile kt+1 are issued one at a time BETWEEN the MFMAs of the
   // first two k-steps of tile kt (an LDS-DMA costs ~60 cycles among MFMAs but 100-185 in a burst,
@@ -655,15 +632,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
     constexpr bool MORE = decltype(more_tag)::value;
     const int cur = kt & 1;
     dma_barrier();  // tile kt landed for every wave; everyone finished reading buf[cur^1]
-#ifndef FMI_ABLATE_NO_LOAD
     if (MORE && !INTERLEAVE) {
       stage_a(kt + 1, bufA(cur ^ 1));
       stage_w(kt + 1, bufW(cur ^ 1));
     }
-#endif
     const char* la = bufA(cur) + a_row_off;
     const char* lw = bufW(cur) + w_row_off;
-#ifndef FMI_ABLATE_NO_MFMA
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       bf16x8_t xf[4], wf[NJ];
@@ -675,24 +649,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-#ifndef FMI_ABLATE_NO_LOAD
-#ifdef FMI_ABLATE_HALF_LOAD
-        if (MORE && INTERLEAVE && s * 4 + i < 4) dma_piece(kt + 1, s * 4 + i, cur ^ 1);  // A pieces only
-#else
         if (MORE && INTERLEAVE && s * 4 + i < 4 + CPWN) dma_piece(kt + 1, s * 4 + i, cur ^ 1);
-#endif
-#endif
       }
     }
-#else
-    acc[0][0][0] += *reinterpret_cast<const float*>(la + koff[0]);  // keep the tile "used"
-#ifndef FMI_ABLATE_NO_LOAD
-    if (MORE && INTERLEAVE) {
-      stage_a(kt + 1, bufA(cur ^ 1));
-      stage_w(kt + 1, bufW(cur ^ 1));
-    }
-#endif
-#endif
   };
   for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
   ktile(nk - 1, std::false_type{});
@@ -760,7 +719,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
   const int t_in = lid - batch.tile_start[pi];
   const int tiles_m = (P.M + BM - 1) / BM;
   const int tiles_n = (P.N + BN - 1) / BN;
-  constexpr int GH = FMI_GH;  // same band/patch order as gemm_bf16_kernel
+  constexpr int GH = TILE_BAND;  // same band/patch order as gemm_bf16_kernel
   const int band = t_in / (GH * tiles_n);
   const int band_h = min(GH, tiles_m - band * GH);
   const int tin = t_in - band * GH * tiles_n;
@@ -799,11 +758,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
   const char* const w_base = reinterpret_cast<const char*>(P.W);
   auto dma_a = [&](int kt, int i) {
     const char* base = a_base + (int64_t)kt * (BK * 2);  // uniform
-    __builtin_amdgcn_global_load_lds((glb_void*)(base + a_off[i]), (lds_void*)(smem + A_RING + (kt & 1) * TILE + (a_chunk0 + i) * 1024), 16, 0, FMI_AUX_A);
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + a_off[i]), (lds_void*)(smem + A_RING + (kt & 1) * TILE + (a_chunk0 + i) * 1024), 16, 0, 0);
   };
   auto dma_w = [&](int kt, int slot, int i) {
     const char* base = w_base + (int64_t)kt * (BK * 2);
-    __builtin_amdgcn_global_load_lds((glb_void*)(base + w_off[i]), (lds_void*)(smem + W_RING + slot * TILE + (w_chunk0 + i) * 1024), 16, 0, FMI_AUX_W);
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + w_off[i]), (lds_void*)(smem + W_RING + slot * TILE + (w_chunk0 + i) * 1024), 16, 0, 0);
   };
   auto slot_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -841,7 +800,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
     const bool a_ok = MAIN || (t + 1 + g < nk);
     const bool w_ok = MAIN || (t + 2 < nk);
     auto issue_dma = [&]() {
-#ifndef FMI_PP_NO_DMA
       if (a_ok) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_a(t + 1 + g, i);
@@ -850,12 +808,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_w(t + 2, wi, i);
       }
-#endif
     };
-#ifdef FMI_PP_DMA_FIRST
-    issue_dma();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     {
       const char* la = smem + A_RING + (t & 1) * TILE + a_row_off;
       const char* lw = smem + W_RING + wr * TILE + w_row_off;
@@ -881,15 +834,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
         }
       }
     }
-#ifndef FMI_PP_DMA_FIRST
     __builtin_amdgcn_sched_barrier(0);
     issue_dma();
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if (MAIN) {
-#ifndef FMI_PP_NO_WAIT
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#endif
     } else {  // tail: wait for everything but what was issued just now
       if (a_ok && w_ok)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -900,9 +849,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
     }
     slot_barrier();
     // ---- COMPUTE(t): the matrix pipe only
-#ifdef FMI_PP_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
     if constexpr (FP8) {
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -913,31 +859,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
             acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[s][j], xq[s][i], acc[i][j], 0, 0, 0, 0, 0, 0);  // e4m3 x e4m3, unscaled
     } else {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        // experiment knob: signal the slot-closing barrier FMI_PP_EARLY MFMA pairs before the end
-        if (s * 4 + i == 16 - FMI_PP_EARLY) slot_barrier();
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-#if defined(FMI_PP_HALF_MFMA)
-          if (s < 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][j], xf[s][i], acc[i][j], 0, 0, 0);
-          else acc[i][j][0] += __builtin_bit_cast(f32x4, wf[s][j])[0] + __builtin_bit_cast(f32x4, xf[s][i])[1];
-#elif !defined(FMI_PP_NO_MFMA)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][j], xf[s][i], acc[i][j], 0, 0, 0);
-#else
-          acc[i][j][0] += __builtin_bit_cast(f32x4, wf[s][j])[0] + __builtin_bit_cast(f32x4, xf[s][i])[1];
-#endif
-        }
-      }
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][j], xf[s][i], acc[i][j], 0, 0, 0);
     }
-#ifdef FMI_PP_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef FMI_PP_SLEEP
-    __builtin_amdgcn_s_sleep(FMI_PP_SLEEP);  // ablation: stand-in for the MFMA time (64 clocks per unit)
-#endif
-    if (FP8 || FMI_PP_EARLY == 0) slot_barrier();
+    slot_barrier();
     wr = wr == 2 ? 0 : wr + 1;
     wi = wi == 2 ? 0 : wi + 1;
   };
@@ -1007,7 +935,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
   const int t_in = lid - batch.tile_start[pi];
   const int tiles_m = (P.M + BM - 1) / BM;
   const int tiles_n = (P.N + BN - 1) / BN;
-  constexpr int GH = FMI_GH;
+  constexpr int GH = TILE_BAND;
   const int band = t_in / (GH * tiles_n);
   const int band_h = min(GH, tiles_m - band * GH);
   const int tin = t_in - band * GH * tiles_n;
@@ -1043,11 +971,11 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
   const char* const w_base = reinterpret_cast<const char*>(P.W);
   auto dma_a = [&](int kt, int i) {
     const char* base = a_base + (int64_t)kt * (BK * 2);
-    __builtin_amdgcn_global_load_lds((glb_void*)(base + a_off[i]), (lds_void*)(smem + A_RING + (kt & 1) * TILE + (wave * 8 + i) * 1024), 16, 0, FMI_AUX_A);
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + a_off[i]), (lds_void*)(smem + A_RING + (kt & 1) * TILE + (wave * 8 + i) * 1024), 16, 0, 0);
   };
   auto dma_w = [&](int kt, int slot, int i) {
     const char* base = w_base + (int64_t)kt * (BK * 2);
-    __builtin_amdgcn_global_load_lds((glb_void*)(base + w_off[i]), (lds_void*)(smem + W_RING + slot * TILE + (wave * 8 + i) * 1024), 16, 0, FMI_AUX_W);
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + w_off[i]), (lds_void*)(smem + W_RING + slot * TILE + (wave * 8 + i) * 1024), 16, 0, 0);
   };
   auto sync_all = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -1056,7 +984,6 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
   };
 
   // ---- prologue, in the order the steady-state vmcnt arithmetic expects: A(0), W(0), W(1), A(1)
-  W4_TR(0);
   const int klast = nk - 1;
 #pragma unroll
   for (int i = 0; i < 8; ++i) dma_a(0, i);
@@ -1099,14 +1026,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
   asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                                   \
                : "+v"(xf[s][0]), "+v"(xf[s][1]), "+v"(xf[s][2]), "+v"(xf[s][3]), "+v"(wf[s][0]), "+v"(wf[s][1]), "+v"(wf[s][2]), "+v"(wf[s][3]))
   auto mfma = [&](int s, int i, int j) {
-#ifndef FMI_W4_NO_MFMA
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[s][j]), __builtin_bit_cast(bf16x8_t, xf[s][i]), acc[i][j], 0, 0, 0);
-#else
-    acc[i][j][0] += __builtin_bit_cast(f32x4, wf[s][j])[0] + __builtin_bit_cast(f32x4, xf[s][i])[1];
-#endif
   };
 
-  W4_TR(1);
   // steps 0 and 1 of tile 0
   rebase(0, 0);
 #pragma unroll
@@ -1133,9 +1055,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
       for (int q = 0; q < 16; ++q) {
         mfma(s, q >> 2, q & 3);
         if ((q & 1) == 0) read_frag(s + 2, q >> 1);
-#ifndef FMI_W4_NO_DMA
         if ((q & 3) == 1) dma_w(kt2, wnn, (s * 16 + q) >> 2);
-#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -1145,35 +1065,25 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
     for (int q = 0; q < 16; ++q) {
       if (q == 4) {
         FMI_W4_WAIT(0, 3);  // the tile's last reads are in: its LDS slots are free
-#ifndef FMI_W4_NO_DMA
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // oldest first: ..., A(t+1) x8, W(t+2) x8
-#endif
-#ifndef FMI_W4_NO_BARRIER
         sync_all();
-#endif
         rebase((t + 1) & 1, wnext);
       }
       mfma(2, q >> 2, q & 3);
       if (q >= 8) read_frag(0, q - 8);
-#ifndef FMI_W4_NO_DMA
       if (q >= 9 && (q & 1)) dma_a(kt2, (q - 9) >> 1);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       mfma(3, q >> 2, q & 3);
       if ((q & 1) == 0) read_frag(1, q >> 1);
-#ifndef FMI_W4_NO_DMA
       if ((q & 3) == 3) dma_a(kt2, 4 + (q >> 2));
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     wslot = wnext;
   }
-  W4_TR(2);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the trailing dummy DMA / reads must not land in the epilogue's staging
-  W4_TR(3);
 #undef FMI_W4_RD
 #undef FMI_W4_WAIT
   // The wave's 128 x 128 leaves as two 128 x 64 halves through the 8-wave epilogue: half h plays wave (wm, 2*wn + h)
@@ -1199,8 +1109,11 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
       asm volatile("" : "+v"(lane_e));  // keep the second round's address math out of the first
     }
   }
-  W4_TR(4);
 }
+
+}  // namespace fmi
+#include "gemm_w4q.h"
+namespace fmi {
 
 static bool g_pingpong = true;
 // Default ON for the launches `w4_pays` selects below (the residual-update GEMMs: proj, mlp2, linear2).  Bit-identical
@@ -1210,6 +1123,8 @@ static bool g_w4 = [] {
   const char* e = getenv("FMI_GEMM_W4");
   return e ? atoi(e) != 0 : true;
 }();
+static int g_w4q_min_rows = 256;
+void set_gemm_w4q_min_rows(int rows) { g_w4q_min_rows = rows; }
 void set_gemm_w4(bool on) { g_w4 = on; }
 void set_gemm_pingpong(bool on) { g_pingpong = on; }
 
@@ -1261,6 +1176,14 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   // mlp2 -10 %, linear2 -7 %), everything else from K = 8192 on (mlp1 + GELU at K = 3072 is a wash).
   // The fused q|k|v relayout epilogue exists for the 8-wave layout only.
   bool w4_pays = !fp8 && !conv && !quant;
+  // 4-bit weights: the one-wave-per-SIMD fused kernel from g_w4q_min_rows rows on (below it the GEMM is bound by the packed
+  // weight stream and the two-workgroups-per-CU kernel with the VGPR expand hides latency better)
+  bool w4q_ok = quant;
+  for (int i = 0; i < nprob; ++i) {
+    const GemmProblem& p = probs[i];
+    const int kb = p.q_blocksize / BK;  // K tiles per absmax block
+    if (p.qk_qh || p.M < g_w4q_min_rows || p.K % p.q_blocksize || (kb & (kb - 1)) || (int64_t)p.N * p.K / 2 >= (1ll << 32)) w4q_ok = false;
+  }
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem& p = probs[i];
     if (p.qk_qh || (p.epi != EPI_RESID_GATE_F32 && p.K < 8192)) w4_pays = false;
@@ -1276,7 +1199,14 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
     FMI_ACT_LAUNCH(gemm_pp_kernel, true, GEMM_THREADS);
   else if (conv)
     FMI_GEMM_LAUNCH(2);
-  else if (quant)
+  else if (quant && bn == 256 && w4q_ok) {
+    // fused dequant-GEMM, one wave per SIMD (gemm_w4q.h); the QKV relayout epilogue exists for the 8-wave layout only
+    const dim3 g4(total), b4(W4_THREADS);
+    if (act == 0) hipLaunchKernelGGL((gemm_w4q_kernel<0>), g4, b4, 0, stream, b);
+    else if (act == 1) hipLaunchKernelGGL((gemm_w4q_kernel<1>), g4, b4, 0, stream, b);
+    else if (act == 2) hipLaunchKernelGGL((gemm_w4q_kernel<2>), g4, b4, 0, stream, b);
+    else hipLaunchKernelGGL((gemm_w4q_kernel<3>), g4, b4, 0, stream, b);
+  } else if (quant)
     FMI_GEMM_LAUNCH(1);
   else if (bn == 256 && g_w4 && w4_pays)
     FMI_ACT_LAUNCH(gemm_w4_kernel, false, W4_THREADS);

@@ -221,17 +221,43 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2])
   k[0] += 0x9E3779B9u;
   k[1] += 0xBB67AE85u;
 }
-extern "C" int fmi_randn(float* out, int64_t n_per_sample, int B, uint64_t seed, uint64_t first_sample, void* stream) {
+// counter = (quad lo, quad hi, sample lo, sample hi), key = (seed lo, seed hi): 4 words per counter
+__device__ __forceinline__ void philox_quad(int64_t qd, uint64_t sample, uint64_t seed, uint32_t (&c)[4]) {
+  c[0] = (uint32_t)qd, c[1] = (uint32_t)((uint64_t)qd >> 32), c[2] = (uint32_t)sample, c[3] = (uint32_t)(sample >> 32);
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) philox_round(c, k);
+}
+// the raw stream fmi_randn draws from (checked bit for bit against the oracle / Random123 known answers)
+extern "C" int fmi_philox_u32(uint32_t* out, int64_t n_per_sample, int B, uint64_t seed, uint64_t first_sample, void* stream) {
+  if (!out || n_per_sample < 0 || B < 0) return fail(FMI_ERR_INVALID, "philox_u32: bad arguments");
   const int64_t quads = (n_per_sample + 3) / 4;
   const int64_t n = quads * B;
+  if (n == 0) return FMI_OK;
   auto body = [=] __device__(int64_t i) {
     const int64_t qd = i % quads;
     const int b = (int)(i / quads);
-    const uint64_t sample = first_sample + (uint64_t)b;
-    uint32_t c[4] = {(uint32_t)qd, (uint32_t)(qd >> 32), (uint32_t)sample, (uint32_t)(sample >> 32)};
-    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    uint32_t c[4];
+    philox_quad(qd, first_sample + (uint64_t)b, seed, c);
+    for (int e = 0; e < 4; ++e) {
+      const int64_t idx = qd * 4 + e;
+      if (idx < n_per_sample) out[(int64_t)b * n_per_sample + idx] = c[e];
+    }
+  };
+  hipLaunchKernelGGL(map_kernel, map_grid(n), dim3(256), 0, (hipStream_t)stream, n, body);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+extern "C" int fmi_randn(float* out, int64_t n_per_sample, int B, uint64_t seed, uint64_t first_sample, void* stream) {
+  if (!out || n_per_sample < 0 || B < 0) return fail(FMI_ERR_INVALID, "randn: bad arguments");
+  const int64_t quads = (n_per_sample + 3) / 4;
+  const int64_t n = quads * B;
+  if (n == 0) return FMI_OK;
+  auto body = [=] __device__(int64_t i) {
+    const int64_t qd = i % quads;
+    const int b = (int)(i / quads);
+    uint32_t c[4];
+    philox_quad(qd, first_sample + (uint64_t)b, seed, c);
     float z[4];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {

@@ -298,6 +298,7 @@ using namespace fmi;
 // =============================================================================================== T5
 struct fmi_t5 {
   fmi_t5_config cfg;
+  int device = current_device();
   Registry r;
   Workspace ws;
   bf16_t *shared = nullptr, *rel = nullptr, *final_ln = nullptr;
@@ -383,6 +384,7 @@ extern "C" void fmi_t5_destroy(fmi_t5* m) {
   delete m;
 }
 extern "C" int fmi_t5_set_tensor(fmi_t5* m, const char* name, const void* data, fmi_dtype dtype, const int64_t* shape, int rank) {
+  if (m) FMI_TRY(use_device_ordinal(m->device));
   if (!m) return fail(FMI_ERR_INVALID, "t5_set_tensor: null model");
   return m->r.set("t5_set_tensor", name, data, dtype, shape, rank);
 }
@@ -395,6 +397,7 @@ extern "C" const char* fmi_t5_missing_name(fmi_t5* m, int i) {
 extern "C" size_t fmi_t5_size_in_bytes(const fmi_t5* m) { return m ? m->r.bytes + m->ws.bytes : 0; }
 
 extern "C" int fmi_t5_forward(fmi_t5* m, const int32_t* input_ids, int B, int T, void* out, fmi_dtype out_dtype, void* stream) {
+  if (m) FMI_TRY(use_device_ordinal(m->device));
   if (!m || !input_ids || !out) return fail(FMI_ERR_INVALID, "t5_forward: null argument");
   if (B <= 0 || T <= 0) return fail(FMI_ERR_INVALID, "t5_forward: empty batch");
   FMI_TRY(m->r.ready("t5_forward"));
@@ -471,6 +474,7 @@ extern "C" int fmi_t5_forward(fmi_t5* m, const int32_t* input_ids, int B, int T,
 // ============================================================================================= CLIP
 struct fmi_clip {
   fmi_clip_config cfg;
+  int device = current_device();
   Registry r;
   Workspace ws;
   bf16_t *tok = nullptr, *pos = nullptr, *fw = nullptr, *fb = nullptr;
@@ -548,6 +552,7 @@ extern "C" void fmi_clip_destroy(fmi_clip* m) {
   delete m;
 }
 extern "C" int fmi_clip_set_tensor(fmi_clip* m, const char* name, const void* data, fmi_dtype dtype, const int64_t* shape, int rank) {
+  if (m) FMI_TRY(use_device_ordinal(m->device));
   if (!m) return fail(FMI_ERR_INVALID, "clip_set_tensor: null model");
   return m->r.set("clip_set_tensor", name, data, dtype, shape, rank);
 }
@@ -560,6 +565,7 @@ extern "C" const char* fmi_clip_missing_name(fmi_clip* m, int i) {
 extern "C" size_t fmi_clip_size_in_bytes(const fmi_clip* m) { return m ? m->r.bytes + m->ws.bytes : 0; }
 
 extern "C" int fmi_clip_forward(fmi_clip* m, const int32_t* input_ids, int B, int T, void* pooled_out, fmi_dtype pooled_dtype, float* hidden_out, void* stream) {
+  if (m) FMI_TRY(use_device_ordinal(m->device));
   if (!m || !input_ids || !pooled_out) return fail(FMI_ERR_INVALID, "clip_forward: null argument");
   if (B <= 0 || T <= 0) return fail(FMI_ERR_INVALID, "clip_forward: empty batch");
   const fmi_clip_config& c = m->cfg;

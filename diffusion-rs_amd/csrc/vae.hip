@@ -239,6 +239,7 @@ struct Dest {
 
 struct fmi_vae {
   fmi_vae_config cfg;
+  int device = current_device();
   std::vector<void*> allocs;
   Conv conv_in, conv_out;
   Resnet mid1, mid2;
@@ -510,6 +511,7 @@ extern "C" void fmi_vae_destroy(fmi_vae* v) {
 }
 
 extern "C" int fmi_vae_set_tensor(fmi_vae* v, const char* name, const void* data, fmi_dtype dtype, const int64_t* shape, int rank) {
+  if (v) FMI_TRY(use_device_ordinal(v->device));
   if (!v || !name || !data) return fail(FMI_ERR_INVALID, "vae_set_tensor: null argument");
   auto it = v->names.find(name);
   if (it == v->names.end()) return fail(FMI_ERR_INVALID, std::string("vae_set_tensor: unknown tensor name '") + name + "'");
@@ -597,6 +599,7 @@ __global__ void diag_gaussian_kernel(const bf16_t* __restrict mom, const float* 
 // == AutoEncoderKl::encode (autoencoder_kl.rs:103-110) = Encoder::forward (vae.rs:330-349),
 // optional quant_conv, DiagonalGaussian.  H, W must be multiples of 8.
 extern "C" int fmi_vae_encode(fmi_vae* v, const float* image, int B, int H, int W, const float* noise, float* z_out, float* moments_out, void* stream) {
+  if (v) FMI_TRY(use_device_ordinal(v->device));
   if (!v || !image || !z_out) return fail(FMI_ERR_INVALID, "vae_encode: null argument");
   if (B <= 0 || H <= 0 || W <= 0 || H % 8 || W % 8) return fail(FMI_ERR_INVALID, "vae_encode: H and W must be positive multiples of 8");
   FMI_TRY(check_part(v, false));
@@ -640,6 +643,7 @@ extern "C" int fmi_vae_encode(fmi_vae* v, const float* image, int B, int H, int 
 }
 
 extern "C" int fmi_vae_decode(fmi_vae* v, const float* z, int B, int h, int w, float* image_out, void* stream) {
+  if (v) FMI_TRY(use_device_ordinal(v->device));
   if (!v || !z || !image_out) return fail(FMI_ERR_INVALID, "vae_decode: null argument");
   if (B <= 0 || h <= 0 || w <= 0) return fail(FMI_ERR_INVALID, "vae_decode: empty input");
   FMI_TRY(check_part(v, true));

@@ -3,8 +3,9 @@ RCCL/xGMI ("nccl" backend on ROCm; "gloo" in the CPU tests).
 
 The path shards by independent samples — every (prompt, latent) pair is its own 50-step
 trajectory — so there is NO data-path collective.  The only communication is
-  * one broadcast of the weights from rank 0 at load (23.8 GB bf16 for FLUX.1-dev), tensor by
-    tensor so each message is a large contiguous buffer (xGMI is point-to-point: few, big messages);
+  * one broadcast of the weights from rank 0 at load: the model's flat weight arenas
+    (23.8 GB bf16 / 6.7 GB nf4 for FLUX.1-dev) go out in a few messages of up to 1 GiB each
+    (`broadcast_state`; xGMI is point-to-point: few, big messages), after a ~1 KB description of the layout;
   * one gather of the decoded u8 images (3 MB/sample at 1024^2) to rank 0 per batch.
 The reference has no distributed code at all (pipelines/mod.rs:214-217 uses device 0 only).
 """
@@ -44,6 +45,50 @@ def broadcast_tensors(shapes: Dict[str, tuple], make: Callable[[str, tuple], tor
     return total
 
 
+STATE_CHUNK = 1 << 30  # bytes per broadcast message of the weight arenas
+
+
+def broadcast_state(model, device, src: int = 0, chunk_bytes: int = STATE_CHUNK) -> dict:
+    """Replicate `model`'s weights from rank `src` to every rank: the layout blob first (state_export /
+    state_adopt), then every weight arena in messages of `chunk_bytes` through one reusable staging tensor
+    (arena -> staging on the source, broadcast, staging -> arena on the receivers; the extra device-to-device
+    copy runs at HBM speed and keeps the C-ABI free of torch types).  `model` needs state_export(), state_adopt(blob),
+    state_buffers() -> [(ptr, bytes)] and copy_state_chunk(index, offset, staging, nbytes, to_staging).
+    Returns {"bytes", "messages", "seconds"}."""
+    import time
+    rank, ws = world()
+    t0 = time.perf_counter()
+    if ws == 1:
+        return {"bytes": 0, "messages": 0, "seconds": 0.0}
+    blob = [model.state_export() if rank == src else None]
+    dist.broadcast_object_list(blob, src=src)
+    if rank != src:
+        model.state_adopt(blob[0])
+    sizes = [n for _, n in model.state_buffers()]
+    staging = torch.empty(min(chunk_bytes, max(sizes + [1])), dtype=torch.uint8, device=device)
+    total = msgs = 0
+    for i, n in enumerate(sizes):
+        off = 0
+        while off < n:
+            k = min(chunk_bytes, n - off)
+            if rank == src:
+                model.copy_state_chunk(i, off, staging, k, True)
+                _sync(device)
+            dist.broadcast(staging[:k], src=src)
+            if rank != src:
+                model.copy_state_chunk(i, off, staging, k, False)
+                _sync(device)
+            off += k
+            total += k
+            msgs += 1
+    return {"bytes": total, "messages": msgs, "seconds": time.perf_counter() - t0}
+
+
+def _sync(device):
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
 def gather_to_rank0(local: torch.Tensor, n_total: int) -> Optional[torch.Tensor]:
     """Gather per-rank sample stacks (n_local, ...) to rank 0 and restore the global sample order
     (sample i was produced by rank i % world).  Ranks may hold different counts (ragged batch)."""
@@ -56,6 +101,8 @@ def gather_to_rank0(local: torch.Tensor, n_total: int) -> Optional[torch.Tensor]
     if local.shape[0] < cmax:  # pad so every rank sends the same shape
         fill = torch.zeros((cmax - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         pad = torch.cat([local, fill], 0)
+    if cmax == 0:
+        return local if rank == 0 else None
     bufs = [torch.empty_like(pad) for _ in range(ws)] if rank == 0 else None
     dist.gather(pad.contiguous(), bufs, dst=0)
     if rank != 0:
@@ -67,10 +114,74 @@ def gather_to_rank0(local: torch.Tensor, n_total: int) -> Optional[torch.Tensor]
     return torch.stack(out, 0)
 
 
-def generate_sharded(prompts: Sequence[str], run_local: Callable[[List[str], List[int]], torch.Tensor]) -> Optional[torch.Tensor]:
+def generate_sharded(prompts: Sequence[str], run_local: Callable[[List[str], List[int]], torch.Tensor],
+                     empty: Optional[Callable[[], torch.Tensor]] = None) -> Optional[torch.Tensor]:
     """Shard `prompts` across ranks, run `run_local(my_prompts, my_sample_ids)` -> (n_local, ...) on each,
-    gather to rank 0 in prompt order."""
+    gather to rank 0 in prompt order.  A rank without samples (fewer prompts than ranks) does not call
+    `run_local`; it contributes `empty()` — a (0, ...) tensor of the output's trailing shape and dtype."""
     rank, ws = world()
     ids = shard_indices(len(prompts), rank, ws)
-    local = run_local([prompts[i] for i in ids], ids)
+    if ids or empty is None:
+        local = run_local([prompts[i] for i in ids], ids)
+    else:
+        local = empty()
     return gather_to_rank0(local, len(prompts))
+
+
+# ---------------------------------------------------------------------------------------------
+# Single-image sequence parallelism (SURVEY §8(f)-4, DESIGN §9): Ulysses-style head sharding of the
+# joint attention.  Tokens are sharded across the P ranks of a sequence-parallel group for everything
+# that is per-token (LayerNorm, the q|k|v / MLP GEMMs, the residual updates); attention needs every
+# key for a head, so q, k, v are redistributed  (tokens/P, all H heads) -> (all tokens, H/P heads)  by
+# one all-to-all, and the attention output goes back by a second one.  These helpers are the index
+# math of that exchange (layout (tokens, heads, 128)); they run on any backend (tested with gloo).
+def ulysses_token_range(n_tokens: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous token shard of a rank: ceil-split, the last ranks may hold fewer (or no) tokens."""
+    per = (n_tokens + world_size - 1) // world_size
+    a = min(rank * per, n_tokens)
+    return a, min(a + per, n_tokens)
+
+
+def ulysses_head_range(n_heads: int, rank: int, world_size: int) -> Tuple[int, int]:
+    if n_heads % world_size:
+        raise ValueError(f"{n_heads} heads do not split over {world_size} ranks")
+    per = n_heads // world_size
+    return rank * per, (rank + 1) * per
+
+
+def ulysses_scatter_heads(x_local: torch.Tensor, n_tokens: int, group=None) -> torch.Tensor:
+    """(my tokens, H, d) -> (n_tokens, H/P, d): every rank ends with ALL tokens of ITS heads.
+    One all_to_all; message to rank r = my tokens x r's heads (bytes = tokens/P * H/P * d * 2 for bf16)."""
+    rank, ws = world()
+    if ws == 1:
+        return x_local
+    H, d = x_local.shape[1], x_local.shape[2]
+    send = [x_local[:, slice(*ulysses_head_range(H, r, ws)), :].contiguous() for r in range(ws)]
+    recv = [torch.empty((ulysses_token_range(n_tokens, r, ws)[1] - ulysses_token_range(n_tokens, r, ws)[0], H // ws, d),
+                        dtype=x_local.dtype, device=x_local.device) for r in range(ws)]
+    _all_to_all(recv, send, group)
+    return torch.cat(recv, 0)
+
+
+def ulysses_gather_heads(o_heads: torch.Tensor, n_tokens: int, n_heads: int, group=None) -> torch.Tensor:
+    """Inverse of ulysses_scatter_heads: (n_tokens, H/P, d) -> (my tokens, H, d)."""
+    rank, ws = world()
+    if ws == 1:
+        return o_heads
+    d = o_heads.shape[2]
+    send = [o_heads[slice(*ulysses_token_range(n_tokens, r, ws))].contiguous() for r in range(ws)]
+    a, b = ulysses_token_range(n_tokens, rank, ws)
+    recv = [torch.empty((b - a, n_heads // ws, d), dtype=o_heads.dtype, device=o_heads.device) for _ in range(ws)]
+    _all_to_all(recv, send, group)
+    return torch.cat(recv, 1)
+
+
+def _all_to_all(recv: List[torch.Tensor], send: List[torch.Tensor], group=None):
+    """One all-to-all with ragged pieces: all_to_all_single over flattened buffers (RCCL and gloo both have it)."""
+    flat_send = torch.cat([t.reshape(-1) for t in send])
+    flat_recv = torch.empty(sum(t.numel() for t in recv), dtype=flat_send.dtype, device=flat_send.device)
+    dist.all_to_all_single(flat_recv, flat_send, [t.numel() for t in recv], [t.numel() for t in send], group=group)
+    off = 0
+    for t in recv:
+        t.copy_(flat_recv[off:off + t.numel()].view_as(t))
+        off += t.numel()

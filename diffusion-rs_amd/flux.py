@@ -146,6 +146,39 @@ class FluxModel:
     def size_in_bytes(self) -> int:
         return self.lib.fmi_flux_size_in_bytes(self.h)
 
+    def set_quant_dense_cache(self, on: bool):
+        """Quantised linears: False (default) = fused dequant-GEMM on the packed codes, no bf16 copy resident;
+        True = expand each matrix once into the bf16 arena and run the dense kernels."""
+        L.check(self.lib.fmi_flux_set_quant_dense_cache(self.h, int(on)))
+
+    # ---- the weights as flat device buffers (multi-GPU broadcast, dist.broadcast_state)
+    def state_export(self) -> bytes:
+        n = C.c_size_t()
+        L.check(self.lib.fmi_flux_state_export(self.h, None, 0, C.byref(n)))
+        buf = (C.c_uint8 * n.value)()
+        L.check(self.lib.fmi_flux_state_export(self.h, buf, n.value, C.byref(n)))
+        return bytes(buf)
+
+    def state_adopt(self, blob: bytes):
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        L.check(self.lib.fmi_flux_state_adopt(self.h, buf, len(blob)))
+
+    def state_buffers(self):
+        """[(device pointer, bytes)] of the weight arenas (pointer 0 / 0 bytes for an arena not in use)."""
+        out = []
+        for i in range(self.lib.fmi_flux_state_buffer_count()):
+            p, n = C.c_void_p(), C.c_size_t()
+            L.check(self.lib.fmi_flux_state_buffer(self.h, i, C.byref(p), C.byref(n)))
+            out.append((p.value or 0, n.value))
+        return out
+
+    def copy_state_chunk(self, index: int, offset: int, staging: torch.Tensor, nbytes: int, to_staging: bool):
+        """Device-to-device copy between weight buffer `index` (+offset) and a torch staging tensor."""
+        ptr, total = self.state_buffers()[index]
+        assert ptr and offset + nbytes <= total and staging.numel() * staging.element_size() >= nbytes
+        a, b = C.c_void_p(ptr + offset), C.c_void_p(staging.data_ptr())
+        L.check(self.lib.fmi_memcpy(b, a, nbytes, _stream()) if to_staging else self.lib.fmi_memcpy(a, b, nbytes, _stream()))
+
     def _inputs(self, img, img_ids, txt, txt_ids, timesteps, y, guidance):
         B, S = int(img_ids.shape[0]), int(img_ids.shape[1])
         T = int(txt.shape[1])

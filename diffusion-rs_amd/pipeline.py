@@ -10,9 +10,14 @@ diffusion_rs_core/src/pipelines/mod.rs:24-33,110-270) over the MI355X hot path.
 Scope: text encoders (when the checkpoint ships them), the denoise loop and the VAE
 decode run on the GPU through the C-ABI.  Tokenisation needs the checkpoint's tokenizer files and
 the `tokenizers` package; without them pass `token_ids=(t5_ids, clip_ids)` or precomputed
-`embeddings=(t5_emb, clip_emb)`.  A pipeline built WITHOUT text encoders (the benchmark's synthetic
-source) derives deterministic placeholder embeddings from the prompt text — only shapes matter there.  Extensions over the reference, all keyword-only:
-`latents=` / `seed=` (the reference cannot be seeded), `embeddings=`, `output=`.
+`embeddings=(t5_emb, clip_emb)` — a loaded checkpoint never falls back to made-up embeddings.  Only the
+Synthetic source built without text encoders (the benchmark) derives deterministic placeholder
+embeddings from the prompt text: only shapes matter there.  Extensions over the reference, all keyword-only:
+`latents=` / `seed=` (the reference cannot be seeded), `embeddings=`, `token_ids=`, `output=`.
+
+Multi-GPU: when torch.distributed is initialised (one process per GPU), the constructor loads the
+DiT on rank 0 only and broadcasts its weight arenas over RCCL (dist.broadcast_state), and `forward` shards the
+prompts — prompt i runs on rank i % world — and gathers the images to rank 0 (other ranks return None).
 """
 import enum
 import hashlib
@@ -108,7 +113,7 @@ def encode_png(rgb: np.ndarray) -> bytes:
 
 
 def placeholder_embeddings(prompts: Sequence[str], T: int, joint_dim: int, pooled_dim: int, device):
-    """Deterministic stand-in for T5/CLIP outputs (text encoders are out of scope)."""
+    """Deterministic stand-in for T5/CLIP outputs, for the Synthetic source without text encoders only."""
     t5, clip = [], []
     for p in prompts:
         seed = int.from_bytes(hashlib.sha256(p.encode()).digest()[:8], "little")
@@ -133,11 +138,18 @@ class Pipeline:
         self._lock = threading.Lock()  # Arc<Mutex<dyn ModelPipeline>>, pipelines/mod.rs:110-113
         self.scheduler = F.SchedulerConfig()
         self.t5 = self.clip = self.t5_tokenizer = self.clip_tokenizer = None
+        self.source_kind = source.kind
+        from . import dist as D
+        rank, world = D.world()
+        # multi-GPU: the DiT (98 % of the bytes) is materialised on rank 0 and broadcast as flat arenas; the VAE and
+        # the text encoders are loaded / generated by every rank itself (same files, same seeds)
+        self.load_stats = {}
         if source.kind == "synthetic":
             fcfg = source.flux_cfg or (F.FLUX_DEV if source.variant == "dev" else F.FLUX_SCHNELL)
             vcfg = source.vae_cfg or F.VAE_FLUX
             self.flux = F.FluxModel(fcfg, device)
-            synth.fill_flux_random_device(self.flux, seed=source.seed, device=self.device)
+            if rank == 0:
+                synth.fill_flux_random_device(self.flux, seed=source.seed, device=self.device)
             self.vae = F.AutoEncoderKl(vcfg, device)
             synth.fill_vae_random_device(self.vae, seed=source.seed + 1, device=self.device)
             if source.variant != "dev":
@@ -149,16 +161,18 @@ class Pipeline:
                 self.clip = text.ClipTextTransformer(source.clip_cfg, device)
                 synth.fill_text_random_device(self.clip, seed=source.seed + 3, device=self.device)
         elif source.kind == "model_id":
-            self._load_checkpoint(source.model_id, getattr(source, "transformer_model_id", None))
+            self._load_checkpoint(source.model_id, getattr(source, "transformer_model_id", None), load_dit=(rank == 0))
         else:
-            self._load_checkpoint(source.file, None)
+            self._load_checkpoint(source.file, None, load_dit=(rank == 0))
+        if world > 1:
+            self.load_stats["broadcast"] = D.broadcast_state(self.flux, self.device)
         if dtype == ModelDType.F8E4M3:
             self.flux.quantize_fp8()
 
     # Pipeline::load (pipelines/mod.rs:120-236) for a local diffusers directory or a DDUF file:
-    # model_index.json -> FluxPipeline only; scheduler / transformer / vae components
-    # (text_encoder*, tokenizer* are listed by the reference loader but out of scope here).
-    def _load_checkpoint(self, path: str, transformer_path: Optional[str]):
+    # model_index.json -> FluxPipeline only; scheduler / transformer / vae components, plus text_encoder (CLIP),
+    # text_encoder_2 (T5) and their tokenizers when the checkpoint ships them (flux/mod.rs:74-127).
+    def _load_checkpoint(self, path: str, transformer_path: Optional[str], load_dit: bool = True):
         from . import loader
         fl = loader.FileLoader(path)
         if fl.read_json("model_index.json").get("_class_name") != "FluxPipeline":  # pipelines/mod.rs:146-149
@@ -171,7 +185,8 @@ class Pipeline:
         fcfg = dict(F.FLUX_DEV, **{k: tc[k] for k in ("in_channels", "pooled_projection_dim", "joint_attention_dim", "num_attention_heads", "num_layers",
                                                      "num_single_layers", "guidance_embeds") if k in tc})
         self.flux = F.FluxModel(fcfg, self.device_index)
-        self.load_stats = loader.load_flux(self.flux, tl.tensors("transformer"))
+        if load_dit:  # (multi-GPU: the other ranks receive the weight arenas, dist.broadcast_state)
+            self.load_stats.update(loader.load_flux(self.flux, tl.tensors("transformer")))
         vc = fl.read_json("vae/config.json")
         vcfg = dict(F.VAE_FLUX, **{k: vc[k] for k in F.VAE_FLUX if k in vc})
         self.vae = F.AutoEncoderKl(vcfg, self.device_index)
@@ -223,41 +238,90 @@ class Pipeline:
             t5_ids = torch.nn.functional.pad(t5_ids, (0, 256 - t5_ids.shape[1]))
         return self.t5.forward(t5_ids), self.clip.forward(torch.as_tensor(clip_ids, dtype=torch.int32))
 
+    MAX_BATCH = 8  # samples per denoise call (the C-ABI's per-device batch limit); longer prompt lists run in chunks
+
     def generate_tensor(self, prompts: List[str], params: DiffusionGenerationParams, *, embeddings=None, latents=None,
-                        seed: Optional[int] = None, first_sample: int = 0, token_ids=None) -> torch.Tensor:
-        """== ModelPipeline::forward for FluxPipeline (pipelines/flux/mod.rs:224-335) from the
-        embeddings onward.  Returns (B,3,H,W) u8 on the device."""
-        cfg = self.flux.cfg
+                        seed: Optional[int] = None, first_sample: int = 0, token_ids=None, sample_ids: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """== ModelPipeline::forward for FluxPipeline (pipelines/flux/mod.rs:224-335) on THIS device.
+        Returns (B,3,H,W) u8 on the device.  `sample_ids` (default first_sample + 0..B-1) name the Philox streams of
+        the samples, so that a sample draws the same noise whichever rank / chunk it runs in."""
         B = len(prompts)
+        ids = list(sample_ids) if sample_ids is not None else [first_sample + b for b in range(B)]
+        if len(ids) != B:
+            raise ValueError("sample_ids must name one stream per prompt")
+        if B == 0:
+            return torch.empty((0, 3, params.height, params.width), dtype=torch.uint8, device=self.device)
+        if B > self.MAX_BATCH:  # the reference accepts any batch (pipelines/mod.rs:241-270)
+            outs = []
+            for a in range(0, B, self.MAX_BATCH):
+                sl = slice(a, a + self.MAX_BATCH)
+                outs.append(self.generate_tensor(
+                    prompts[sl], params, embeddings=None if embeddings is None else (embeddings[0][sl], embeddings[1][sl]),
+                    latents=None if latents is None else latents[sl], seed=seed,
+                    token_ids=None if token_ids is None else (token_ids[0][sl], token_ids[1][sl]), sample_ids=ids[sl]))
+            return torch.cat(outs, 0)
+        cfg = self.flux.cfg
         dev = self.device
-        if embeddings is None and self.t5 is not None and (token_ids is not None or self.t5_tokenizer is not None):
-            t5_emb, clip_emb = self.encode_prompts(prompts, token_ids)
-        elif embeddings is None:
-            # schnell pads T5 ids to 256 (flux/mod.rs:243-253); dev uses the prompt length — 512 here
-            T = 256 if not self.flux.is_guidance() else 512
-            t5_emb, clip_emb = placeholder_embeddings(prompts, T, cfg["joint_attention_dim"], cfg["pooled_projection_dim"], dev)
-        else:
-            t5_emb, clip_emb = embeddings
-            t5_emb, clip_emb = t5_emb.to(dev), clip_emb.to(dev)
-        h = (params.height + 15) // 16 * 2  # get_noise, flux/sampling.rs:12-13
-        w = (params.width + 15) // 16 * 2
-        if latents is None:
-            latents = F.randn_latents(B, 16, h, w, seed if seed is not None else 299792458, first_sample, dev)
-        latents = latents.to(device=dev, dtype=torch.float32)
-        img, img_ids = F.pack_latents(latents)  # State::new
-        txt_ids = torch.zeros((B, t5_emb.shape[1], 3), dtype=torch.float32, device=dev)
-        mu = self.scheduler.calculate_shift(img.shape[1])
-        timesteps = self.scheduler.get_timesteps(params.num_steps, mu)
-        guidance = torch.full((B,), float(params.guidance_scale), dtype=torch.float32, device=dev) if self.flux.is_guidance() else None
-        with self._lock:
+        with self._lock:  # the whole forward, text encoders included, like the reference's mutex (pipelines/mod.rs:247)
+            if embeddings is not None:
+                t5_emb, clip_emb = embeddings
+                t5_emb, clip_emb = t5_emb.to(dev), clip_emb.to(dev)
+            elif self.t5 is not None and self.clip is not None:
+                t5_emb, clip_emb = self.encode_prompts(prompts, token_ids)
+            elif self.source_kind == "synthetic":
+                # schnell pads T5 ids to 256 (flux/mod.rs:243-253); dev uses the prompt length — 512 here
+                T = 256 if not self.flux.is_guidance() else 512
+                t5_emb, clip_emb = placeholder_embeddings(prompts, T, cfg["joint_attention_dim"], cfg["pooled_projection_dim"], dev)
+            else:
+                raise F.L.FmiError("this checkpoint was loaded without text encoders: pass embeddings=(t5_emb, clip_emb)")
+            h = (params.height + 15) // 16 * 2  # get_noise, flux/sampling.rs:12-13
+            w = (params.width + 15) // 16 * 2
+            if latents is None:
+                sd = seed if seed is not None else 299792458
+                if ids == list(range(ids[0], ids[0] + B)):
+                    latents = F.randn_latents(B, 16, h, w, sd, ids[0], dev)
+                else:
+                    latents = torch.cat([F.randn_latents(1, 16, h, w, sd, i, dev) for i in ids], 0)
+            latents = latents.to(device=dev, dtype=torch.float32)
+            img, img_ids = F.pack_latents(latents)  # State::new
+            txt_ids = torch.zeros((B, t5_emb.shape[1], 3), dtype=torch.float32, device=dev)
+            mu = self.scheduler.calculate_shift(img.shape[1])
+            timesteps = self.scheduler.get_timesteps(params.num_steps, mu)
+            guidance = torch.full((B,), float(params.guidance_scale), dtype=torch.float32, device=dev) if self.flux.is_guidance() else None
             img = self.flux.denoise(img, img_ids, t5_emb, txt_ids, clip_emb, guidance, timesteps)
             z = F.unpack_latents(img, 16, h, w, self.vae.scale_factor(), self.vae.shift_factor())
             image = self.vae.decode(z)
             return F.postprocess_u8(image)
 
     def forward(self, prompts: List[str], params: DiffusionGenerationParams, *, output: str = "png", **kw):
-        """== Pipeline::forward (pipelines/mod.rs:241-270) + the PNG encode of the pyo3 binding."""
-        u8 = self.generate_tensor(prompts, params, **kw)
+        """== Pipeline::forward (pipelines/mod.rs:241-270) + the PNG encode of the pyo3 binding.
+        With torch.distributed initialised the batch is sharded (prompt i on rank i % world, no data-path collective) and
+        the images are gathered to rank 0; every rank must make the same call, ranks != 0 return None."""
+        from . import dist as D
+        rank, world = D.world()
+        if world > 1:
+            n = len(prompts)
+
+            def pick(x, ids):
+                return None if x is None else x[torch.as_tensor(ids, dtype=torch.long)] if isinstance(x, torch.Tensor) else [x[i] for i in ids]
+
+            def run_local(my_prompts, ids):
+                sub = dict(kw)
+                for key in ("embeddings", "token_ids"):
+                    if sub.get(key) is not None:
+                        sub[key] = tuple(pick(t, ids) for t in sub[key])
+                if sub.get("latents") is not None:
+                    sub["latents"] = pick(sub["latents"], ids)
+                first = sub.pop("first_sample", 0)
+                return self.generate_tensor(my_prompts, params, sample_ids=[first + i for i in ids], **sub)
+
+            u8 = D.generate_sharded(prompts, run_local,
+                                    empty=lambda: torch.empty((0, 3, params.height, params.width), dtype=torch.uint8, device=self.device))
+            if rank != 0:
+                return None
+            assert u8.shape[0] == n
+        else:
+            u8 = self.generate_tensor(prompts, params, **kw)
         if output == "tensor":
             return u8
         hwc = u8.permute(0, 2, 3, 1).contiguous().cpu().numpy()

@@ -31,8 +31,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
+#pragma GCC visibility push(default)
 
-#define FMI_ABI_VERSION 1
+#define FMI_ABI_VERSION 2
 
 typedef enum fmi_status {
   FMI_OK = 0,
@@ -122,12 +124,29 @@ int fmi_flux_set_linear_bnb4(fmi_flux*, const char* prefix, const uint8_t* packe
  * major + SCB f32 (out); effective weight = w * SCB[row] / 127 (dequant.cu:205-214), expanded to
  * bf16 right before the layer's GEMM.  Same prefix rules as fmi_flux_set_linear_bnb4. */
 int fmi_flux_set_linear_int8(fmi_flux*, const char* prefix, const int8_t* weight, const float* scb, int out_features, int in_features);
-/* Quantised (nf4/fp4/int8) block linears in the MFMA-bound regime (rows >= 512): 1 (default) = each
- * layer is expanded once into its slot of the bf16 weight arena on first use and reused afterwards
- * (BnbLinear::forward's dequantize-then-matmul, bitsandbytes/mod.rs:301-312, amortised over the denoise
- * loop); 0 = expanded into a scratch before every GEMM call.  Small-row calls always use the fused
- * dequant-GEMM on the packed weights. */
+/* Quantised block / modulation linears.  Default (0): nf4 / fp4 matrices are multiplied straight from the
+ * packed codes by the fused dequant-GEMM (the expansion is an LDS stage of the GEMM, gemm_w4q.h) and no
+ * bf16 copy of them exists (an nf4 FLUX.1-dev occupies ~6.7 GB); LLM.int8 matrices are expanded into a
+ * scratch before every GEMM call.  1: each quantised matrix is expanded ONCE into its slot of the bf16
+ * arena (allocated on first use) and the dense kernels run — BnbLinear::forward's dequantize-then-matmul
+ * (bitsandbytes/mod.rs:301-312) amortised over the denoise loop, at the price of the bf16 footprint. */
 int fmi_flux_set_quant_dense_cache(fmi_flux*, int enable);
+/* Process-wide: rows from which 4-bit GEMMs use the one-wave-per-SIMD fused kernel (default 256). */
+int fmi_set_bnb4_onewave_min_rows(int rows);
+/* Test hook of the attention kernel's deferred-rescale branch: 0 = rescale on every key tile, else the
+ * threshold in sixteenths of a log2 unit (default 96 = 6.0). */
+int fmi_flux_set_attention_rescale_threshold(fmi_flux*, int thr_x16);
+/* The weights as flat device buffers — the unit of the multi-GPU broadcast (north star: "RCCL broadcast of
+ * weights").  Rank 0 loads a checkpoint, fmi_flux_state_export() fills a small host blob saying which
+ * arenas exist and how every fused matrix is stored (pass blob_host = NULL to query *len); the other ranks
+ * fmi_flux_state_adopt() it (same arenas allocated, every tensor marked present) and receive the bytes of
+ * buffers 0 .. fmi_flux_state_buffer_count()-1 (fmi_flux_state_buffer: device pointer + size, NULL / 0 for
+ * an arena this checkpoint does not use).  LLM.int8 matrices are not covered (FMI_ERR_UNSUPPORTED).
+ * The reference is single-device (pipelines/mod.rs:214-217). */
+int fmi_flux_state_buffer_count(void);
+int fmi_flux_state_export(fmi_flux*, uint8_t* blob_host, size_t cap, size_t* len);
+int fmi_flux_state_adopt(fmi_flux*, const uint8_t* blob_host, size_t len);
+int fmi_flux_state_buffer(fmi_flux*, int index, void** ptr, size_t* bytes);
 /* fmi_flux_denoise computes every step's modulation vectors (they depend on t, guidance and y only) before
  * the loop: 1 (default) = one MFMA GEMM (n_steps*B, D) x (n_mod, D)^T with silu(vec) rounded to bf16, the
  * 6.5 GB modulation matrix read once per image; 0 = f32 GEMV passes of 4 rows (one pass per 4 steps). */
@@ -316,9 +335,16 @@ int fmi_postprocess_u8(const float* image, int B, int C, int H, int W, int inter
                        uint8_t* out, void* stream);
 /* Deterministic N(0,1) latents from a counter-based Philox4x32-10 generator
  * (the reference's RNG is unseedable; this is the explicit-seed extension).
- * element i of sample b uses counter (i, b) and key (seed). */
+ * Elements 4q..4q+3 of sample b come from the four words of philox(counter = (q lo, q hi, s lo, s hi),
+ * key = (seed lo, seed hi)), s = first_sample + b: words (0,1) and (2,3) each feed one Box-Muller pair,
+ * u = ((word >> 8) + 0.5) / 2^24, z = sqrt(-2 ln u1) * (cos, sin)(2 pi u2).  Replaces get_noise
+ * (pipelines/flux/sampling.rs:5-14). */
 int fmi_randn(float* out, int64_t n_per_sample, int B, uint64_t seed, uint64_t first_sample,
               void* stream);
+/* The raw 32-bit words fmi_randn draws from, same indexing (out (B, n_per_sample) u32): integer work,
+ * bit-exact against the oracle's Philox, which is pinned by Random123's known-answer vectors. */
+int fmi_philox_u32(uint32_t* out, int64_t n_per_sample, int B, uint64_t seed, uint64_t first_sample,
+                   void* stream);
 
 /* Host-side schedule helpers (f64, bit-for-bit the reference formulas). */
 double fmi_calculate_shift(int image_seq_len, int base_seq_len, int max_seq_len,
@@ -420,6 +446,7 @@ int fmi_event_record(void* ev, void* stream);
 int fmi_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 int fmi_event_destroy(void* ev);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -301,6 +301,65 @@ def postprocess_u8(x):
     return out
 
 
+# ---- seedable get_noise (row a4).  The reference's `get_noise` (pipelines/flux/sampling.rs:5-14) is
+# `Tensor::randn` on an unseedable backend RNG, so the product replaces it by a counter-based
+# generator whose stream is a pure function of (seed, sample, element): Philox4x32-10 (Salmon, Moraes, Dror,
+# Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123 v1.14 `philox.h`: multipliers
+# 0xD2511F53 / 0xCD9E8D57, Weyl key increments 0x9E3779B9 / 0xBB67AE85, 10 rounds) followed by Box-Muller.
+# Pinned by Random123's own known-answer vectors (tests/golden/philox_kat.json, tests/test_oracle_philox.py).
+_PHILOX_M0, _PHILOX_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_PHILOX_W0, _PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(ctr, key):
+    """ctr (..., 4) u32, key (..., 2) u32 -> (..., 4) u32."""
+    c = np.array(ctr, dtype=np.uint32).reshape(-1, 4).astype(np.uint64)
+    k = np.broadcast_to(np.array(key, dtype=np.uint32).reshape(-1, 2), (c.shape[0], 2)).astype(np.uint64)
+    c0, c1, c2, c3 = c[:, 0], c[:, 1], c[:, 2], c[:, 3]
+    k0, k1 = k[:, 0].copy(), k[:, 1].copy()
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = _PHILOX_M0 * c0  # 32 x 32 -> 64 bit products
+        p1 = _PHILOX_M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+        hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = (k0 + np.uint64(_PHILOX_W0)) & mask
+        k1 = (k1 + np.uint64(_PHILOX_W1)) & mask
+    out = np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+    return out.reshape(np.array(ctr).shape)
+
+
+def philox_u32(n_per_sample, B, seed, first_sample=0):
+    """The raw stream behind `randn`: element e of sample b is word e % 4 of
+    philox(ctr = (q lo, q hi, sample lo, sample hi), key = (seed lo, seed hi)), q = e // 4, sample = first_sample + b."""
+    quads = (n_per_sample + 3) // 4
+    q = np.arange(quads, dtype=np.uint64)
+    out = np.empty((B, quads * 4), np.uint32)
+    for b in range(B):
+        smp = np.uint64(first_sample + b)
+        ctr = np.stack([q & np.uint64(0xFFFFFFFF), q >> np.uint64(32), np.full(quads, smp & np.uint64(0xFFFFFFFF)),
+                        np.full(quads, smp >> np.uint64(32))], axis=-1).astype(np.uint32)
+        out[b] = philox4x32_10(ctr, [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF]).reshape(-1)
+    return out[:, :n_per_sample]
+
+
+def randn(n_per_sample, B, seed, first_sample=0):
+    """N(0,1) f32 (B, n_per_sample): per counter, words (0,1) and (2,3) each give a Box-Muller pair
+    u = ((w >> 8) + 0.5) / 2^24 (exact in f32), z = sqrt(-2 ln u1) * (cos, sin)(2 pi u2) — evaluated here in
+    f64 and rounded once, so the device's f32 libm results are expected within a few ulp (stated in the test)."""
+    quads = (n_per_sample + 3) // 4
+    w = philox_u32(quads * 4, B, seed, first_sample).reshape(B, quads, 4)
+    u = ((w >> np.uint32(8)).astype(np.float64) + 0.5) / 16777216.0
+    out = np.empty((B, quads, 4), np.float64)
+    for p in range(2):
+        rad = np.sqrt(-2.0 * np.log(u[..., 2 * p]))
+        ang = np.float64(np.float32(6.283185307179586)) * u[..., 2 * p + 1]  # the device multiplies by the f32 constant
+        out[..., 2 * p] = rad * np.cos(ang)
+        out[..., 2 * p + 1] = rad * np.sin(ang)
+    return out.reshape(B, quads * 4)[:, :n_per_sample].astype(np.float32)
+
+
 class Flux:
     """CPU oracle of models::flux::Flux (model.rs:709-838), f32."""
 

@@ -1,5 +1,6 @@
-"""world_size-2 test of the batch-sharding path on CPU (gloo): sample -> rank mapping, weight
-broadcast from rank 0, ragged gather back to rank 0 in prompt order."""
+"""world_size-2 tests of the multi-GPU paths on CPU (gloo): sample -> rank mapping, weight broadcast from rank 0
+(tensor-wise and as flat arenas), ragged gather back to rank 0 in prompt order, Pipeline.forward's sharded front door
+(SURVEY §8e), and the index math of the Ulysses head redistribution."""
 import os
 import socket
 
@@ -42,7 +43,74 @@ def _worker(rank, world, port, n_prompts, q):
         return torch.stack([torch.full((3, 4, 4), 10 * i + len(p), dtype=torch.uint8) for p, i in zip(my_prompts, ids)])
 
     out = fd.generate_sharded(prompts, run_local)
-    q.put((rank, {k: v.numpy() for k, v in got.items()}, None if out is None else out.numpy(), fd.shard_indices(n_prompts, rank, world)))
+
+    # 3. flat-arena broadcast (dist.broadcast_state) with a stand-in for FluxModel's state_* methods
+    class StubModel:
+        def __init__(self):
+            self.blob = None
+            self.bufs = [torch.zeros(0, dtype=torch.uint8)] * 4
+
+        def state_export(self):
+            return b"FMIS-stub:" + bytes([1, 0, 1, 1])
+
+        def state_adopt(self, blob):
+            self.blob = blob
+            self.bufs = [torch.zeros(n, dtype=torch.uint8) for n in (1000, 0, 2500, 77)]
+
+        def state_buffers(self):
+            return [(1 if b.numel() else 0, b.numel()) for b in self.bufs]
+
+        def copy_state_chunk(self, index, offset, staging, nbytes, to_staging):
+            if to_staging:
+                staging[:nbytes] = self.bufs[index][offset:offset + nbytes]
+            else:
+                self.bufs[index][offset:offset + nbytes] = staging[:nbytes]
+
+    sm = StubModel()
+    if rank == 0:
+        gg = torch.Generator().manual_seed(7)
+        sm.bufs = [torch.randint(0, 256, (n,), dtype=torch.uint8, generator=gg) for n in (1000, 0, 2500, 77)]
+    st = fd.broadcast_state(sm, "cpu", chunk_bytes=1024)  # forces several messages per arena
+    assert st["bytes"] == 3577 and st["messages"] == 1 + 3 + 1
+    assert rank == 0 or sm.blob == b"FMIS-stub:" + bytes([1, 0, 1, 1])
+    state_sum = [int(b.to(torch.int64).sum()) for b in sm.bufs]
+
+    # 4. the front door: Pipeline.forward shards prompts when torch.distributed is initialised
+    from diffusion_rs_amd import pipeline as pl
+
+    class StubPipeline(pl.Pipeline):
+        def __init__(self):  # no GPU: only forward()'s sharding / gather logic is under test
+            self.device = torch.device("cpu")
+            self.calls = []
+
+        def generate_tensor(self, my_prompts, params, *, embeddings=None, latents=None, seed=None, sample_ids=None, **kw):
+            self.calls.append((list(my_prompts), list(sample_ids)))
+            assert embeddings is None or embeddings[0].shape[0] == len(my_prompts)
+            e = torch.zeros(len(my_prompts)) if embeddings is None else embeddings[0][:, 0]
+            return torch.stack([torch.full((3, params.height, params.width), (7 * i + len(p) + int(e[j])) % 256, dtype=torch.uint8)
+                                for j, (p, i) in enumerate(zip(my_prompts, sample_ids))]) if my_prompts else torch.empty((0, 3, params.height, params.width), dtype=torch.uint8)
+
+    sp = StubPipeline()
+    params = pl.DiffusionGenerationParams(8, 8, 2, 3.5)
+    emb = (torch.arange(n_prompts, dtype=torch.float32)[:, None].repeat(1, 4), torch.zeros(n_prompts, 2))
+    fwd = sp.forward(prompts, params, output="tensor", embeddings=emb, first_sample=100)
+    assert (fwd is None) == (rank != 0)
+    assert sp.calls == ([([prompts[i] for i in fd.shard_indices(n_prompts, rank, world)], [100 + i for i in fd.shard_indices(n_prompts, rank, world)])]
+                        if fd.shard_indices(n_prompts, rank, world) else [])
+
+    # 5. Ulysses head redistribution: scatter tokens->heads, "attention" as a per-head reduction over all tokens, gather back
+    H, d, n_tok = 4, 8, 11  # 11 tokens over 2 ranks: ragged (6 + 5)
+    full = torch.arange(n_tok * H * d, dtype=torch.float32).reshape(n_tok, H, d)
+    a, b = fd.ulysses_token_range(n_tok, rank, world)
+    heads = fd.ulysses_scatter_heads(full[a:b].clone(), n_tok)
+    h0, h1 = fd.ulysses_head_range(H, rank, world)
+    assert torch.equal(heads, full[:, h0:h1])  # every token of my heads, in token order
+    attn = heads + heads.sum(0, keepdim=True)  # needs all tokens of a head, nothing of other heads
+    back = fd.ulysses_gather_heads(attn, n_tok, H)
+    assert torch.equal(back, (full + full.sum(0, keepdim=True))[a:b])
+
+    q.put((rank, {k: v.numpy() for k, v in got.items()}, None if out is None else out.numpy(), fd.shard_indices(n_prompts, rank, world),
+           state_sum, None if fwd is None else fwd.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,3 +140,7 @@ def test_shard_broadcast_gather_world2():
         for i in range(n_prompts):
             assert (out[i] == 10 * i + len(f"p{i}")).all()  # prompt order restored
         assert sorted(r0[3] + r1[3]) == list(range(n_prompts)) and r0[3] == list(range(0, n_prompts, 2))
+        assert r0[4] == r1[4] and r0[4][1] == 0 and r0[4][0] > 0  # flat arenas identical on both ranks
+        assert r1[5] is None and r0[5].shape == (n_prompts, 3, 8, 8)
+        for i in range(n_prompts):  # Pipeline.forward: prompt order, per-sample embeddings and Philox stream ids followed the shard
+            assert (r0[5][i] == (7 * (100 + i) + len(f"p{i}") + i) % 256).all()

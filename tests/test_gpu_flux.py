@@ -79,7 +79,7 @@ def test_flux_batch_independence(models):
 
 
 def test_flux_nf4_blocks_match_dequantised_oracle(models):
-    """C3 semantics: block linears stored nf4 and run through the fused dequant-GEMM equal the
+    """C3 semantics: block AND modulation linears stored nf4 and run through the fused dequant-GEMM equal the
     oracle run on the dequantised (bf16) weights — BnbLinear::forward (bitsandbytes/mod.rs:301-312)."""
     torch, d = models["torch"], models["d"]
     from oracle import oracle as orc
@@ -88,8 +88,8 @@ def test_flux_nf4_blocks_match_dequantised_oracle(models):
     oq = orc.Flux(SMALL_FLUX)
     D = 256
     for name, w in sd.items():
-        is_block_lin = name.endswith(".weight") and w.ndim == 2 and ("transformer_blocks." in name) and ("norm" not in name)
-        if is_block_lin:
+        is_quant_lin = name.endswith(".weight") and w.ndim == 2 and (("transformer_blocks." in name) or name == "norm_out.linear.weight")
+        if is_quant_lin:  # what a bitsandbytes checkpoint quantises: every nn.Linear of the blocks (modulation included)
             packed, absmax = orc.quantize_blockwise_4bit(w.ravel(), 64, "nf4")
             wdq = orc.dequantize_blockwise(None, packed, absmax, 64, w.size, "nf4", "bf16").reshape(w.shape)
             gq.set_linear_bnb4(name[:-len(".weight")], packed, absmax, 64, "nf4", w.shape[0], w.shape[1])
@@ -106,30 +106,65 @@ def test_flux_nf4_blocks_match_dequantised_oracle(models):
     err = rel_l2(got, ref)
     print(f"nf4 forward (fused dequant-GEMM): rel-L2 {err:.3e}")
     assert err <= 1e-2
-    # large-M dispatch: dequantise once per call into the bf16 scratch, then the dense MFMA kernel
+    # default: packed codes only — the bf16 BLOCKS arena was never allocated
+    assert gq.state_buffers()[2][1] == 0 and gq.state_buffers()[3][1] > 0
+    # opt-in expanded cache: each matrix dequantised once into the bf16 arena, then the dense MFMA kernels
     from diffusion_rs_amd import _lib as L
-    L.check(L.load().fmi_flux_set_bnb4_fused_max_rows(gq.h, 1))
+    gq.set_quant_dense_cache(True)
     got2 = host(gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
     err2 = rel_l2(got2, ref)
     print(f"nf4 forward (dequant-once + dense): rel-L2 {err2:.3e}")
     assert err2 <= 1e-2
-    # both paths multiply the same bf16 weights: they agree far below the oracle tolerance
-    assert rel_l2(got2, got) <= 2e-3
-    # the expanded copies are cached in the arena (default) — a second call reuses them; the per-call scratch form agrees bit for bit
+    # both paths multiply the same bf16 weights in the same order: identical bits
+    np.testing.assert_array_equal(got2, got)
+    assert gq.state_buffers()[2][1] > 0
+    # a second call reuses the cached copies
     got3 = host(gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
     np.testing.assert_array_equal(got3, got2)
-    L.check(L.load().fmi_flux_set_quant_dense_cache(gq.h, 0))
-    got4 = host(gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
-    np.testing.assert_array_equal(got4, got2)
     # re-setting a quantised linear invalidates its cached copy
-    L.check(L.load().fmi_flux_set_quant_dense_cache(gq.h, 1))
-    gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
     name = next(n for n in sd if n.endswith("ff.net.2.weight"))
     w = sd[name]
     packed, absmax = orc.quantize_blockwise_4bit((2.0 * w).ravel(), 64, "nf4")
     gq.set_linear_bnb4(name[:-len(".weight")], packed, absmax, 64, "nf4", w.shape[0], w.shape[1])
     got5 = host(gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
     assert not np.array_equal(got5, got2)
+
+
+def test_flux_mixed_quantised_and_dense_parts_of_a_fused_projection(models):
+    """A checkpoint may quantise only some Linears of a fused matrix (to_q nf4, to_k / to_v dense — e.g. bnb's
+    skip-modules): the quantised parts are expanded at finalisation and the matrix runs dense; nothing reads
+    uninitialised packed rows."""
+    torch, d = models["torch"], models["d"]
+    from oracle import oracle as orc
+    sd = dict(models["sd"])
+    gq = d.FluxModel(SMALL_FLUX)
+    oq = orc.Flux(SMALL_FLUX)
+    nq = 0
+    for name, w in sd.items():
+        if name.endswith("attn.to_q.weight") or name.endswith("attn.add_k_proj.weight") or name.endswith("proj_mlp.weight"):
+            packed, absmax = orc.quantize_blockwise_4bit(w.ravel(), 64, "nf4")
+            wdq = orc.dequantize_blockwise(None, packed, absmax, 64, w.size, "nf4", "bf16").reshape(w.shape)
+            gq.set_linear_bnb4(name[:-len(".weight")], packed, absmax, 64, "nf4", w.shape[0], w.shape[1])
+            oq.set_tensor(name, wdq)
+            nq += 1
+        else:
+            gq.set_tensor(name, w)
+            oq.set_tensor(name, w)
+    assert nq == 2 + 2 + 2 + 2  # to_q of 2 double + 2 single blocks, add_k_proj of 2 double, proj_mlp of 2 single
+    gq.assert_complete()
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, 1, (8, 8), 32, seed=12)
+    t = np.array([0.8], np.float32)
+    g = np.array([3.5], np.float32)
+    ref = oq.forward(img, ids, txt, txt_ids, t, y, g)
+    got = host(gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
+    err = rel_l2(got, ref)
+    print(f"mixed nf4 / dense parts: rel-L2 {err:.3e}")
+    assert err <= 1e-2
+    # a later dense set_tensor on a part of a quantised matrix takes effect too (the cached state is invalidated)
+    name = next(n for n in sd if n.endswith("attn.to_q.weight"))
+    gq.set_tensor(name, 2.0 * sd[name])
+    got2 = host(gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
+    assert not np.array_equal(got2, got)
 
 
 def test_flux_int8_scb_blocks_match_dequantised_oracle(models, tmp_path):

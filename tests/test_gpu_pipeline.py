@@ -21,7 +21,10 @@ def _oracle_pipeline(sd, vsd, lat, t5, clip, steps, guidance, sched):
     B, C, h, w = lat.shape
     img, ids = orc.pack_latents(lat)
     txt_ids = np.zeros((B, t5.shape[1], 3), np.float32)
-    ts = sched.get_timesteps(steps, sched.calculate_shift(img.shape[1]))
+    # the schedule is computed by the ORACLE (orc.calculate_shift / orc.get_timesteps restate flux/sampling.rs:70-80 and
+    # scheduler.rs:22-51), not taken from the product's scheduler object — `sched` only supplies the config values
+    mu = orc.calculate_shift(img.shape[1], sched.base_image_seq_len, sched.max_image_seq_len, sched.base_shift, sched.max_shift)
+    ts = orc.get_timesteps(steps, sched.use_dynamic_shifting, mu, sched.shift)
     g = np.full(B, guidance, np.float32)
     img = om.denoise(img, ids, t5, txt_ids, clip, g, ts)
     z = orc.unpack_latents(img, C, h, w) * np.float32(1.0 / SMALL_VAE["scaling_factor"]) + np.float32(SMALL_VAE["shift_factor"])
@@ -73,9 +76,13 @@ def test_pipeline_end_to_end_matches_oracle(tmp_path):
     # PNG front end == the pyo3 binding's return type
     pngs = pipe.forward(["a", "b"], params, embeddings=(dev(t5, torch.bfloat16), dev(clip)), latents=dev(lat))
     assert len(pngs) == 2 and all(p[:8] == b"\x89PNG\r\n\x1a\n" for p in pngs)
+    # a loaded checkpoint never invents embeddings (the reference always tokenises and encodes): without text encoders it needs them passed
+    with pytest.raises(d.FmiError):
+        pipe.forward(["x", "y"], params, seed=5, output="tensor")
     # seeded latents are reproducible and differ per sample
-    a = pipe.forward(["x", "y"], params, seed=5, output="tensor").cpu().numpy()
-    b = pipe.forward(["x", "y"], params, seed=5, output="tensor").cpu().numpy()
+    emb = (dev(t5, torch.bfloat16), dev(clip))
+    a = pipe.forward(["x", "y"], params, seed=5, output="tensor", embeddings=emb).cpu().numpy()
+    b = pipe.forward(["x", "y"], params, seed=5, output="tensor", embeddings=emb).cpu().numpy()
     np.testing.assert_array_equal(a, b)
     assert not np.array_equal(a[0], a[1])
 

@@ -1,6 +1,7 @@
-// tools/gemm_bench.hip — standalone micro-benchmark / ablation harness for the bf16 GEMM.
-// Build variants with -DFMI_ABLATE_NO_LOAD / -DFMI_ABLATE_NO_MFMA (see tools/run_gemm_bench.sh).
-// Prints TFLOP/s per FLUX shape on random bf16 data (never zero-filled: DVFS, cdna guide rule 25).
+// tools/gemm_bench.hip — standalone micro-benchmark harness for the GEMM kernels (includes the product source).
+// Prints TFLOP/s per FLUX shape on random bf16 data (never zero-filled: DVFS, cdna guide rule 25): the double-buffered,
+// ping-pong and 4-wave dense kernels, and (FMI_Q4=1) the fused nf4 dequant-GEMM next to "dequant kernel + dense GEMM",
+// with the number of output elements that differ between the arms (must be 0).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,28 @@ __global__ void fill_kernel(bf16_t* p, size_t n, uint32_t seed) {
     x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
     float f = ((float)(x & 0xffff) / 32768.0f - 1.0f);  // uniform [-1,1)
     p[i] = f32_to_bf16(f);
+  }
+}
+
+// random 4-bit codes and absmax ~ U[0.5, 1.5) / 32
+__global__ void fill_codes(uint8_t* q, size_t nq, float* am, size_t na) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t x = (uint32_t)i * 2654435761u ^ 0x9e3779b9u;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    q[i] = (uint8_t)(x >> 8);
+  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t x = (uint32_t)i * 2246822519u ^ 0x85ebca6bu;
+    x ^= x >> 15; x *= 2654435761u; x ^= x >> 13;
+    am[i] = (0.5f + (float)(x & 0xffff) / 65536.0f) / 32.0f;
+  }
+}
+// element e = code(e) * absmax[e / 64], high nibble first (the arithmetic of bnb_dequant.hip, blocksize 64)
+__global__ void expand_nf4(const uint8_t* q, const float* am, bf16_t* out, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const unsigned byte = q[e >> 1];
+    const unsigned code = (e & 1) ? (byte & 15) : (byte >> 4);
+    out[e] = f32_to_bf16(kNF4[code] * am[e >> 6]);
   }
 }
 
@@ -116,13 +139,6 @@ int main(int argc, char** argv) {
       ms /= iters;
       tf[pp] = 2.0 * s.M * s.N * s.K / (ms * 1e-3) / 1e12;
     }
-#ifdef FMI_W4_TRACE
-    {
-      long long h[64 * 8];
-      hipMemcpyFromSymbol(h, HIP_SYMBOL(fmi::g_w4_trace), sizeof(h));
-      for (int b : {0, 7, 33}) printf("   w4 trace block %2d (clock64 ticks): prologue %lld  loop %lld  drain %lld  epilogue %lld (sync %lld, staging %lld, stores %lld)\n", b, h[b * 8 + 1] - h[b * 8 + 0], h[b * 8 + 2] - h[b * 8 + 1], h[b * 8 + 3] - h[b * 8 + 2], h[b * 8 + 4] - h[b * 8 + 3], h[b * 8 + 5] - h[b * 8 + 3], h[b * 8 + 6] - h[b * 8 + 5], h[b * 8 + 4] - h[b * 8 + 6]);
-    }
-#endif
     hipMemset(d_mis, 0, 8);
     count_mismatch<<<1024, 256>>>(O, O2, (size_t)s.M * p.ldo * (out_es / 2), d_mis);  // resid: both accumulated the same number of launches
     unsigned long long mis = 0;
@@ -130,6 +146,45 @@ int main(int argc, char** argv) {
     printf("%-18s M=%5d N=%5d K=%5d  tiles %5d  double-buffered %7.1f TF   ping-pong %7.1f TF (%7.1f us)   4-wave %7.1f TF (%7.1f us)   4-wave vs ping-pong mismatching elements %llu%s\n", s.name, s.M, s.N, s.K,
            ((s.M + 255) / 256) * ((s.N + 255) / 256), tf[0], tf[1], 2.0 * s.M * s.N * s.K / tf[1] * 1e-6, tf[2], 2.0 * s.M * s.N * s.K / tf[2] * 1e-6, mis,
            hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
+  }
+  if (getenv("FMI_Q4") && epi_kind != 2) {
+    // ---- fused nf4 dequant-GEMM: random codes + absmax, reference = stand-alone expansion + the dense kernel of the run above
+    uint8_t* Wq;
+    float* am;
+    hipMalloc((void**)&Wq, maxW / 2);
+    hipMalloc((void**)&am, maxW / 64 * 4);
+    fill_codes<<<2048, 256>>>(Wq, maxW / 2, am, maxW / 64);
+    set_gemm_pingpong(true);
+    set_gemm_w4(true);
+    for (auto& s : shapes) {
+      if (s.M < 256) continue;
+      expand_nf4<<<4096, 256>>>(Wq, am, W, (size_t)s.N * s.K);
+      GemmProblem p{};
+      p.A = A, p.W = W, p.out = O2, p.M = s.M, p.N = s.N, p.K = s.K, p.lda = s.K, p.ldw = s.K, p.ldo = s.N, p.epi = epi_kind == 1 ? EPI_GELU_BF16 : EPI_STORE_BF16, p.alpha = 1.f;
+      if (epi_kind) p.bias = bias;
+      GemmProblem q = p;
+      q.out = O, q.W = nullptr, q.Wq = Wq, q.absmax = am, q.q_blocksize = 64, q.q_type = 2;
+      double us[2];
+      for (int arm = 0; arm < 2; ++arm) {
+        GemmProblem& r = arm ? q : p;
+        for (int i = 0; i < 2; ++i) launch_gemm(&r, 1, nullptr);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, nullptr);
+        for (int i = 0; i < iters; ++i) launch_gemm(&r, 1, nullptr);
+        hipEventRecord(e1, nullptr);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        us[arm] = ms / iters * 1e3;
+      }
+      hipMemset(d_mis, 0, 8);
+      count_mismatch<<<1024, 256>>>(O, O2, (size_t)s.M * s.N, d_mis);
+      unsigned long long mis = 0;
+      hipMemcpy(&mis, d_mis, 8, hipMemcpyDeviceToHost);
+      const double fl = 2.0 * s.M * s.N * s.K;
+      printf("nf4 %-18s M=%5d N=%5d K=%5d  dense(on expanded W) %7.1f us %7.1f TF   fused nf4 %7.1f us %7.1f TF  (%.2fx)   mismatching elements %llu%s\n", s.name, s.M, s.N, s.K,
+             us[0], fl / us[0] * 1e-6, us[1], fl / us[1] * 1e-6, us[0] / us[1], mis, hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
+    }
   }
   return 0;
 }
