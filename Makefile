@@ -15,7 +15,7 @@ lib: $(LIB)
 oracle:
 	$(MAKE) -C oracle -s
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h include/flux_mi355x.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h include/flux_mi355x.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

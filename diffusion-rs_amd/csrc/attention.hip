@@ -22,6 +22,7 @@
 //     address so the ds_read_b128 operand reads are bank-conflict free.
 //   * Online softmax in the exp2 domain with deferred rescale (skip the O rescale while the row
 //     max grows by < THR; P stays bounded by 2^THR, cdna guide T13).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -36,9 +37,7 @@ constexpr int ATT_THREADS = 512;
 constexpr int ATT_QBLK = 256;  // query rows per workgroup
 constexpr int ATT_KV = 64;     // kv rows per tile
 constexpr int HD = 128;
-#ifndef ATT_PF
-#define ATT_PF 4  // operand reads in flight in the ping-pong kernel's MFMA phase (4/6/8 measured within 2 %)
-#endif
+constexpr int ATT_PF = 4;  // operand reads in flight in the ping-pong kernel's MFMA phase (4/6/8 measured within 2 %)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -139,21 +138,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
   // double-buffered rings: at iteration t the K ring holds tiles t+1 / t+2, the Vt ring t / t+1.
   auto body = [&](int t, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
     dma_barrier();  // K(t+1), Vt(t) landed; every wave finished iteration t-1
-#ifndef FMI_ATT_DMA_AFTER_QK
     if (t + 2 < ntiles) stage_k(t + 2, t & 1);
     if (t + 1 < ntiles) stage_v(t + 1, (t + 1) & 1);
-#endif
-#ifdef FMI_ATT_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
     if (t + 1 < ntiles) qk(sn, (t + 1) & 1);
-#ifdef FMI_ATT_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef FMI_ATT_DMA_AFTER_QK
-    if (t + 2 < ntiles) stage_k(t + 2, t & 1);
-    if (t + 1 < ntiles) stage_v(t + 1, (t + 1) & 1);
-#endif
     // ---- mask the ragged tail (kv >= Lk); kv_local = 32u + (r&3) + 8(r>>2) + 4hl
     if ((t + 1) * ATT_KV > Lk) {
       const int kvb = t * ATT_KV + 4 * hl;
@@ -201,9 +188,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
     l_run += lsum;
     // ---- Oᵀ += Vᵀ Pᵀ : k-slot (hl,e) of step (u,w) <-> Vt position 32u + 16w + 8hl + e
     const char* vl = smem + 32768 + (t & 1) * 16384;
-#ifdef FMI_ATT_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
@@ -212,9 +196,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
         ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c], ot[dt], 0, 0, 0);
       }
     }
-#ifdef FMI_ATT_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   };
 
   f32x16 sa[2], sb[2];
@@ -271,12 +252,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
 //          the wave issued before V(t) has landed; the closing barrier publishes it)
 // so on every SIMD one wave keeps the VALU busy while the other keeps the matrix pipe busy.
 // K and Vt live in 4-deep LDS rings (128 KiB): a piece has >= 4 slots (two tile periods) to land.
-#ifdef ATT_PP_TRACE
-__device__ long long g_att_trace[8 * 64];
-#define ATT_TR(k) do { if (blockIdx.x == 0 && lane == 0 && t >= 16 && t < 24) g_att_trace[wave * 64 + (t - 16) * 8 + (k)] = clock64(); } while (0)
-#else
-#define ATT_TR(k) do {} while (0)
-#endif
 // QK8 = true (fp8 mode of the model): Q and K arrive as OCP e4m3 bytes (rows of 128 B, static scales folded
 // into scale_log2e by the caller) and S^T = K Q^T runs on v_mfma_f32_32x32x64_f8f6f4: 4 MFMAs of 64 clocks per tile instead
 // of 16 of 32.  The K tile is 64 x 128 B (one DMA piece per wave, 16-byte slots XOR-swizzled with row & 7); a lane's
@@ -411,12 +386,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
   bf16x8_t pf[4];
   auto body = [&](int t, auto more_tag) {
     constexpr bool MORE = decltype(more_tag)::value;  // a tile t+1 exists
-    ATT_TR(0);
     // ================= V(t): DMA issue + online softmax of S(t) -> pf
-#ifndef ATT_PP_NO_DMA
     if (t + 3 < ntiles) stage_k(t + 3);
     if (t + 2 < ntiles) stage_v(t + 2);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if ((t + 1) * ATT_KV > Lk) {
       const int kvb = t * ATT_KV + 4 * hl;
@@ -426,7 +398,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
         for (int r = 0; r < 16; ++r)
           if (kvb + 32 * u + (r & 3) + 8 * (r >> 2) >= Lk) sc[u][r] = -1e30f;
     }
-#ifndef ATT_PP_NO_V
     float pmax = sc[0][0];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -461,16 +432,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
       __builtin_memcpy(&pf[2 * u + 1], &hi, 16);
     }
     l_run += lsum;
-    ATT_TR(1);
-#else
-#pragma unroll
-    for (int c = 0; c < 4; ++c) pf[c] = __builtin_bit_cast(bf16x8_t, make_uint4(__float_as_uint(sc[c >> 1][0]), 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
-#endif
     slot_barrier();
-#ifdef ATT_PP_SETPRIO
-    __builtin_amdgcn_s_setprio(ATT_PP_SETPRIO);  // the MFMA wave wins issue arbitration against the softmax wave of its SIMD
-#endif
-    ATT_TR(2);
     // ================= M(t): PV(t) (steps 0..15), then QK^T(t+1) (steps 16..31) into sc
     {
       const char* vl = smem + VT_RING + (t & 3) * 16384;
@@ -500,11 +462,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
       const uint32_t vbase = (uint32_t)(uintptr_t)(lds_void*)vl, kbase = (uint32_t)(uintptr_t)(lds_void*)kl;
       auto load = [&](int i, bf16x8_t& dst) {  // i is a compile-time constant after unrolling
         const uint32_t a = i < 16 ? vbase + (i & 3) * 32 * 128 + (v_off0 ^ ((i >> 2) << 5)) : kbase + ((i - 16) & 1) * 32 * 256 + (k_off0 ^ (((i - 16) >> 1) << 5));
-#ifndef ATT_PP_NO_LDS
         asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(a));
-#else
-        dst = __builtin_bit_cast(bf16x8_t, make_uint4(a, 0x3f803f80u, 0x3f803f80u, a));  // ablation: no LDS traffic
-#endif
       };
 #pragma unroll
       for (int i = 0; i < ATT_PF; ++i) load(i, fr[i]);
@@ -523,11 +481,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
           else if (pending == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f));
           else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f));
         }
-#ifdef ATT_PP_NO_MFMA
-        sc[0][i & 15] += __builtin_bit_cast(f32x4, fr[i % ATT_PF])[0];
-        if (i + ATT_PF < NSTEP) load(i + ATT_PF, fr[i % ATT_PF]);
-        continue;
-#endif
         if (i < 16) {
           ot[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % ATT_PF], pf[i >> 2], ot[i & 3], 0, 0, 0);
         } else {
@@ -552,10 +505,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
           for (int u = 0; u < 2; ++u) sc[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kq[u][s2], qq[s2], sc[u], 0, 0, 0, 0, 0, 0);
       }
     }
-    ATT_TR(3);
-#ifdef ATT_PP_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     // everything older than the pieces issued in this tile's V phase must have landed
     if (t + 3 < ntiles) {
       if constexpr (QK8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // K(t+3) is one piece per wave here
@@ -565,9 +514,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ATT_TR(4);
     slot_barrier();
-    ATT_TR(5);
   };
   for (int t = 0; t < ntiles - 1; ++t) body(t, std::true_type{});
   body(ntiles - 1, std::false_type{});
@@ -596,8 +543,18 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
   }
 }
 
+}  // namespace fmi
+#include "attention_w4.h"
+namespace fmi {
+
 static bool g_att_pingpong = true;
 void set_attention_pingpong(bool on) { g_att_pingpong = on; }
+// bf16 operands: the one-wave-per-SIMD kernel (attention_w4.h); FMI_ATT_W4=0 / set_attention_w4(false) -> the 8-wave ping-pong kernel
+static bool g_att_w4 = [] {
+  const char* e = getenv("FMI_ATT_W4");
+  return e ? atoi(e) != 0 : true;
+}();
+void set_attention_w4(bool on) { g_att_w4 = on; }
 
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
                         int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8) {
@@ -610,6 +567,11 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
       hipLaunchKernelGGL((attention_pp_kernel<0, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
     else
       hipLaunchKernelGGL((attention_pp_kernel<96, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+  } else if (g_att_w4 && Lk > ATT_KV) {  // (a single KV tile has no steady state to pipeline: the 8-wave kernel serves it)
+    if (rescale_thr_x16 == 0)
+      hipLaunchKernelGGL((attention_w4_kernel<0>), grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+    else
+      hipLaunchKernelGGL((attention_w4_kernel<96>), grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
   } else if (g_att_pingpong) {
     if (rescale_thr_x16 == 0)
       hipLaunchKernelGGL((attention_pp_kernel<0, false>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);

@@ -214,6 +214,15 @@ extern "C" int fmi_sdpa_fp8qk(const void* q, const void* k, const void* v, void*
   return rc;
 }
 
+// Process-wide kernel selection for bf16 attention (test / benchmark hook; all three give bit-identical results):
+// 2 (default) = one wave per SIMD (attention_w4.h), 1 = 8-wave ping-pong, 0 = 8-wave single barrier.
+extern "C" int fmi_set_attention_kernel(int kind) {
+  if (kind < 0 || kind > 2) return fail(FMI_ERR_INVALID, "set_attention_kernel: kind must be 0, 1 or 2");
+  set_attention_w4(kind == 2);
+  set_attention_pingpong(kind >= 1);
+  return FMI_OK;
+}
+
 extern "C" int fmi_layernorm_mod(const float* x, const float* scale, const float* shift, void* out_bf16, int rows, int D, float eps, void* stream) {
   if (!x || !out_bf16) return fail(FMI_ERR_INVALID, "layernorm_mod: null pointer");
   return launch_layernorm_mod(x, scale, shift, 0, 0, (bf16_t*)out_bf16, rows, D, eps, (hipStream_t)stream);

@@ -200,7 +200,8 @@ struct AttnOut {
 // qk_fp8 != 0: q and k are e4m3 bytes (B,H,L,128), QK^T runs on the fp8 MFMA (scale must already hold 1 / (q scale * k scale))
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
                         int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8 = 0);
-void set_attention_pingpong(bool on);  // ping-pong kernel (default) or the single-barrier one
+void set_attention_pingpong(bool on);  // 8-wave kernels: ping-pong (default) or the single-barrier one
+void set_attention_w4(bool on);        // bf16 operands: one-wave-per-SIMD kernel (default) or the 8-wave ones
 // flash attention, d = 128.  q,k: (BH, L, 128) bf16; vt: (BH, 128, Lpad) bf16 with the kv axis
 // permuted inside each group of 16 (see attention.hip); out token-major (B, L, H*128) or (BH,L,128)
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int B, int H,

@@ -474,12 +474,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc
   }
   gemm_epilogue_impl<NJ, WN, ACT>(P, acc, smem, m0, n0, wave, lane);
 }
-// the activation kind a launch group needs (all problems of a group must agree, else the run-time kind 3)
+// the activation kind a launch group needs; all problems of a group must agree (-1 otherwise: the per-kind kernel
+// instantiations apply ONE activation, a mixed group would silently lose a GELU — launch_gemm rejects it)
 inline int epilogue_kind(const GemmProblem* p, int n) {
   auto kind = [](int epi) { return (epi == EPI_STORE_BF16 || epi == EPI_RESID_GATE_F32) ? 0 : epi == EPI_GELU_BF16 ? 1 : epi == EPI_GELU_FROM_COL ? 2 : 3; };
   const int k = kind(p[0].epi);
   for (int i = 1; i < n; ++i)
-    if (kind(p[i].epi) != k) return 3;
+    if (kind(p[i].epi) != k) return -1;
   return k;
 }
 
@@ -1171,6 +1172,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
       hipLaunchKernelGGL((gemm_bf16_kernel<MODE, 2>), grid, blk, 0, stream, b);             \
   } while (0)
   const int act = epilogue_kind(probs, nprob);
+  if (act < 0) return fail(FMI_ERR_INVALID, "launch_gemm: the problems of a grouped launch must share the activation kind");
   // 4-wave kernel: its K loop is 7-10 % faster, its two-round epilogue slower — measured break-even (tools/gemm_bench,
   // FMI_EPI=store|gelu|resid on the FLUX shapes): the f32 residual read-modify-write launches at every K (proj -5 %,
   // mlp2 -10 %, linear2 -7 %), everything else from K = 8192 on (mlp1 + GELU at K = 3072 is a wash).
@@ -1179,7 +1181,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   // 4-bit weights: the one-wave-per-SIMD fused kernel from g_w4q_min_rows rows on (below it the GEMM is bound by the packed
   // weight stream and the two-workgroups-per-CU kernel with the VGPR expand hides latency better)
   bool w4q_ok = quant;
-  for (int i = 0; i < nprob; ++i) {
+  for (int i = 0; quant && i < nprob; ++i) {
     const GemmProblem& p = probs[i];
     const int kb = p.q_blocksize / BK;  // K tiles per absmax block
     if (p.qk_qh || p.M < g_w4q_min_rows || p.K % p.q_blocksize || (kb & (kb - 1)) || (int64_t)p.N * p.K / 2 >= (1ll << 32)) w4q_ok = false;

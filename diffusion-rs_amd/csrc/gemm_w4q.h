@@ -12,13 +12,15 @@
 // 32x32x16 MFMA (MI355X_MICROARCH.md, per-instruction table), so the expansion is cut into micro-steps and one
 // micro-step rides in each MFMA gap:
 //   * a lane owns one W row of the tile: 64 weights per K tile = 8 "units" of one packed dword;
-//   * the 16 code values sit in LDS as f32 (64 B, one bank each: conflict-free, broadcast); per MFMA gap one
-//     nibble is turned into a table address (v_bfe on the pre-shifted word) and looked up (ds_read_b32); eight gaps
-//     later the value is multiplied by the row's absmax, pairs are rounded to bf16 (v_cvt_pk_bf16_f32) and every
-//     eighth gap a 16-byte piece of the row goes to the W ring (ds_write_b128 at slot u ^ ((row >> 1) & 7));
+//   * a 256-entry table in LDS maps a packed BYTE to the f32 values of its two codes (2 KiB); every second MFMA gap
+//     one byte is turned into a table address (shift + and) and looked up with ONE ds_read_b64 — with one wave per
+//     SIMD the LDS pipe retires narrow reads at a fraction of its rate, so the number of lookups, not their bank
+//     conflicts, is what counts (a 16-entry conflict-free table read per nibble ran 0.8x the dense kernel; r02 bench);
+//     eight gaps later the two values are multiplied by the row's absmax and rounded to bf16 (v_cvt_pk_bf16_f32), and
+//     every eighth gap a 16-byte piece of the row goes to the W ring (ds_write_b128 at slot u ^ ((row >> 1) & 7));
 //   * the unit stream is a modulo-8 pipeline that runs across K tiles: the group that looks up unit u consumes unit
 //     u-1, the first lookups of tile t+2 ride next to the last writes of tile t+1, so every group is the same.
-// LDS: 256 B (table) + A ring 2 x 32 KiB + W ring 2 x 32 KiB.  Per K tile t the order is
+// LDS: 2 KiB (table) + A ring 2 x 32 KiB + W ring 2 x 32 KiB.  Per K tile t the order is
 //   G0..G4 (steps 0, 1, first half of 2): lookups of W(t+1) units 3..7, writes of units 2..6; G0 also issues the packed
 //       loads of W(t+2) into a landing register set; G4 waits for them (and thereby for the A(t+1) DMA) and swaps sets;
 //   G5: the last unit of W(t+1) is written early in the group, then lgkmcnt / s_barrier: tile t's slots are free,
@@ -31,7 +33,7 @@
 
 namespace fmi {
 
-constexpr int W4Q_LUT_BYTES = 256;
+constexpr int W4Q_LUT_BYTES = 2048;  // 256 byte values x {value of the high nibble, value of the low nibble} f32
 
 template <int ACT>
 __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const GemmBatch batch) {
@@ -71,9 +73,10 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const GemmBatch
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
   if (lds0 != 0) __builtin_trap();  // the table lookups address LDS byte 0 directly (smem is the only __shared__ object)
-  if (tid < 16) {                   // code -> value table; fp4: value * sign of the tree in dequant.cu:12-37 (sign is exact)
+  {  // packed byte -> the two code values, weight order (high nibble first); fp4: value * sign of the tree in dequant.cu:12-37
     const float fp4[8] = {0.0f, 5.208333333e-03f, 0.66666667f, 1.0f, 0.33333333f, 0.5f, 0.16666667f, 0.25f};
-    reinterpret_cast<float*>(smem)[tid] = P.q_type == 2 ? kNF4[tid] : ((tid & 8) ? -fp4[tid & 7] : fp4[tid & 7]);
+    auto val = [&](int c) { return P.q_type == 2 ? kNF4[c] : ((c & 8) ? -fp4[c & 7] : fp4[c & 7]); };
+    reinterpret_cast<float2*>(smem)[tid] = make_float2(val(tid >> 4), val(tid & 15));  // 256 threads, 256 entries
   }
 
   // ---- A operand: LDS-DMA pieces of this wave (1-KiB chunks wave*8 + i), as gemm_w4_kernel
@@ -121,29 +124,31 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const GemmBatch
   };
 
   // ---- expansion pipeline state
-  float L[2][8];            // table values of the unit being looked up / consumed (set = unit & 1)
-  uint32_t ty = 0, tz = 0;  // the unit's word pre-shifted and masked so that each byte is a table address
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 L[2][4];            // table values of the unit being looked up / consumed (set = unit & 1): pair jp = weights 2jp, 2jp+1
+  uint32_t tw = 0, tw3 = 0;  // the unit's word shifted left by 3: byte k (masked per lookup) is a table address; byte 3 apart (its top bits fall off)
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
   u32x4 pk;                 // the unit's 8 bf16 on their way to LDS
-  // weight 2k of a unit is the HIGH nibble of byte k, weight 2k+1 the low one (dequant.cu:142-151)
-  // (plain int parameters, constant after inlining: a generic lambda cannot name the register arrays in asm operands)
-  auto lookup = [&](int u, int j) {
-    if (j == 0) {
-      ty = (cur[u] << 2) & 0x3c3c3c3cu;
-      tz = (cur[u] >> 2) & 0x3c3c3c3cu;
+  // byte k of a unit holds weights 2k (high nibble) and 2k+1 (low nibble) (dequant.cu:142-151).
+  // (plain int parameters, constant after inlining: a generic lambda cannot name the register arrays in asm operands.)
+  auto lookup = [&](int u, int jp) {
+    if (jp == 0) {  // (both taken now: group G4 swaps `cur` to the next tile right after its first lookup)
+      tw = cur[u] << 3;
+      tw3 = (cur[u] >> 21) & 0x7f8u;
     }
-    const uint32_t a = (((j & 1) ? ty : tz) >> (8 * (j >> 1))) & 0xffu;
-    asm volatile("ds_read_b32 %0, %1" : "=v"(L[u & 1][j]) : "v"(a));
+    const uint32_t a = jp == 0 ? (tw & 0x7f8u) : jp == 3 ? tw3 : ((tw >> (8 * jp)) & 0x7f8u);
+    asm volatile("ds_read_b64 %0, %1" : "=v"(L[u & 1][jp]) : "v"(a));
   };
-#define FMI_W4Q_LGKM(N, a, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a), "+v"(b))
   // pair jp of unit u: two values * absmax -> one dword of bf16; after the fourth pair the 16-byte piece is stored
   auto consume_pair = [&](int u, int jp, int slot) {
-    pk[jp] = pack_bf16x2(L[u & 1][2 * jp] * am_c, L[u & 1][2 * jp + 1] * am_c);
+    pk[jp] = pack_bf16x2(L[u & 1][jp][0] * am_c, L[u & 1][jp][1] * am_c);
     if (jp == 3) {
       const uint32_t ad = (w_wr + slot * TILE) ^ (uint32_t)(u << 4);
       asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(pk) : "memory");
     }
   };
+  // wait until at most N LDS operations are pending, tied to the two pairs (h = 0: pairs 0, 1; h = 1: pairs 2, 3) it releases
+#define FMI_W4Q_LGKM(N, c, h) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(L[c][2 * (h)]), "+v"(L[c][2 * (h) + 1]))
 
   // ---- prologue: A(0), A(1) by DMA; W(0) and units 0, 1 of W(1) expanded with nothing to overlap
   const int k1 = min(1, klast);
@@ -154,9 +159,14 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const GemmBatch
   __syncthreads();  // table visible
   auto serial_unit = [&](int u, int slot) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) lookup(u, j);
-    const int b = u & 1;
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(L[b][0]), "+v"(L[b][1]), "+v"(L[b][2]), "+v"(L[b][3]), "+v"(L[b][4]), "+v"(L[b][5]), "+v"(L[b][6]), "+v"(L[b][7]));
+    for (int jp = 0; jp < 4; ++jp) lookup(u, jp);
+    if (u & 1) {
+      FMI_W4Q_LGKM(0, 1, 0);
+      FMI_W4Q_LGKM(0, 1, 1);
+    } else {
+      FMI_W4Q_LGKM(0, 0, 0);
+      FMI_W4Q_LGKM(0, 0, 1);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int jp = 0; jp < 4; ++jp) consume_pair(u, jp, slot);
@@ -176,11 +186,10 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const GemmBatch
   serial_unit(0, 1), serial_unit(1, 1);
   // unit 2 of W(1): looked up, not yet consumed — the state group G0 of the first K tile expects
 #pragma unroll
-  for (int j = 0; j < 8; ++j) lookup(2, j);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-               : "+v"(L[0][0]), "+v"(L[0][1]), "+v"(L[0][2]), "+v"(L[0][3]), "+v"(L[0][4]), "+v"(L[0][5]), "+v"(L[0][6]), "+v"(L[0][7])
-               :
-               : "memory");
+  for (int jp = 0; jp < 4; ++jp) lookup(2, jp);
+  FMI_W4Q_LGKM(0, 0, 0);  // unit 2 -> value set 0
+  FMI_W4Q_LGKM(0, 0, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();  // A(0), A(1), W(0) published
   __builtin_amdgcn_sched_barrier(0);
@@ -232,35 +241,42 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const GemmBatch
     const int step = G >> 1, q = (G & 1) * 8 + J, b = step & 1;
     const int U = (G + 3) & 7;   // unit looked up in this group
     const int UC = (G + 2) & 7;  // unit consumed in this group
+    // ---- consume unit UC (W(t+1) through G5, W(t+2) from G6 on) — first in the gap, so that its waits only count
+    // operations of earlier gaps.  LDS operations retire in order; a group issues its 4 lookups in gaps 0, 2, 4, 6.
+    const int wslot = (G >= 6 ? t : t + 1) & 1;
+    if (G == 6 && J == 0) am_c = cur_am;
+    if (G == 5) {
+      // the last unit of W(t+1) early in the group, so that its store is old when the barrier waits for it
+      if (J == 1) FMI_W4Q_LGKM(3, 1, 0);  // (unit 7 -> value set 1) pairs 0, 1: the lookups of G4 gaps 4, 6 and G5 gap 0 are younger
+      if (J == 1) consume_pair(UC, 0, wslot);
+      if (J == 2) consume_pair(UC, 1, wslot);
+      if (J == 3) FMI_W4Q_LGKM(2, 1, 1);  // pairs 2, 3: the lookups of G5 gaps 0, 2 are younger
+      if (J == 3) consume_pair(UC, 2, wslot);
+      if (J == 4) consume_pair(UC, 3, wslot);
+    } else {
+      // pairs 0, 1 were looked up in gaps 0, 2 of the previous group (2 younger lookups: its gaps 4, 6); pairs 2, 3 in its
+      // gaps 4, 6 (2 younger lookups: this group's gaps 0, 2)
+      if (J == 0 && (UC & 1)) FMI_W4Q_LGKM(2, 1, 0);
+      if (J == 0 && !(UC & 1)) FMI_W4Q_LGKM(2, 0, 0);
+      if (J == 4 && (UC & 1)) FMI_W4Q_LGKM(2, 1, 1);
+      if (J == 4 && !(UC & 1)) FMI_W4Q_LGKM(2, 0, 1);
+      if (J == 1) consume_pair(UC, 0, wslot);
+      if (J == 2) consume_pair(UC, 1, wslot);
+      if (J == 5) consume_pair(UC, 2, wslot);
+      if (J == 6) consume_pair(UC, 3, wslot);
+    }
     if (G % 2 == 0 && J == 0) {
-      // this step's fragments were read in the first half of the previous step; the second half issued 8 lookups and a store
-      if (b) FMI_W4Q_FRAG_WAIT(8, 1);
-      else FMI_W4Q_FRAG_WAIT(8, 0);
+      // this step's fragments were read in the first half of the previous step; the second half issued 4 lookups and a store
+      if (b) FMI_W4Q_FRAG_WAIT(4, 1);
+      else FMI_W4Q_FRAG_WAIT(4, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     acc[q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[b][q & 3]), __builtin_bit_cast(bf16x8_t, xf[b][q >> 2]),
                                                                  acc[q >> 2][q & 3], 0, 0, 0);
     // ---- fragment reads of the next k-step (during step 3: step 0 of tile t + 1; addresses rebased after the barrier)
     if (G % 2 == 0) read_frag((step + 1) & 3, J);
-    // ---- consume unit UC: W(t+1) through G5, W(t+2) from G6 on
-    const int wslot = (G >= 6 ? t : t + 1) & 1;
-    if (G == 6 && J == 0) am_c = cur_am;
-    const int c = UC & 1;
-    if (G == 5) {
-      // the last unit of W(t+1): one pair per gap, so that its store is old when the barrier waits for it.
-      // Lookups issued after the younger value of pair J: 6 - 2J in G4 and J in G5.
-      if (J == 0) FMI_W4Q_LGKM(6, L[c][0], L[c][1]);
-      if (J == 1) FMI_W4Q_LGKM(5, L[c][2], L[c][3]);
-      if (J == 2) FMI_W4Q_LGKM(4, L[c][4], L[c][5]);
-      if (J == 3) FMI_W4Q_LGKM(3, L[c][6], L[c][7]);
-      if (J < 4) consume_pair(UC, J, wslot);
-    } else if (J % 2 == 0) {
-      FMI_W4Q_LGKM(6, L[c][J], L[c][J + 1]);  // at least 6 lookups were issued after the pair's younger value
-    } else {
-      consume_pair(UC, J >> 1, wslot);
-    }
-    // ---- look up nibble J of unit U
-    lookup(U, J);
+    // ---- look up byte J / 2 of unit U
+    if (J % 2 == 0) lookup(U, J >> 1);
     // ---- memory side
     if (G == 0 && J >= 1 && J <= 3) load_w(min(t + 2, klast), J - 1);  // packed W(t+2) -> landing registers
     if (G == 4 && J == 1) {
@@ -270,9 +286,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const GemmBatch
     }
     if (G >= 6 && (J & 1)) dma_a(min(t + 2, klast), t & 1, (G - 6) * 4 + (J >> 1));  // A slot t & 1: free since the barrier
     if (G == 5 && J == 7) {
-      // this wave's reads of tile t (issued by G4) and its stores of W(t+1) (the last one in gap 3) are all older
-      // than the newest 4 LDS operations (the lookups of gaps 4..7)
-      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      // this wave's reads of tile t (issued by G4) and its stores of W(t+1) (the last one in gap 4, ahead of that gap's
+      // lookup) are all older than the newest 2 LDS operations (the lookups of gaps 4 and 6)
+      asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);

@@ -337,7 +337,7 @@ int fmi_postprocess_u8(const float* image, int B, int C, int H, int W, int inter
  * (the reference's RNG is unseedable; this is the explicit-seed extension).
  * Elements 4q..4q+3 of sample b come from the four words of philox(counter = (q lo, q hi, s lo, s hi),
  * key = (seed lo, seed hi)), s = first_sample + b: words (0,1) and (2,3) each feed one Box-Muller pair,
- * u = ((word >> 8) + 0.5) / 2^24, z = sqrt(-2 ln u1) * (cos, sin)(2 pi u2).  Replaces get_noise
+ * u = f32(f32(word >> 8) + 0.5f) * 2^-24 (f32 roundings included), z = sqrt(-2 ln u1) * (cos, sin)(2 pi u2).  Replaces get_noise
  * (pipelines/flux/sampling.rs:5-14). */
 int fmi_randn(float* out, int64_t n_per_sample, int B, uint64_t seed, uint64_t first_sample,
               void* stream);
@@ -390,6 +390,9 @@ int fmi_linear_fp8(const void* x, const uint8_t* wq, const float* w_scale, const
  * == backend::ops::sdpa fallback (ops.rs:247-262) without materialising the scores. */
 int fmi_sdpa_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
                   int Lk, int d, float scale, int out_token_major, void* stream);
+/* Process-wide choice of the bf16 attention kernel (test / benchmark hook; the three are bit-identical):
+ * 2 (default) one wave per SIMD (attention_w4.h), 1 the 8-wave ping-pong kernel, 0 the 8-wave single-barrier kernel. */
+int fmi_set_attention_kernel(int kind);
 /* Same with q and k as OCP e4m3 bytes (B,H,L,128): QK^T on the fp8 MFMA, softmax / P / V in f32 / bf16 as above.
  * `scale` must include 1 / (q scale * k scale).  The fp8-mode attention of fmi_flux_* (fmi_flux_set_fp8_attention). */
 int fmi_sdpa_fp8qk(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,

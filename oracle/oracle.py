@@ -345,16 +345,19 @@ def philox_u32(n_per_sample, B, seed, first_sample=0):
 
 
 def randn(n_per_sample, B, seed, first_sample=0):
-    """N(0,1) f32 (B, n_per_sample): per counter, words (0,1) and (2,3) each give a Box-Muller pair
-    u = ((w >> 8) + 0.5) / 2^24 (exact in f32), z = sqrt(-2 ln u1) * (cos, sin)(2 pi u2) — evaluated here in
-    f64 and rounded once, so the device's f32 libm results are expected within a few ulp (stated in the test)."""
+    """N(0,1) f32 (B, n_per_sample): per counter, words (0,1) and (2,3) each give a Box-Muller pair.
+    u = f32(f32(w >> 8) + 0.5f) * 2^-24 with the device's f32 roundings (for w >> 8 >= 2^23 the + 0.5 rounds to even:
+    restated here in numpy float32, so u is bit-identical to the device's); z = sqrt(-2 ln u1) * (cos, sin)(2 pi u2) is
+    then evaluated in f64 and rounded once — the device's f32 libm results are expected within a few ulp of it (bound
+    stated in tests/test_gpu_philox.py)."""
     quads = (n_per_sample + 3) // 4
     w = philox_u32(quads * 4, B, seed, first_sample).reshape(B, quads, 4)
-    u = ((w >> np.uint32(8)).astype(np.float64) + 0.5) / 16777216.0
+    u32 = ((w >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    u = u32.astype(np.float64)
     out = np.empty((B, quads, 4), np.float64)
     for p in range(2):
         rad = np.sqrt(-2.0 * np.log(u[..., 2 * p]))
-        ang = np.float64(np.float32(6.283185307179586)) * u[..., 2 * p + 1]  # the device multiplies by the f32 constant
+        ang = (np.float32(6.283185307179586) * u32[..., 2 * p + 1]).astype(np.float64)  # the device's f32 product
         out[..., 2 * p] = rad * np.cos(ang)
         out[..., 2 * p + 1] = rad * np.sin(ang)
     return out.reshape(B, quads * 4)[:, :n_per_sample].astype(np.float32)

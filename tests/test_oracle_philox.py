@@ -36,7 +36,8 @@ def test_randn_moments_and_box_muller_pairs():
     assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
     assert np.isfinite(z).all() and float(np.abs(z).max()) < 6.0  # u1 >= 2^-25 -> |z| <= sqrt(50 ln 2)
     w = orc.philox_u32(4, 1, 7)[0]
-    u1, u2 = ((int(w[0]) >> 8) + 0.5) / 2**24, ((int(w[1]) >> 8) + 0.5) / 2**24
+    f = lambda x: float((np.float32(int(x) >> 8) + np.float32(0.5)) * np.float32(2.0 ** -24))  # the device's f32 roundings
+    u1, u2 = f(w[0]), f(w[1])
     zz = orc.randn(4, 1, 7)[0]
-    ang = float(np.float32(6.283185307179586)) * u2
+    ang = float(np.float32(6.283185307179586) * np.float32(u2))
     np.testing.assert_allclose(zz[:2], [np.sqrt(-2 * np.log(u1)) * np.cos(ang), np.sqrt(-2 * np.log(u1)) * np.sin(ang)], rtol=1e-6)

@@ -1,7 +1,9 @@
 // tools/attn_bench.hip — micro-benchmark of the fused attention kernel at the FLUX C2 shape
 // (B=1, H=24, L=4608, d=128) on random bf16 data.  Build with extra -D flags to try variants.
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../diffusion-rs_amd/csrc/attention.hip"
@@ -27,7 +29,7 @@ __global__ void fill_kernel(bf16_t* p, size_t n, uint32_t seed) {
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 20;
   struct Shape { int B, H, L; };
-  std::vector<Shape> shapes = {{1, 24, 4608}, {1, 24, 4112}, {2, 24, 4608}};
+  std::vector<Shape> shapes = {{1, 24, 4608}, {1, 24, 4112}, {2, 24, 4608}, {1, 4, 1000}, {1, 2, 64}, {1, 3, 200}, {1, 2, 128}, {1, 2, 192}, {1, 1, 116}, {1, 2, 127}, {1, 2, 129}, {1, 2, 512}};  // + ragged / tiny shapes for the bit-identity check
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -41,10 +43,13 @@ int main(int argc, char** argv) {
     const float scale = 0.08838834764f;
     bf16_t* o2;
     hipMalloc((void**)&o2, n * 2);
-    double tf[2];
-    for (int pp = 0; pp < 2; ++pp) {  // single-barrier kernel, then the ping-pong kernel
+    bf16_t* o3;
+    hipMalloc((void**)&o3, n * 2);
+    double tf[3];
+    for (int pp = 0; pp < 3; ++pp) {  // single-barrier kernel, the ping-pong kernel, the one-wave-per-SIMD kernel
       set_attention_pingpong(pp != 0);
-      bf16_t* dst = pp ? o2 : o;
+      set_attention_w4(pp == 2);
+      bf16_t* dst = pp == 0 ? o : pp == 1 ? o2 : o3;
       for (int i = 0; i < 3; ++i) launch_attention(q, k, vt, dst, s.B, s.H, s.L, s.L, Lpad, scale, 1, nullptr);
       hipDeviceSynchronize();
       hipEventRecord(e0, nullptr);
@@ -56,27 +61,38 @@ int main(int argc, char** argv) {
       ms /= iters;
       tf[pp] = 4.0 * s.B * s.H * (double)s.L * s.L * 128 / (ms * 1e-3) / 1e12;
     }
-    std::vector<uint16_t> ha(n), hb(n);
+    std::vector<uint16_t> ha(n), hb(n), hc(n);
     hipMemcpy(ha.data(), o, n * 2, hipMemcpyDeviceToHost);
     hipMemcpy(hb.data(), o2, n * 2, hipMemcpyDeviceToHost);
-    size_t mis = 0;
-    for (size_t i = 0; i < n; ++i) mis += ha[i] != hb[i];
-    printf("B=%d H=%d L=%d  single-barrier %7.1f TF   ping-pong %7.1f TF   mismatching elements %zu%s\n", s.B, s.H, s.L, tf[0], tf[1], mis,
-           hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
-    hipFree(o2);
-#ifdef ATT_PP_TRACE
-    {
-      long long tr[8 * 64];
-      hipMemcpyFromSymbol(tr, HIP_SYMBOL(fmi::g_att_trace), sizeof(tr));
-      for (int w : {0, 4}) {
-        printf("wave %d (clock64 deltas): per tile [V softmax | wait barrier | M issue | vmcnt wait | barrier wait]  and tile period\n", w);
-        for (int t = 0; t < 7; ++t) {
-          const long long* a = tr + w * 64 + t * 8;
-          printf("  tile %2d: V %5lld  b %5lld  M %5lld  vm %5lld  b %5lld   period %5lld\n", 16 + t, a[1] - a[0], a[2] - a[1], a[3] - a[2], a[4] - a[3], a[5] - a[4], a[8] - a[0]);
-        }
+    hipMemcpy(hc.data(), o3, n * 2, hipMemcpyDeviceToHost);
+    size_t mis = 0, mis3 = 0, first = n;
+    double maxd = 0;
+    auto tof = [](uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return (double)f; };
+    for (size_t i = 0; i < n; ++i) {
+      mis += ha[i] != hb[i];
+      if (hb[i] != hc[i]) {
+        ++mis3;
+        if (first == n) first = i;
+        maxd = std::max(maxd, std::fabs(tof(hb[i]) - tof(hc[i])));
       }
     }
-#endif
+    if (mis3) {  // token-major output (B, L, H*128): where does the one-wave kernel first differ?
+      const size_t row = first / ((size_t)s.H * 128), col = first % ((size_t)s.H * 128);
+      size_t rows_bad = 0, last_row = 0;
+      for (size_t r = 0; r < (size_t)s.B * s.L; ++r) {
+        bool bad = false;
+        for (size_t c = 0; c < (size_t)s.H * 128 && !bad; ++c) bad = hb[r * s.H * 128 + c] != hc[r * s.H * 128 + c];
+        rows_bad += bad;
+        if (bad) last_row = r;
+      }
+      printf("   one-wave vs pp: max |diff| %.4g, first at token %zu head %zu d %zu (pp %.5g, one-wave %.5g); %zu of %zu token rows differ, last %zu\n", maxd, row,
+             col / 128, col % 128, tof(hb[first]), tof(hc[first]), rows_bad, (size_t)s.B * s.L, last_row);
+    }
+    const double fl = 4.0 * s.B * s.H * (double)s.L * s.L * 128;
+    printf("B=%d H=%d L=%d  single-barrier %7.1f TF   ping-pong %7.1f TF (%6.1f us)   one-wave %7.1f TF (%6.1f us)   mismatching elements: pp vs sb %zu, one-wave vs pp %zu%s\n", s.B,
+           s.H, s.L, tf[0], tf[1], fl / tf[1] * 1e-6, tf[2], fl / tf[2] * 1e-6, mis, mis3, hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
+    hipFree(o2);
+    hipFree(o3);
     hipFree(q); hipFree(k); hipFree(vt); hipFree(o);
   }
   return 0;
