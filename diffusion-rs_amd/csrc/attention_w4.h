@@ -27,6 +27,7 @@
 //   * O leaves through LDS as whole 256-byte rows (16-byte stores, four rows per wave-instruction) instead of
 //     8-byte pieces at a row stride.
 #pragma once
+#include "attention_w4_loop.inc"
 
 namespace fmi {
 
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
   const int hl = lane >> 5, l31 = lane & 31;
   const bf16_t* Kb = K + (int64_t)bh * Lk * HD;
   const bf16_t* Vb = Vt + (int64_t)bh * HD * Lkpad;
-  const int ntiles = (Lk + ATT_KV - 1) / ATT_KV;
+  const int ntiles = (Lk + ATT_KV - 1) / ATT_KV;  // >= 2 (the launcher sends single-tile problems to the 8-wave kernel)
 
   // ---- Q fragments (MFMA B operand): block b, d-step s -> Q[q0 + 32 b + l31][16 s + 8 hl .. + 7]
   typedef __attribute__((ext_vector_type(4))) int frag_t;
@@ -103,13 +104,17 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
   for (int s = 0; s < 8; ++s) k_ad[s] = (l31 * 256 + ((hl ^ (lane & 15)) << 4)) ^ (s << 5);
 #pragma unroll
   for (int c = 0; c < 4; ++c) v_ad[c] = VT_RING + ((l31 * 128 + ((hl ^ ((l31 >> 1) & 7)) << 4)) ^ (c << 5));
-  auto advance_k = [&]() __attribute__((always_inline)) {
+  // ring slots are bits 14..15 of the address: slot s -> s + 1 (mod 4) is ONE xor per register with a wave-uniform mask,
+  // 1 << 14 out of an even slot, 3 << 14 out of an odd one (`from` = the slot being left)
+  auto advance_k = [&](int from) __attribute__((always_inline)) {
+    const uint32_t mk = (from & 1) ? 3u * TILE : 1u * TILE;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) k_ad[s] = (k_ad[s] + TILE) & (4 * TILE - 1);
+    for (int s = 0; s < 8; ++s) k_ad[s] ^= mk;
   };
-  auto advance_v = [&]() __attribute__((always_inline)) {
+  auto advance_v = [&](int from) __attribute__((always_inline)) {
+    const uint32_t mk = (from & 1) ? 3u * TILE : 1u * TILE;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v_ad[c] = ((v_ad[c] + TILE) & (4 * TILE - 1)) | VT_RING;
+    for (int c = 0; c < 4; ++c) v_ad[c] ^= mk;
   };
 
   f32x16 ot[2][4];  // O^T accumulators: block b, 32-wide d block
@@ -178,6 +183,8 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
       const float alpha = fast_exp2(m_run[b] - mn);
       m_run[b] = mn;
       l_run[b] *= alpha;
+      // (volatile: hipcc otherwise hoists the 64 accumulator reads of this rarely taken block above the branch, into every tile)
+      asm volatile("" : "+a"(ot[b][0]), "+a"(ot[b][1]), "+a"(ot[b][2]), "+a"(ot[b][3]));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -235,12 +242,14 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
 #define FMI_AW4_G3(WAIT, CSTR, OUT, B, IMM)                                                                                                  \
   asm volatile(WAIT "v_mfma_f32_32x32x16_bf16 %0, %1, %2, " CSTR "\n\tds_read_b128 %1, %3 offset:" #IMM : OUT, "+v"(f) : B, "v"(ra))
 #define FMI_AW4_G2(WAIT, CSTR, OUT, B) asm volatile(WAIT "v_mfma_f32_32x32x16_bf16 %0, %1, %2, " CSTR : OUT : "v"(f), B)
+#define FMI_AW4_G2D(WAIT, CSTR, OUT, B) asm volatile(WAIT "v_mfma_f32_32x32x16_bf16 %0, %1, %2, " CSTR "\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : OUT : "v"(f), B)
 #define FMI_AW4_GAP(WAIT, CSTR, OUT, B)                        \
   switch (rd_imm) {                                            \
     case 0: FMI_AW4_G3(WAIT, CSTR, OUT, B, 0); break;          \
     case 4096: FMI_AW4_G3(WAIT, CSTR, OUT, B, 4096); break;    \
     case 8192: FMI_AW4_G3(WAIT, CSTR, OUT, B, 8192); break;    \
     case 12288: FMI_AW4_G3(WAIT, CSTR, OUT, B, 12288); break;  \
+    case -2: FMI_AW4_G2D(WAIT, CSTR, OUT, B); break;           \
     default: FMI_AW4_G2(WAIT, CSTR, OUT, B); break;            \
   }
 #define FMI_AW4_MFMA(CSTR, OUT, B)                                          \
@@ -285,9 +294,10 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
   // its QK^T part may be a run-time choice).  sm: softmax of block b_sm / tile t_sm in the gaps.  bar_gap >= 0: the tile
   // barrier sits in that gap, after waiting until at most bar_vm of this wave's DMA pieces are outstanding.  dma: 1 = the
   // pieces of V^T(dma_tile) in the second half (behind the barrier), 2 = those of K(dma_tile), one every 8 gaps.
-  // adv: bit 0 / 1 = advance the K / V^T address registers by one ring slot behind this phase's last own read.
+  // adv: bit 0 / 1 = advance the K / V^T address registers by one ring slot behind this phase's last own read (adv_u = the
+  // tile index u of the phase A(u) doing it).
   auto phase = [&](bool has_pv, bool has_qk, int b_pv, int b_qk, const Aw4Phase& nx, bool has_sm, int b_sm, int t_sm, int bar_gap, int bar_vm, int dma,
-                   int dma_tile, int adv) __attribute__((always_inline)) {
+                   int dma_tile, int adv, int adv_u, bool tail_drain = false) __attribute__((always_inline)) {
     const Aw4Phase p{has_pv, has_qk, b_pv, b_qk};
     const int n = p.n(), nn = nx.n();
 #pragma clang loop unroll(full)
@@ -297,8 +307,8 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
         const int ahead = n - i - 4 + nn;  // stream reads issued beyond gap i + 3
         const int wait = (i & 3) == 0 ? min(PF - 4, max(ahead, 0)) : -1;
         if (adv && i + PF == n) {  // all own reads are out: move the address registers to the next iteration's slots
-          if (adv & 1) advance_k();
-          if (adv & 2) advance_v();
+          if (adv & 1) advance_k(adv_u);  // A(u): K leaves slot u, V^T slot u - 1
+          if (adv & 2) advance_v(adv_u - 1);
         }
         if (i + PF < n) {
           mfma_step(p, i, fr[i % PF], wait, frag_reg(has_pv, has_qk, i + PF), frag_imm(has_pv, has_qk, i + PF));
@@ -308,7 +318,9 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
           else if (nx.has_pv) mfma_step(p, i, fr[i % PF], wait, frag_reg(true, false, k), frag_imm(true, false, k));
           else mfma_step(p, i, fr[i % PF], wait, frag_reg(false, true, k), frag_imm(false, true, k));
         } else {
-          mfma_step(p, i, fr[i % PF], wait, 0u, -1);
+          // no read; rd_imm -2 on the phase's last MFMA = drain inside the statement (used in front of the pinned loop statement:
+          // hipcc may copy S^T / O^T right behind this statement and knows nothing of the MFMAs in flight)
+          mfma_step(p, i, fr[i % PF], wait, 0u, (tail_drain && i == n - 1) ? -2 : -1);
         }
         const int g0 = n == 32 ? i : 2 * i;  // a 16-MFMA phase carries two softmax slices per gap
         // (its first max step would sit one MFMA behind the previous phase's last write of S^T: drain once, untied asm order)
@@ -350,25 +362,92 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
         default: asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fr[7]) : "v"(k_ad[3])); break;
       }
     }
-    phase(false, true, 0, 0, Aw4Phase{false, true, 1, 1}, false, 0, 0, -1, 0, 0, 0, 0);       // pre: QK^T(0, 0) from K(0)
-    if (ntiles > 1) phase(false, true, 1, 1, Aw4Phase{true, true, 0, 0}, true, 0, 0, 8, 0, 1, 2, 1);  // A(0): QK^T(1, 0); V^T(2); then K -> slot 1
-    else phase(false, true, 1, 1, Aw4Phase{true, false, 0, 0}, true, 0, 0, 8, 0, 1, 2, 1);
+    phase(false, true, 0, 0, Aw4Phase{false, true, 1, 1}, false, 0, 0, -1, 0, 0, 0, 0, 0);       // pre: QK^T(0, 0) from K(0)
+    // A(0): QK^T(1, 0); V^T(2); then K -> slot 1.  No fragment prefetch for the next phase and the MFMAs drained inside its
+    // last statement: the pinned loop statement follows, see there.
+    phase(false, true, 1, 1, none, true, 0, 0, 8, 0, 1, 2, 1, 0, true);
   }
   // B(t), A(t+1): both read K(t+1) and V^T(t).  The last pair is peeled so that the phase following A is a literal
   // inside the loop (a run-time choice there made hipcc shuffle S^T between two register assignments every iteration).
-  for (int t = 0; t + 2 < ntiles; ++t) {
-    phase(true, true, 0, 0, Aw4Phase{true, true, 1, 1}, true, 1, t, -1, 0, 2, t + 3, 0);
-    phase(true, true, 1, 1, Aw4Phase{true, true, 0, 0}, true, 0, t + 1, 16, 8, 1, t + 3, 3);
+  // The steady state — B(t), A(t+1) for t = 0 .. ntiles-3, i.e. the two calls
+  //     phase(true, true, 0, 0, Aw4Phase{true, true, 1, 1}, true, 1, t, -1, 0, 2, t + 3, 0, 0);
+  //     phase(true, true, 1, 1, Aw4Phase{true, true, 0, 0}, true, 0, t + 1, 16, 8, 1, t + 3, 3, t + 1);
+  // — is ONE asm statement with hand-assigned registers, generated by tools/gen_attention_w4_loop.py into
+  // attention_w4_loop.inc (same instructions, same order per gap; nothing padded or placed by hipcc in between: as a
+  // chain of per-gap statements the loop carried 52 compiler-inserted s_nop and ~70 stray address / control
+  // instructions per pair of phases).  The operands below pin every array to the registers the generated text names.
+  // hipcc knows nothing of the fragment reads / MFMAs in flight and copies registers in front of and behind a statement with
+  // pinned operands, so the statement is entered and left with nothing in flight (A(0) above; the statement fetches the
+  // first fragments of B itself and ends with a drain) and runs on every path (zero iterations when ntiles == 2).
+  {
+    typedef float f32x32 __attribute__((ext_vector_type(32)));
+    typedef int i32x32 __attribute__((ext_vector_type(32)));
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    f32x32 O[4], S[2];
+    i32x32 F, QA[2];
+    i32x16 P[2], misc;
+    i32x8 KA;
+    frag_t VA;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        O[2 * b][r] = ot[b][r >> 4][r & 15], O[2 * b + 1][r] = ot[b][2 + (r >> 4)][r & 15];
+        S[b][r] = sc[b][r >> 4][r & 15];
+        QA[b][r] = qf[b][r >> 2][r & 3];
+      }
+      F[r] = fr[r >> 2][r & 3];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P[0][r] = pf[0][r >> 2][r & 3], P[1][r] = pf[1][r >> 2][r & 3];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) KA[r] = (int)k_ad[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      VA[r] = (int)v_ad[r];
+      misc[r] = (int)k_voff[r], misc[4 + r] = (int)v_voff[r];
+      // K rows past the last key of a ragged last tile are fetched from the last key (stage_k)
+      const int kr = (wave * 4 + r) * 4 + (lane >> 4);
+      misc[8 + r] = kr >= k_last_rows ? (int)((k_last_rows - 1) * 256 + (((lane & 15) ^ (kr & 15)) << 4)) : (int)k_voff[r];
+    }
+    misc[12] = __float_as_int(m_run[0]), misc[13] = __float_as_int(m_run[1]), misc[14] = __float_as_int(l_run[0]), misc[15] = __float_as_int(l_run[1]);
+    const uint64_t kb64 = (uint64_t)(uintptr_t)Kb, vb64 = (uint64_t)(uintptr_t)Vb;
+    const uint32_t kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)kb64), kb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(kb64 >> 32));
+    const uint32_t vb_lo = __builtin_amdgcn_readfirstlane((uint32_t)vb64), vb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(vb64 >> 32));
+    const float thr = (float)THR_X16 * 0.0625f;
+    asm volatile(FMI_AW4_LOOP_ASM
+                 : "+{a[0:31]}"(O[0]), "+{a[32:63]}"(O[1]), "+{a[64:95]}"(O[2]), "+{a[96:127]}"(O[3]), "+{v[0:31]}"(S[0]), "+{v[32:63]}"(S[1]),
+                   "+{v[64:79]}"(P[0]), "+{v[80:95]}"(P[1]), "+{v[96:127]}"(F), "+{v[128:135]}"(KA), "+{v[136:139]}"(VA), "+{v[140:155]}"(misc)
+                 : "{a[128:159]}"(QA[0]), "{a[160:191]}"(QA[1]), [kb_lo] "s"(kb_lo), [kb_hi] "s"(kb_hi), [vb_lo] "s"(vb_lo), [vb_hi] "s"(vb_hi),
+                   [nt] "s"(ntiles), [ntm1] "s"(ntiles - 1), [sl] "s"(scale_log2e), [thr] "s"(thr), [woff] "s"(wave * 4096)
+                 : "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "s80",
+                   "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "vcc", "scc", "memory");
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        ot[b][r >> 4][r & 15] = O[2 * b][r], ot[b][2 + (r >> 4)][r & 15] = O[2 * b + 1][r];
+        sc[b][r >> 4][r & 15] = S[b][r];
+      }
+      fr[r >> 2][r & 3] = F[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pf[0][r >> 2][r & 3] = P[0][r], pf[1][r >> 2][r & 3] = P[1][r];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) k_ad[r] = (uint32_t)KA[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v_ad[r] = (uint32_t)VA[r];
+    m_run[0] = __int_as_float(misc[12]), m_run[1] = __int_as_float(misc[13]), l_run[0] = __int_as_float(misc[14]), l_run[1] = __int_as_float(misc[15]);
   }
-  if (ntiles > 1) {
-    phase(true, true, 0, 0, Aw4Phase{true, true, 1, 1}, true, 1, ntiles - 2, -1, 0, 2, ntiles - 1, 0);
-    phase(true, true, 1, 1, Aw4Phase{true, false, 0, 0}, true, 0, ntiles - 1, 16, 8, 1, ntiles - 1, 3);
-  }
-  phase(true, false, 0, 0, Aw4Phase{true, false, 1, 1}, true, 1, ntiles - 1, -1, 0, 0, 0, 0);  // B(last): PV(0, last) beside softmax(1, last)
-  phase(true, false, 1, 1, none, false, 0, 0, -1, 0, 0, 0, 0);                                // post: PV(1, last)
+  phase(true, true, 0, 0, Aw4Phase{true, true, 1, 1}, true, 1, ntiles - 2, -1, 0, 2, ntiles - 1, 0, 0);
+  phase(true, true, 1, 1, Aw4Phase{true, false, 0, 0}, true, 0, ntiles - 1, 16, 8, 1, ntiles - 1, 3, ntiles - 1);
+  phase(true, false, 0, 0, Aw4Phase{true, false, 1, 1}, true, 1, ntiles - 1, -1, 0, 0, 0, 0, 0);  // B(last): PV(0, last) beside softmax(1, last)
+  phase(true, false, 1, 1, none, false, 0, 0, -1, 0, 0, 0, 0, 0);                                // post: PV(1, last)
 #undef FMI_AW4_MFMA
 #undef FMI_AW4_GAP
 #undef FMI_AW4_G2
+#undef FMI_AW4_G2D
 #undef FMI_AW4_G3
 
   // ---- epilogue: O[q][d] = O^T / l, d = 32 dt + 8 g + 4 hl + {0..3}; staged through LDS so that whole 256-byte rows leave

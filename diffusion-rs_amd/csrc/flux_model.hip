@@ -470,7 +470,6 @@ bool with_qkv_relayout(fmi_flux* m, GemmProblem& p, const bf16_t* nq, const bf16
                        float k8 = 0.f) {
   auto& w = m->ws;
   if (!can_fuse_relayout(m, p.M, rows, row_off) || p.N < 256) return false;
-  if (p.q_type && !m->dense_cache) return false;  // packed weights run on the one-wave-per-SIMD kernel: relayout by the stand-alone kernels
   p.qk_q8 = q8, p.qk_k8 = k8;
   p.qk_qh = w.Qh, p.qk_kh = w.Kh, p.qk_vt = w.Vt;
   p.qk_wq = nq, p.qk_wk = nk;

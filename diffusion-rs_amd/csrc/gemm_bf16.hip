@@ -120,11 +120,13 @@ __device__ __forceinline__ void stage_tile_q4(const GemmProblem& P, int n0, int 
 // The arithmetic (bf16 rounding of the projection first, then f32 RMS / RoPE in the same operation
 // order, 16 lanes x 8 elements per head row) is that of qk_norm_rope_kernel, so both paths produce
 // the same bits.  Requires qk_rows, qk_row_off and M to be multiples of 16 (host-checked).
-__device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int wave, int lane) {
+// Two halves, so that the 4-wave kernels (each wave = two of the eight 128 x 64 sub-tiles) run them as
+//   barrier; stage(sub-tile 0); stage(sub-tile 1); barrier; emit(row group 0); emit(row group 1)
+// over the same LDS image and the same stores: `wave` is the index 0..7 in the 2 x 4 layout.
+__device__ __forceinline__ void qkv_relayout_stage(const GemmProblem& P, f32x16 (&acc)[4][2], char* smem, int n0, int wave, int lane) {
   const int wm = wave >> 2, wn = wave & 3;
   const int hl = lane >> 5, l31 = lane & 31;
   const int part = n0 / P.qk_D;                     // 0 q, 1 k, 2 v
-  const int head0 = (n0 - part * P.qk_D) >> 7;      // first of the tile's two heads
   auto biased = [&](int n, float (&v)[4]) {
     if (P.bias) {
       const uint2 b = *reinterpret_cast<const uint2*>(P.bias + n);
@@ -134,7 +136,6 @@ __device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, f32x
       v[3] += bf16_to_f32((bf16_t)(b.y >> 16));
     }
   };
-  __syncthreads();  // every wave is done with the operand tiles
   if (part < 2) {
     // ---- stage the bf16 tile in the wave-private swizzled regions of the normal store path
     char* cw = smem + wave * 16384;
@@ -152,8 +153,37 @@ __device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, f32x
           const int r = i * 32 + l31, c = j * 8 + q * 2 + hl;
           *reinterpret_cast<uint2*>(cw + r * 128 + ((c ^ (r & 15)) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
         }
-    __syncthreads();
-    // ---- 512 (row, head) vectors of 128: 16 lanes x 8 elements each; this wave takes rows 32*wave .. +31
+  } else {
+    // ---- v: stage TRANSPOSED, [d column 0..255][tile-local token 0..255] bf16 (512-B rows), with the
+    // attention kernel's kv permutation (swap bits 2,3 inside groups of 16) applied to the token
+    // index on the way in, so that a row leaves as plain 16-B pieces of consecutive stored positions
+    bf16_t* tp = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tl = wm * 128 + i * 32 + l31;
+      const int tpos = (tl & ~12) | ((tl & 4) << 1) | ((tl & 8) >> 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+          const int dc = wn * 64 + j * 32 + q * 8 + 4 * hl;
+          biased(n0 + dc, v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tp[(dc + e) * 256 + tpos] = f32_to_bf16(v[e]);
+        }
+    }
+  }
+}
+
+__device__ __forceinline__ void qkv_relayout_emit(const GemmProblem& P, char* smem, int m0, int n0, int wave, int lane) {
+  const int hl = lane >> 5;
+  const int part = n0 / P.qk_D;                     // 0 q, 1 k, 2 v
+  const int head0 = (n0 - part * P.qk_D) >> 7;      // first of the tile's two heads
+  if (part < 2) {
+    // ---- 512 (row, head) vectors of 128: 16 lanes x 8 elements each; row group `wave` is rows 32*wave .. +31
     const int sub = lane & 15, grp = lane >> 4;
     const bf16_t* wsel = part == 0 ? P.qk_wq : P.qk_wk;
     bf16_t* osel = part == 0 ? P.qk_qh : P.qk_kh;
@@ -213,28 +243,7 @@ __device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, f32x
       }
     }
   } else {
-    // ---- v: stage TRANSPOSED, [d column 0..255][tile-local token 0..255] bf16 (512-B rows), with the
-    // attention kernel's kv permutation (swap bits 2,3 inside groups of 16) applied to the token
-    // index on the way in, so that a row leaves as plain 16-B pieces of consecutive stored positions
-    bf16_t* tp = reinterpret_cast<bf16_t*>(smem);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int tl = wm * 128 + i * 32 + l31;
-      const int tpos = (tl & ~12) | ((tl & 4) << 1) | ((tl & 8) >> 1);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-          const int dc = wn * 64 + j * 32 + q * 8 + 4 * hl;
-          biased(n0 + dc, v);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) tp[(dc + e) * 256 + tpos] = f32_to_bf16(v[e]);
-        }
-    }
-    __syncthreads();
+    const bf16_t* tp = reinterpret_cast<const bf16_t*>(smem);
     const int g8 = lane & 31;  // 8 stored positions (16 B) of a row per lane
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
@@ -248,6 +257,13 @@ __device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, f32x
       }
     }
   }
+}
+
+__device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int wave, int lane) {
+  __syncthreads();  // every wave is done with the operand tiles
+  qkv_relayout_stage(P, acc, smem, n0, wave, lane);
+  __syncthreads();
+  qkv_relayout_emit(P, smem, m0, n0, wave, lane);
 }
 
 // WN = waves along N (4: the 8-wave kernels, wave = wm*4 + wn, 128 x 32*NJ per wave; 2: the 4-wave kernel, 128 x 128 per wave)
@@ -915,6 +931,53 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
 // LDS: A ring of 2 + W ring of 3 tiles of 32 KiB (same image, swizzle and DMA pieces as the other kernels).
 // Accumulation order per output element is that of the other kernels: bit-identical results.
 constexpr int W4_THREADS = 256;
+// Tail of the one-wave-per-SIMD kernels (gemm_w4_kernel, gemm_w4q_kernel): wave (wm, wn) of the 2 x 2 layout holds 128 x 128.
+// It leaves as two 128 x 64 halves through the 8-wave epilogue: half r plays wave (wm, 2*wn + r) of the 2 x 4 layout (same
+// staging regions, same stores, same arithmetic).  Real loops, not two inlined copies: the unrolled epilogue is large, and
+// twice that code (or its 128-wide instantiation) runs out of the instruction cache and, with the accumulators filling the
+// AGPRs, spills (measured 3-4x slower).
+// The lane id is laundered: everything the epilogue derives from it is then computed after the K loop instead of being
+// hoisted above it, kept live across 256 arch VGPRs of loop state, spilled, and reloaded (each reload = vmcnt(0) = the
+// wave's stores serialised: measured 30 us per tile instead of 12).
+template <int ACT>
+__device__ __forceinline__ void w4_epilogue(const GemmProblem& P, f32x16 (&acc)[4][4], char* smem, int m0, int n0, int wave, int wm, int wn, int lane) {
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  if (P.qk_qh != nullptr && n0 < 3 * P.qk_D) {
+    // fused q|k|v relayout: both halves staged into the one LDS image, then this wave emits row groups 2*wave, 2*wave + 1
+    __syncthreads();
+    {
+      f32x16 hacc[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][0], hacc[i][1] = acc[i][1];
+#pragma clang loop unroll(disable)
+      for (int r = 0; r < 2; ++r) {
+        qkv_relayout_stage(P, hacc, smem, n0, wm * 4 + wn * 2 + r, lane_e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][2], hacc[i][1] = acc[i][3];
+        asm volatile("" : "+v"(lane_e));
+      }
+    }
+    __syncthreads();
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < 2; ++r) {
+      qkv_relayout_emit(P, smem, m0, n0, wave * 2 + r, lane_e);
+      asm volatile("" : "+v"(lane_e));
+    }
+    return;
+  }
+  f32x16 hacc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][0], hacc[i][1] = acc[i][1];
+#pragma clang loop unroll(disable)
+  for (int r = 0; r < 2; ++r) {
+    gemm_epilogue_impl<2, 4, ACT>(P, hacc, smem, m0, n0, wm * 4 + wn * 2 + r, lane_e);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][2], hacc[i][1] = acc[i][3];
+    asm volatile("" : "+v"(lane_e));  // keep the second round's address math out of the first
+  }
+}
+
 template <bool FP8, int ACT>
 __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch batch) {
   constexpr int NJ = 4, BN = 256;
@@ -1087,29 +1150,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the trailing dummy DMA / reads must not land in the epilogue's staging
 #undef FMI_W4_RD
 #undef FMI_W4_WAIT
-  // The wave's 128 x 128 leaves as two 128 x 64 halves through the 8-wave epilogue: half h plays wave (wm, 2*wn + h)
-  // of the 2 x 4 layout (same staging regions, same stores).
-  // Launder the lane id: everything the epilogue derives from it is then computed after the loop instead of being
-  // hoisted above it, kept live across 256 arch VGPRs of loop state, spilled, and reloaded (each reload = vmcnt(0) = the
-  // wave's stores serialised: measured 30 us per tile instead of 12).
-  int lane_e = lane;
-  asm volatile("" : "+v"(lane_e));
-  // The wave's 128 x 128 leaves in two rounds through the 8-wave epilogue: in round r its column half r plays wave
-  // (wm, 2*wn + r) of the 2 x 4 layout (same staging regions, same stores, same arithmetic).  A real loop, not two inlined
-  // copies: the unrolled epilogue is large, and twice that code (or its 128-wide instantiation) runs out of the
-  // instruction cache and, with the accumulators filling the AGPRs, spills (measured 3-4x slower).
-  {
-    f32x16 hacc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][0], hacc[i][1] = acc[i][1];
-#pragma clang loop unroll(disable)
-    for (int r = 0; r < 2; ++r) {
-      gemm_epilogue<2, 4, ACT>(P, hacc, smem, m0, n0, wm * 4 + wn * 2 + r, lane_e);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][2], hacc[i][1] = acc[i][3];
-      asm volatile("" : "+v"(lane_e));  // keep the second round's address math out of the first
-    }
-  }
+  w4_epilogue<ACT>(P, acc, smem, m0, n0, wave, wm, wn, lane);
 }
 
 }  // namespace fmi
@@ -1125,6 +1166,8 @@ static bool g_w4 = [] {
   return e ? atoi(e) != 0 : true;
 }();
 static int g_w4q_min_rows = 256;
+static int g_w4_qkv_min_n = 16384;
+void set_gemm_w4_qkv_min_n(int n) { g_w4_qkv_min_n = n; }
 void set_gemm_w4q_min_rows(int rows) { g_w4q_min_rows = rows; }
 void set_gemm_w4(bool on) { g_w4 = on; }
 void set_gemm_pingpong(bool on) { g_pingpong = on; }
@@ -1176,7 +1219,8 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   // 4-wave kernel: its K loop is 7-10 % faster, its two-round epilogue slower — measured break-even (tools/gemm_bench,
   // FMI_EPI=store|gelu|resid on the FLUX shapes): the f32 residual read-modify-write launches at every K (proj -5 %,
   // mlp2 -10 %, linear2 -7 %), everything else from K = 8192 on (mlp1 + GELU at K = 3072 is a wash).
-  // The fused q|k|v relayout epilogue exists for the 8-wave layout only.
+  // The launches with the fused q|k|v relayout epilogue: from N = g_w4_qkv_min_n on (the single blocks' 21504-wide
+  // qkv+mlp launch, +9 %; the double blocks' 9216-wide qkv launches are a wash and stay on the 8-wave kernel).
   bool w4_pays = !fp8 && !conv && !quant;
   // 4-bit weights: the one-wave-per-SIMD fused kernel from g_w4q_min_rows rows on (below it the GEMM is bound by the packed
   // weight stream and the two-workgroups-per-CU kernel with the VGPR expand hides latency better)
@@ -1184,11 +1228,11 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   for (int i = 0; quant && i < nprob; ++i) {
     const GemmProblem& p = probs[i];
     const int kb = p.q_blocksize / BK;  // K tiles per absmax block
-    if (p.qk_qh || p.M < g_w4q_min_rows || p.K % p.q_blocksize || (kb & (kb - 1)) || (int64_t)p.N * p.K / 2 >= (1ll << 32)) w4q_ok = false;
+    if (p.M < g_w4q_min_rows || p.K % p.q_blocksize || (kb & (kb - 1)) || (int64_t)p.N * p.K / 2 >= (1ll << 32)) w4q_ok = false;
   }
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem& p = probs[i];
-    if (p.qk_qh || (p.epi != EPI_RESID_GATE_F32 && p.K < 8192)) w4_pays = false;
+    if (p.epi != EPI_RESID_GATE_F32 && p.K < 8192 && !(p.qk_qh && p.N >= g_w4_qkv_min_n)) w4_pays = false;
   }
 #define FMI_ACT_LAUNCH(KERNEL, FP8FLAG, THREADS)                                                    \
   do {                                                                                              \
@@ -1202,7 +1246,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   else if (conv)
     FMI_GEMM_LAUNCH(2);
   else if (quant && bn == 256 && w4q_ok) {
-    // fused dequant-GEMM, one wave per SIMD (gemm_w4q.h); the QKV relayout epilogue exists for the 8-wave layout only
+    // fused dequant-GEMM, one wave per SIMD (gemm_w4q.h)
     const dim3 g4(total), b4(W4_THREADS);
     if (act == 0) hipLaunchKernelGGL((gemm_w4q_kernel<0>), g4, b4, 0, stream, b);
     else if (act == 1) hipLaunchKernelGGL((gemm_w4q_kernel<1>), g4, b4, 0, stream, b);

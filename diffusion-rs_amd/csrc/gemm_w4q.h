@@ -306,21 +306,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const GemmBatch
 #undef FMI_W4Q_RD
 #undef FMI_W4Q_FRAG_WAIT
 #undef FMI_W4Q_LGKM
-  // epilogue: as gemm_w4_kernel — two rounds through the 8-wave epilogue (see there)
-  int lane_e = lane;
-  asm volatile("" : "+v"(lane_e));
-  {
-    f32x16 hacc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][0], hacc[i][1] = acc[i][1];
-#pragma clang loop unroll(disable)
-    for (int r = 0; r < 2; ++r) {
-      gemm_epilogue<2, 4, ACT>(P, hacc, smem + W4Q_LUT_BYTES, m0, n0, wm * 4 + wn * 2 + r, lane_e);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][2], hacc[i][1] = acc[i][3];
-      asm volatile("" : "+v"(lane_e));
-    }
-  }
+  w4_epilogue<ACT>(P, acc, smem + W4Q_LUT_BYTES, m0, n0, wave, wm, wn, lane);
 }
 
 }  // namespace fmi

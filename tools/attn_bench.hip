@@ -79,12 +79,16 @@ int main(int argc, char** argv) {
     if (mis3) {  // token-major output (B, L, H*128): where does the one-wave kernel first differ?
       const size_t row = first / ((size_t)s.H * 128), col = first % ((size_t)s.H * 128);
       size_t rows_bad = 0, last_row = 0;
+      int hist[64] = {};
       for (size_t r = 0; r < (size_t)s.B * s.L; ++r) {
         bool bad = false;
         for (size_t c = 0; c < (size_t)s.H * 128 && !bad; ++c) bad = hb[r * s.H * 128 + c] != hc[r * s.H * 128 + c];
         rows_bad += bad;
-        if (bad) last_row = r;
+        if (bad) last_row = r, ++hist[(r % s.L) & 63];
       }
+      printf("   bad rows by (token & 63):");
+      for (int i = 0; i < 64; ++i) printf(" %d", hist[i]);
+      printf("\n");
       printf("   one-wave vs pp: max |diff| %.4g, first at token %zu head %zu d %zu (pp %.5g, one-wave %.5g); %zu of %zu token rows differ, last %zu\n", maxd, row,
              col / 128, col % 128, tof(hb[first]), tof(hc[first]), rows_bad, (size_t)s.B * s.L, last_row);
     }

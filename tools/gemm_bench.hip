@@ -97,6 +97,30 @@ int main(int argc, char** argv) {
   bf16_t* O2;
   const char* epi_env = getenv("FMI_EPI");  // store (default) | gelu | resid
   const int epi_kind = !epi_env ? 0 : !strcmp(epi_env, "gelu") ? 1 : !strcmp(epi_env, "resid") ? 2 : 0;
+  // FMI_EPI=qkv: the model's q|k|v launches — fused RMS + RoPE + head-major relayout epilogue on the first 3*3072 columns
+  // (GELU on the rest, as the single blocks' qkv+mlp launch); only the shapes with N >= 9216 take it
+  const bool qkv_mode = epi_env && !strcmp(epi_env, "qkv");
+  bf16_t *qh[2] = {}, *kh[2] = {}, *vt[2] = {}, *nqk = nullptr;
+  float* pe = nullptr;
+  const int QD = 3072, QH = 24;
+  size_t qkv_elems = 0;
+  if (qkv_mode) {
+    int maxM = 0;
+    for (auto& s : shapes) maxM = std::max(maxM, s.M);
+    const int lpad = (maxM + 63) / 64 * 64;
+    qkv_elems = (size_t)QH * 128 * lpad;
+    for (int i = 0; i < 2; ++i) {
+      hipMalloc((void**)&qh[i], qkv_elems * 2), hipMalloc((void**)&kh[i], qkv_elems * 2), hipMalloc((void**)&vt[i], qkv_elems * 2);
+      hipMemset(qh[i], 0, qkv_elems * 2), hipMemset(kh[i], 0, qkv_elems * 2), hipMemset(vt[i], 0, qkv_elems * 2);
+    }
+    hipMalloc((void**)&nqk, 256 * 2);
+    fill_kernel<<<1, 256>>>(nqk, 256, 5u);
+    std::vector<float> h((size_t)maxM * 128);
+    for (size_t i = 0; i < h.size() / 2; ++i) h[2 * i] = cosf(0.001f * i), h[2 * i + 1] = sinf(0.001f * i);
+    hipMalloc((void**)&pe, h.size() * 4);
+    hipMemcpy(pe, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    set_gemm_w4_qkv_min_n(0);
+  }
   const size_t out_es = epi_kind == 2 ? 4 : 2;
   hipFree(O);
   hipMalloc((void**)&O, maxO * out_es);
@@ -118,11 +142,19 @@ int main(int argc, char** argv) {
     p.A = A, p.W = W, p.out = O, p.M = s.M, p.N = s.N, p.K = s.K, p.lda = s.K + pad_a, p.ldw = s.K + pad_w, p.ldo = s.N + pad_o, p.epi = epi_kind == 1 ? EPI_GELU_BF16 : epi_kind == 2 ? EPI_RESID_GATE_F32 : EPI_STORE_BF16, p.alpha = 1.f;
     if (epi_kind) p.bias = bias;
     if (epi_kind == 2) p.gate = gate;
+    const bool qkv = qkv_mode && s.N >= 3 * QD && s.N % 256 == 0 && s.M % 16 == 0;
+    if (qkv) {
+      p.bias = bias;
+      if (s.N > 3 * QD) p.epi = EPI_GELU_FROM_COL, p.gelu_from = 3 * QD;
+      p.qk_wq = nqk, p.qk_wk = nqk + 128, p.qk_pe = pe, p.qk_pe_bstride = 0, p.qk_H = QH, p.qk_D = QD, p.qk_rows = s.M, p.qk_row_off = 0, p.qk_Ltot = s.M,
+      p.qk_Lpad = (s.M + 63) / 64 * 64;
+    }
     double tf[3];
     for (int pp = 0; pp < 3; ++pp) {  // double-buffered kernel, the ping-pong kernel, the 4-wave kernel
       set_gemm_pingpong(pp != 0);
       set_gemm_w4(pp == 2);
       p.out = pp == 1 ? O : O2;
+      if (qkv) p.qk_qh = qh[pp == 1], p.qk_kh = kh[pp == 1], p.qk_vt = vt[pp == 1];
       if (epi_kind == 2) hipMemsetAsync(p.out, 0, (size_t)s.M * p.ldo * 4, nullptr);
       for (int i = 0; i < 2; ++i) launch_gemm(&p, 1, nullptr);
       hipDeviceSynchronize();
@@ -142,6 +174,11 @@ int main(int argc, char** argv) {
     hipMemset(d_mis, 0, 8);
     count_mismatch<<<1024, 256>>>(O, O2, (size_t)s.M * p.ldo * (out_es / 2), d_mis);  // resid: both accumulated the same number of launches
     unsigned long long mis = 0;
+    if (qkv) {
+      count_mismatch<<<1024, 256>>>(qh[0], qh[1], qkv_elems, d_mis);
+      count_mismatch<<<1024, 256>>>(kh[0], kh[1], qkv_elems, d_mis);
+      count_mismatch<<<1024, 256>>>(vt[0], vt[1], qkv_elems, d_mis);
+    }
     hipMemcpy(&mis, d_mis, 8, hipMemcpyDeviceToHost);
     printf("%-18s M=%5d N=%5d K=%5d  tiles %5d  double-buffered %7.1f TF   ping-pong %7.1f TF (%7.1f us)   4-wave %7.1f TF (%7.1f us)   4-wave vs ping-pong mismatching elements %llu%s\n", s.name, s.M, s.N, s.K,
            ((s.M + 255) / 256) * ((s.N + 255) / 256), tf[0], tf[1], 2.0 * s.M * s.N * s.K / tf[1] * 1e-6, tf[2], 2.0 * s.M * s.N * s.K / tf[2] * 1e-6, mis,
@@ -162,8 +199,17 @@ int main(int argc, char** argv) {
       GemmProblem p{};
       p.A = A, p.W = W, p.out = O2, p.M = s.M, p.N = s.N, p.K = s.K, p.lda = s.K, p.ldw = s.K, p.ldo = s.N, p.epi = epi_kind == 1 ? EPI_GELU_BF16 : EPI_STORE_BF16, p.alpha = 1.f;
       if (epi_kind) p.bias = bias;
+      const bool qkv = qkv_mode && s.N >= 3 * QD && s.N % 256 == 0 && s.M % 16 == 0;
+      if (qkv) {
+        p.bias = bias;
+        if (s.N > 3 * QD) p.epi = EPI_GELU_FROM_COL, p.gelu_from = 3 * QD;
+        p.qk_wq = nqk, p.qk_wk = nqk + 128, p.qk_pe = pe, p.qk_pe_bstride = 0, p.qk_H = QH, p.qk_D = QD, p.qk_rows = s.M, p.qk_row_off = 0, p.qk_Ltot = s.M,
+        p.qk_Lpad = (s.M + 63) / 64 * 64;
+        p.qk_qh = qh[0], p.qk_kh = kh[0], p.qk_vt = vt[0];
+      }
       GemmProblem q = p;
       q.out = O, q.W = nullptr, q.Wq = Wq, q.absmax = am, q.q_blocksize = 64, q.q_type = 2;
+      if (qkv) q.qk_qh = qh[1], q.qk_kh = kh[1], q.qk_vt = vt[1];
       double us[2];
       for (int arm = 0; arm < 2; ++arm) {
         GemmProblem& r = arm ? q : p;
@@ -179,6 +225,11 @@ int main(int argc, char** argv) {
       }
       hipMemset(d_mis, 0, 8);
       count_mismatch<<<1024, 256>>>(O, O2, (size_t)s.M * s.N, d_mis);
+      if (qkv) {
+        count_mismatch<<<1024, 256>>>(qh[0], qh[1], qkv_elems, d_mis);
+        count_mismatch<<<1024, 256>>>(kh[0], kh[1], qkv_elems, d_mis);
+        count_mismatch<<<1024, 256>>>(vt[0], vt[1], qkv_elems, d_mis);
+      }
       unsigned long long mis = 0;
       hipMemcpy(&mis, d_mis, 8, hipMemcpyDeviceToHost);
       const double fl = 2.0 * s.M * s.N * s.K;
