@@ -1166,7 +1166,7 @@ static bool g_w4 = [] {
   return e ? atoi(e) != 0 : true;
 }();
 static int g_w4q_min_rows = 256;
-static int g_w4_qkv_min_n = 16384;
+static int g_w4_qkv_min_n = 1 << 30;  // never for dense weights (measured: slower, see launch_gemm); the packed 4-bit kernel always fuses
 void set_gemm_w4_qkv_min_n(int n) { g_w4_qkv_min_n = n; }
 void set_gemm_w4q_min_rows(int rows) { g_w4q_min_rows = rows; }
 void set_gemm_w4(bool on) { g_w4 = on; }
@@ -1219,8 +1219,10 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   // 4-wave kernel: its K loop is 7-10 % faster, its two-round epilogue slower — measured break-even (tools/gemm_bench,
   // FMI_EPI=store|gelu|resid on the FLUX shapes): the f32 residual read-modify-write launches at every K (proj -5 %,
   // mlp2 -10 %, linear2 -7 %), everything else from K = 8192 on (mlp1 + GELU at K = 3072 is a wash).
-  // The launches with the fused q|k|v relayout epilogue: from N = g_w4_qkv_min_n on (the single blocks' 21504-wide
-  // qkv+mlp launch, +9 %; the double blocks' 9216-wide qkv launches are a wash and stay on the 8-wave kernel).
+  // The launches with the fused q|k|v relayout epilogue stay on the 8-wave kernel: the 4-wave kernels have the epilogue
+  // too (w4_epilogue; the packed 4-bit kernel needs it), but with one workgroup per CU nothing overlaps its two LDS round
+  // trips, and it costs more than the K loop gains (tools/gemm_bench FMI_EPI=qkv, 4608 x 21504 x 3072: 8-wave 588 us,
+  // 4-wave 637 us; 4096 x 9216 x 3072: 258 vs 305 us).  set_gemm_w4_qkv_min_n lowers the bound for experiments.
   bool w4_pays = !fp8 && !conv && !quant;
   // 4-bit weights: the one-wave-per-SIMD fused kernel from g_w4q_min_rows rows on (below it the GEMM is bound by the packed
   // weight stream and the two-workgroups-per-CU kernel with the VGPR expand hides latency better)

@@ -254,7 +254,7 @@ def phase(name, b_pv, b_qk, b_sm, is_a, uid):
                        [f"v_xor_b32 {KAD(s)}, {S_MKK}, {KAD(s)}" for s in range(2, 8)]
         # ---- the MFMA of gap i, behind a counted wait every fourth gap
         if (i & 3) == 0:
-            pre.append("s_waitcnt lgkmcnt(4)")
+            pre.append("s_waitcnt lgkmcnt(2)" if os.environ.get("AW4_X") == "halfreads" else "s_waitcnt lgkmcnt(4)")
         j = i >> 1
         if i % 2 == 0:
             mf = f"v_mfma_f32_32x32x16_bf16 {OT(b_pv, j & 3)}, {FR(i)}, {PFt(b_pv, j >> 2)}, {OT(b_pv, j & 3)}"
@@ -272,10 +272,20 @@ def phase(name, b_pv, b_qk, b_sm, is_a, uid):
             post += lazy_xor
             lazy_xor = []
         o.append(f"; gap {i}")
+        # timing experiments only (wrong results): AW4_X=halfreads | novalu | noexp | nobarrier | nodma
+        X = os.environ.get("AW4_X", "")
+        if X == "halfreads" and (i & 1):
+            rd = "s_nop 0"
+        if X == "novalu":
+            post = [p_ for p_ in post if p_.startswith(("s_cbranch", ".Law4", "v_xor", "v_cmp"))]
+        if X == "noexp":
+            post = [p_.replace("v_exp_f32", "v_mov_b32") for p_ in post]
+        if X == "nodma":
+            dma = None
         o += pre + [mf, rd] + post
         if dma:
             o.append(dma)
-        if is_a and i == 16:
+        if is_a and i == 16 and os.environ.get("AW4_X") != "nobarrier":
             o += ["s_waitcnt vmcnt(8)", "s_barrier"]
     return o
 
