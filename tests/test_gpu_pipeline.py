@@ -281,3 +281,29 @@ def test_c1_schnell_256x256_4step_matches_oracle(tmp_path):
     diff = np.abs(u8.cpu().numpy().astype(np.int32) - ref_u8.astype(np.int32))
     print(f"C1 (schnell 256x256 4-step) u8: max |d| {diff.max()}, frac<=2 {float((diff <= 2).mean()):.4f}")
     assert float((diff <= 2).mean()) >= 0.99
+
+
+def test_pipeline_more_prompts_than_max_batch(tmp_path):
+    """The reference accepts any batch (pipelines/mod.rs:241-270); the workspace here holds MAX_BATCH = 8 samples, so
+    forward() runs sub-batches — with the Philox stream of a sample fixed by its index, 11 prompts in one call must give
+    exactly the images of the same prompts run one sub-batch at a time by hand."""
+    import torch
+    import diffusion_rs_amd as d
+    sd = d.synth.flux_state_dict_numpy(SMALL_FLUX, seed=1)
+    vsd = d.synth.vae_state_dict_numpy(SMALL_VAE, seed=1)
+    root = str(tmp_path / "tiny-flux")
+    _write_diffusers_dir(root, sd, vsd)
+    pipe = d.Pipeline(d.ModelSource.ModelId(root))
+    assert pipe.MAX_BATCH == 8
+    params = d.DiffusionGenerationParams(height=64, width=64, num_steps=2, guidance_scale=3.5)
+    B, T = 11, 8
+    rng = np.random.default_rng(5)
+    t5 = dev(bf16_round(rng.standard_normal((B, T, SMALL_FLUX["joint_attention_dim"])).astype(np.float32)), torch.bfloat16)
+    clip = dev(rng.standard_normal((B, SMALL_FLUX["pooled_projection_dim"])).astype(np.float32))
+    prompts = [f"p{i}" for i in range(B)]
+    whole = pipe.forward(prompts, params, embeddings=(t5, clip), seed=7, output="tensor").cpu().numpy()
+    assert whole.shape == (B, 3, 64, 64)
+    first = pipe.generate_tensor(prompts[:8], params, embeddings=(t5[:8], clip[:8]), seed=7, sample_ids=list(range(8))).cpu().numpy()
+    rest = pipe.generate_tensor(prompts[8:], params, embeddings=(t5[8:], clip[8:]), seed=7, sample_ids=[8, 9, 10]).cpu().numpy()
+    np.testing.assert_array_equal(whole, np.concatenate([first, rest], 0))
+    assert len({whole[i].tobytes() for i in range(B)}) == B  # every sample drew its own noise
