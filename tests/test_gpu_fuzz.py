@@ -107,3 +107,36 @@ def test_sdpa_random_shapes(env):
         worst = max(worst, err)
         assert err <= 6e-3, (B, H, Lq, Lk, err)
     print(f"20 random attentions: worst rel-L2 {worst:.2e}")
+
+
+def test_attention_kernels_agree_bitwise_on_random_shapes(env):
+    """The one-wave kernel (its KV loop is generated assembly, attention_w4_loop.inc), the 8-wave ping-pong kernel and the
+    single-barrier kernel implement one arithmetic: their outputs must be identical bit for bit on every shape — ragged, exact
+    multiples of 64 / 256, long KV (many loop iterations), batch > 1 — and from run to run (a hazard in a hand-scheduled
+    loop shows up as a rare, shape- or timing-dependent difference)."""
+    torch, L, lib = env
+    rng = np.random.default_rng(2024)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(1, 2, 128, 128), (1, 1, 192, 192), (2, 2, 1000, 1000), (1, 3, 2048, 2048), (1, 2, 300, 4608), (1, 1, 4608, 4608), (1, 2, 65, 129)]
+    for _ in range(10):
+        Lq = int(rng.integers(65, 1500))
+        shapes.append((int(rng.integers(1, 3)), int(rng.integers(1, 4)), Lq, Lq if rng.integers(0, 2) else int(rng.integers(65, 3000))))
+    try:
+        for (B, H, Lq, Lk) in shapes:
+            q = torch.randn(B, H, Lq, 128, device="cuda", generator=g).to(torch.bfloat16)
+            k = torch.randn(B, H, Lk, 128, device="cuda", generator=g).to(torch.bfloat16)
+            v = torch.randn(B, H, Lk, 128, device="cuda", generator=g).to(torch.bfloat16)
+            outs = []
+            for kind in (2, 1, 0, 2):  # one-wave (default), ping-pong, single-barrier, one-wave again
+                L.check(lib.fmi_set_attention_kernel(kind))
+                o = torch.full((B, Lq, H * 128), float("nan"), device="cuda", dtype=torch.bfloat16)
+                L.check(lib.fmi_sdpa_bf16(_p(q), _p(k), _p(v), _p(o), B, H, Lq, Lk, 128, 1.0 / 128 ** 0.5, 1, None))
+                torch.cuda.synchronize()
+                outs.append(o.view(torch.int16).cpu().numpy())
+            assert np.isfinite(o.float().cpu().numpy()).all(), (B, H, Lq, Lk)
+            for i in (1, 2, 3):
+                nbad = int((outs[0] != outs[i]).sum())
+                assert nbad == 0, (B, H, Lq, Lk, ["", "ping-pong", "single-barrier", "one-wave rerun"][i], nbad)
+    finally:
+        L.check(lib.fmi_set_attention_kernel(2))
+    print(f"{len(shapes)} shapes x 3 kernels: bit-identical")
