@@ -122,6 +122,7 @@ def load():
     lib.fmi_flux_set_modulation_gemm.argtypes = [C.c_void_p, C.c_int]
     lib.fmi_linear_bnb4_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_void_p]
+    lib.fmi_linear_int8_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.fmi_sdpa_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                   C.c_void_p]
     lib.fmi_sdpa_fp8qk.argtypes = lib.fmi_sdpa_bf16.argtypes
@@ -160,7 +161,7 @@ EXPORTED = [
     "fmi_t5_default_config", "fmi_t5_create", "fmi_t5_destroy", "fmi_t5_set_tensor", "fmi_t5_missing_count", "fmi_t5_missing_name",
     "fmi_t5_size_in_bytes", "fmi_t5_forward", "fmi_clip_default_config", "fmi_clip_create", "fmi_clip_destroy", "fmi_clip_set_tensor",
     "fmi_clip_missing_count", "fmi_clip_missing_name", "fmi_clip_size_in_bytes", "fmi_clip_forward", "fmi_pack_latents", "fmi_unpack_latents", "fmi_postprocess_u8",
-    "fmi_randn", "fmi_philox_u32", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_set_attention_kernel", "fmi_layernorm_mod",
+    "fmi_randn", "fmi_philox_u32", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_linear_int8_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_set_attention_kernel", "fmi_layernorm_mod",
     "fmi_groupnorm_nhwc", "fmi_conv2d_nhwc",
     "dequantize_blockwise_f32_int8", "dequantize_blockwise_f32_fp4", "dequantize_blockwise_f32_nf4", "dequantize_blockwise_f16_int8",
     "dequantize_blockwise_f16_fp4", "dequantize_blockwise_f16_nf4", "dequantize_blockwise_bf16_int8", "dequantize_blockwise_bf16_fp4",

@@ -145,6 +145,19 @@ extern "C" int fmi_linear_bnb4_bf16(const void* x, const uint8_t* packed, const 
   return launch_gemm(&p, 1, (hipStream_t)stream);
 }
 
+extern "C" int fmi_linear_int8_bf16(const void* x, const int8_t* weight, const float* scb, const void* bias, void* y, int M, int N, int K,
+                                    fmi_epilogue epi, void* stream) {
+  if (!x || !weight || !scb || !y) return fail(FMI_ERR_INVALID, "linear_int8_bf16: null pointer");
+  if (M == 0 || N == 0) return FMI_OK;
+  if (N % 4) return fail(FMI_ERR_INVALID, "linear_int8_bf16: N must be a multiple of 4");
+  if (reinterpret_cast<uintptr_t>(weight) & 15) return fail(FMI_ERR_INVALID, "linear_int8_bf16: weight must be 16-byte aligned");
+  GemmProblem p{};
+  p.A = (const bf16_t*)x, p.bias = (const bf16_t*)bias, p.out = y;
+  p.Wq = reinterpret_cast<const uint8_t*>(weight), p.absmax = scb, p.q_blocksize = 0, p.q_type = 3;
+  p.M = M, p.N = N, p.K = K, p.lda = K, p.ldw = K, p.ldo = N, p.epi = epi_of(epi), p.alpha = 1.f;
+  return launch_gemm(&p, 1, (hipStream_t)stream);
+}
+
 extern "C" int fmi_quantize_rows_fp8(const void* x, int rows, int K, uint8_t* out, float* scale, void* stream) {
   if (rows == 0) return FMI_OK;
   if (!x || !out || !scale) return fail(FMI_ERR_INVALID, "quantize_rows_fp8: null pointer");

@@ -122,15 +122,15 @@ struct fmi_flux {
   float *mod_steps = nullptr, *vec_steps = nullptr;
   bf16_t* vec_steps_bf = nullptr;  // silu(vec_steps) in bf16: A operand of the modulation GEMM
   size_t mod_steps_rows = 0;
-  bf16_t* wscratch[2] = {nullptr, nullptr};
-  size_t wscratch_elems = 0;
   bool mod_gemm = true;  // fmi_flux_denoise: all steps' modulation vectors in one MFMA GEMM (else GEMV passes of 4 rows)
   bool fuse_qkv_relayout = true;  // QkNorm + RoPE + head/transposed relayout in the QKV GEMM's epilogue
-  // Quantised block linears: by default the fused dequant-GEMM reads the packed codes on every call (gemm_w4q.h).
+  // Quantised block linears (nf4 / fp4 / LLM.int8): by default the fused dequant-GEMM reads the packed codes on every call.
   // Opt-in cache (fmi_flux_set_quant_dense_cache): expand ONCE into the layer's slot of the BLOCKS arena — allocated
-  // on first use, 17 GB more — and run the dense kernels; LLM.int8 layers without the cache expand per call into a scratch.
+  // on first use, 17 GB more — and run the dense kernels.
   bool dense_cache = false;
   std::set<const void*> dense_ready;
+  bf16_t* wscratch[2] = {nullptr, nullptr};  // per-call expansion of LLM.int8 matrices at large M (densify)
+  size_t wscratch_elems = 0;
   // fp8 mode (fmi_flux_quantize_fp8)
   bool fp8 = false;
   char* fp8_arena = nullptr;
@@ -485,12 +485,19 @@ void with_gate(GemmProblem& p, const float* gate, int rows_per_batch, int bstrid
 // Quantised linears (BnbLinear::forward, bitsandbytes/mod.rs:293-312: "dequantize_w then matmul"):
 //   nf4 / fp4  -> the fused dequant-GEMM reads the packed codes (launch_gemm picks the kernel by M), nothing is expanded;
 //                 with the dense cache on, the matrix is expanded once into its slot of the BLOCKS / MOD arena instead;
-//   LLM.int8   -> expanded (w * SCB / 127) into the arena slot (cache on) or, per call, into a reusable scratch.
+//   LLM.int8   -> up to INT8_FUSED_MAX_ROWS rows: expanded (w * SCB / 127) by the GEMM's weight-tile stage (gemm_bf16_kernel<1>: VALU
+//                 expansion into the swizzled LDS image, bit-identical to the stand-alone dequant); above: stand-alone expansion
+//                 into a reusable scratch + the dense kernel (faster, see densify); with the dense cache on, expanded once.
+constexpr int INT8_FUSED_MAX_ROWS = 256;
 int densify(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s) {
   for (int i = 0; i < n && i < 2; ++i) {
     Dense* d = dn[i];
     if (!d || !p[i].q_type) continue;
-    if (p[i].q_type != 3 && !m->dense_cache) continue;  // fused 4-bit path
+    // LLM.int8 above INT8_FUSED_MAX_ROWS rows: expand per call into a scratch and run the dense kernel.  The fused int8 stage
+    // (VALU expansion inside the 8-wave kernel) is bit-identical but runs at 0.56-0.67x of the dense kernel, while one
+    // stand-alone expansion is amortised over all M rows (4608 x 21504 x 3072: 493 + 50 us against 765 us fused).
+    const bool int8_scratch = p[i].q_type == 3 && !m->dense_cache && p[i].M > INT8_FUSED_MAX_ROWS;
+    if (!m->dense_cache && !int8_scratch) continue;  // fused paths (launch_gemm picks the kernel)
     const size_t elems = (size_t)p[i].N * p[i].K;
     if (elems >= (1ull << 31)) return fail(FMI_ERR_UNSUPPORTED, "densify: weight too large");
     if (m->dense_cache) {

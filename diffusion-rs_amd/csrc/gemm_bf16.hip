@@ -80,13 +80,44 @@ __device__ __forceinline__ void stage_tile_dma(const bf16_t* __restrict g, int l
   }
 }
 
-// 4-bit weight tile: ROWS x 64 k = 32 packed bytes per row; thread t expands half a row.
+// x / 127 for the LLM.int8 expansion, correctly rounded without the IEEE division sequence: q = x * RN(1/127), one Newton
+// step on the residual.  Equal to x / 127.0f for EVERY finite f32 x with |x| >= 2^-118 (checked exhaustively over all 2^32
+// bit patterns on the host, tests/test_oracle_kats.py keeps a sampled version), so the fused path reproduces
+// dequantize_8bit (dequant.cu:205-214: w * SCB / 127) bit for bit at 3 instructions instead of ~10.
+__device__ __forceinline__ float div127(float x) {
+  const float r = 1.0f / 127.0f;
+  const float q = x * r;
+  return __builtin_fmaf(__builtin_fmaf(-127.0f, q, x), r, q);
+}
+
+// Quantised weight tile, expanded by the VALU into the swizzled bf16 LDS image: ROWS x 64 k; thread t expands half a row
+// (4-bit: 16 packed bytes; LLM.int8, q_type 3: 32 int8 with the row's SCB).
 template <int ROWS>
 __device__ __forceinline__ void stage_tile_q4(const GemmProblem& P, int n0, int k0, char* lds_tile, int tid) {
   const int row = tid >> 1, half = tid & 1;
   if (row >= ROWS) return;
   int n = n0 + row;
   n = n > P.N - 1 ? P.N - 1 : n;
+  if (P.q_type == 3) {
+    const uint4* src = reinterpret_cast<const uint4*>(P.Wq + (int64_t)n * P.K + k0 + half * 32);
+    const uint4 p0 = src[0], p1 = src[1];
+    const float scb = P.absmax[n];
+    const uint32_t w8[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    const int sw8 = (row >> 1) & 7;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // 4 chunks of 8 weights (two dwords each)
+      uint32_t out[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint32_t d = w8[2 * c + (b >> 1)];
+        const int i0 = (int)(d << (24 - 16 * (b & 1))) >> 24, i1 = (int)(d << (16 - 16 * (b & 1))) >> 24;  // sign-extended bytes 2(b&1), 2(b&1)+1
+        out[b] = pack_bf16x2(div127((float)i0 * scb), div127((float)i1 * scb));
+      }
+      const int slot = (half * 4 + c) ^ sw8;
+      *reinterpret_cast<uint4*>(lds_tile + row * 128 + slot * 16) = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+    return;
+  }
   const int64_t e0 = (int64_t)n * P.K + k0 + half * 32;  // first element index of this thread's 32 weights
   const uint4 pk = *reinterpret_cast<const uint4*>(P.Wq + (e0 >> 1));
   const float am = P.absmax[e0 / P.q_blocksize];
@@ -1195,7 +1226,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
     if (quant && conv) return fail(FMI_ERR_UNSUPPORTED, "launch_gemm: quantised convolution");
     if ((!conv && p.lda % 8) || (!quant && p.ldw % 8)) return fail(FMI_ERR_INVALID, "launch_gemm: lda/ldw must be multiples of 8 elements (16-byte rows)");
     if (conv && (p.cv_cin % 64 || p.K != p.cv_ks * p.cv_ks * p.cv_cin || !p.cv_zero)) return fail(FMI_ERR_INVALID, "launch_gemm: bad conv descriptor (Cin % 64, K = k*k*Cin)");
-    if (quant && (p.q_blocksize % 64 != 0 || p.q_blocksize <= 0)) return fail(FMI_ERR_INVALID, "launch_gemm: 4-bit blocksize must be a multiple of 64");
+    if (quant && p.q_type != 3 && (p.q_blocksize % 64 != 0 || p.q_blocksize <= 0)) return fail(FMI_ERR_INVALID, "launch_gemm: 4-bit blocksize must be a multiple of 64");
     if (p.qk_qh) {
       if (conv || bn != 256 || p.qk_D % 256 || p.qk_H * 128 != p.qk_D || 3 * p.qk_D > p.N || p.qk_rows <= 0 || p.qk_rows % 16 || p.qk_row_off % 16 || p.M % 16 ||
           p.qk_Lpad % 64 || !p.qk_kh || !p.qk_vt || !p.qk_wq || !p.qk_wk || !p.qk_pe || (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 7)))
@@ -1230,7 +1261,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   for (int i = 0; quant && i < nprob; ++i) {
     const GemmProblem& p = probs[i];
     const int kb = p.q_blocksize / BK;  // K tiles per absmax block
-    if (p.M < g_w4q_min_rows || p.K % p.q_blocksize || (kb & (kb - 1)) || (int64_t)p.N * p.K / 2 >= (1ll << 32)) w4q_ok = false;
+    if (p.q_type == 3 || p.M < g_w4q_min_rows || p.K % p.q_blocksize || (kb & (kb - 1)) || (int64_t)p.N * p.K / 2 >= (1ll << 32)) w4q_ok = false;
   }
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem& p = probs[i];

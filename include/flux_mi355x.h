@@ -376,6 +376,11 @@ int fmi_linear_bf16(const void* x, const void* w, const void* bias, void* y, int
 int fmi_linear_bnb4_bf16(const void* x, const uint8_t* packed, const float* absmax,
                          int blocksize, int quant_type, const void* bias, void* y, int M,
                          int N, int K, fmi_epilogue epi, void* stream);
+/* Same with an LLM.int8 weight (BnbLinear::Int8, bitsandbytes/mod.rs:104-134, 293-300): W = weight_i8 * SCB[row] / 127
+ * (dequantize_8bit, dequant.cu:205-214) expanded inside the GEMM's weight-tile stage, bit-identical to the stand-alone
+ * dequant followed by fmi_linear_bf16.  weight (N,K) int8 row-major, 16-byte aligned; scb (N) f32.  K % 64 == 0. */
+int fmi_linear_int8_bf16(const void* x, const int8_t* weight, const float* scb, const void* bias, void* y,
+                         int M, int N, int K, fmi_epilogue epi, void* stream);
 /* Row-wise dynamic e4m3 quantisation: scale[r] = max(absmax(x[r,:]), 1e-30) / 448,
  * out[r,k] = e4m3_rne(x[r,k] * (448 / max(absmax, 1e-30))).  x (rows,K) bf16, out (rows,K) u8, K % 8 == 0,
  * K <= 16384.  Used for weights (row = output channel) and activations (row = token). */

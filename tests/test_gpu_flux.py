@@ -200,6 +200,17 @@ def test_flux_int8_scb_blocks_match_dequantised_oracle(models, tmp_path):
     err = rel_l2(got, ref)
     print(f"int8 (SCB) forward, {nq} quantised linears: rel-L2 {err:.3e}")
     assert err <= 1e-2
+    # the default path expands the int8 tiles inside the GEMM; the dense cache expands each matrix once with the stand-alone
+    # dequant kernel and runs the dense GEMM: same bits
+    # a larger latent (1152 image rows: above INT8_FUSED_MAX_ROWS the int8 matrices are expanded per call into a scratch and the
+    # dense kernel runs; the 64 text rows stay on the fused stage)
+    img2, ids2, txt2, txt_ids2, y2 = flux_inputs(SMALL_FLUX, 2, (24, 24), 32, seed=14)
+    big = host(gq.forward(dev(img2), dev(ids2), dev(txt2, torch.bfloat16), dev(txt_ids2), dev(t), dev(y2), dev(g)))
+    gq.set_quant_dense_cache(True)
+    got2 = host(gq.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g)))
+    np.testing.assert_array_equal(got, got2)
+    big2 = host(gq.forward(dev(img2), dev(ids2), dev(txt2, torch.bfloat16), dev(txt_ids2), dev(t), dev(y2), dev(g)))
+    np.testing.assert_array_equal(big, big2)
 
 
 @pytest.mark.parametrize("B,S_hw,T", [(2, (8, 8), 32), (1, (8, 12), 40), (1, (16, 16), 48)])

@@ -185,6 +185,34 @@ def test_linear_bnb4_fused(env, qt, M, N, K, blocksize):
     assert rel_l2(host(y), ref) <= 4e-3
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(300, 256, 256, 0), (64, 192, 512, 1), (1000, 3072, 128, 0), (4608, 3072, 3072, 0), (257, 260, 8256, 0)])
+def test_linear_int8_fused_is_bit_identical_to_dequant_then_dense(env, M, N, K, epi):
+    """LLM.int8 weights (BnbLinear::Int8, bitsandbytes/mod.rs:293-300: dequantize_8bit, then matmul) expanded inside the GEMM's
+    weight-tile stage: the expansion reproduces w * SCB / 127 bit for bit (the division is a reciprocal multiply + one Newton step,
+    correctly rounded for every finite input), so the product equals dequant-then-fmi_linear_bf16 exactly, and the oracle within
+    the GEMM tolerance."""
+    torch, L, lib, orc = env["torch"], env["L"], env["lib"], env["orc"]
+    rng = np.random.default_rng(M + N + K)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    scb = np.abs(w).max(axis=1).astype(np.float32)
+    w8 = np.clip(np.rint(w / scb[:, None] * 127.0), -127, 127).astype(np.int8)
+    w8[0, :4] = [-128, 127, 0, -1]
+    x = bf16_round(rng.standard_normal((M, K)).astype(np.float32))
+    b = bf16_round(rng.standard_normal(N).astype(np.float32))
+    xd, wd, sd, bd = dev(x, torch.bfloat16), dev(w8), dev(scb), dev(b, torch.bfloat16)
+    y = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.fmi_linear_int8_bf16(_p(xd), _p(wd), _p(sd), _p(bd), _p(y), M, N, K, epi, None))
+    wdq = torch.empty((N, K), dtype=torch.bfloat16, device="cuda")
+    lib.dequantize_8bit_kernel_bf16(_p(wd), _p(sd), _p(wdq), N, K, N * K)
+    y2 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.fmi_linear_bf16(_p(xd), _p(wdq), _p(bd), _p(y2), M, N, K, epi, None))
+    torch.cuda.synchronize()
+    assert int((y.view(torch.int16) != y2.view(torch.int16)).sum()) == 0
+    if epi == 0 and M * N * K <= 1000 * 3072 * 128:
+        ref = orc.linear(x, orc.dequantize_8bit(w8.ravel(), scb, N, K, "bf16").reshape(N, K), b)
+        assert rel_l2(host(y), ref) <= 4e-3
+
+
 def test_pack_unpack_postprocess_bit_exact(env):
     torch, d, orc = env["torch"], env["d"], env["orc"]
     rng = np.random.default_rng(0)

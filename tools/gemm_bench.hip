@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../diffusion-rs_amd/csrc/gemm_bf16.hip"
+#include "../diffusion-rs_amd/csrc/bnb_dequant.hip"
 
 namespace fmi {
 static thread_local std::string g_err;
@@ -234,6 +235,50 @@ int main(int argc, char** argv) {
       hipMemcpy(&mis, d_mis, 8, hipMemcpyDeviceToHost);
       const double fl = 2.0 * s.M * s.N * s.K;
       printf("nf4 %-18s M=%5d N=%5d K=%5d  dense(on expanded W) %7.1f us %7.1f TF   fused nf4 %7.1f us %7.1f TF  (%.2fx)   mismatching elements %llu%s\n", s.name, s.M, s.N, s.K,
+             us[0], fl / us[0] * 1e-6, us[1], fl / us[1] * 1e-6, us[0] / us[1], mis, hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
+    }
+  }
+  if (getenv("FMI_Q8") && epi_kind != 2) {
+    // ---- fused LLM.int8 GEMM (weight tiles expanded by the VALU inside the 8-wave kernel): random int8 + SCB, reference =
+    // the stand-alone dequant kernel + the dense kernel
+    int8_t* W8;
+    float* scb;
+    hipMalloc((void**)&W8, maxW);
+    hipMalloc((void**)&scb, 65536 * 4);
+    fill_kernel<<<2048, 256>>>(reinterpret_cast<bf16_t*>(W8), maxW / 2, 9u);  // random bytes
+    {
+      std::vector<float> h(65536);
+      for (size_t i = 0; i < h.size(); ++i) h[i] = 0.01f + 0.00001f * (float)(i % 977);
+      hipMemcpy(scb, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    }
+    set_gemm_pingpong(true);
+    set_gemm_w4(true);
+    for (auto& s : shapes) {
+      launch_dequant_int8_scb_bf16(W8, scb, W, s.K, (int64_t)s.N * s.K, nullptr);
+      GemmProblem p{};
+      p.A = A, p.W = W, p.out = O2, p.M = s.M, p.N = s.N, p.K = s.K, p.lda = s.K, p.ldw = s.K, p.ldo = s.N, p.epi = epi_kind == 1 ? EPI_GELU_BF16 : EPI_STORE_BF16, p.alpha = 1.f;
+      if (epi_kind) p.bias = bias;
+      GemmProblem q = p;
+      q.out = O, q.W = nullptr, q.Wq = reinterpret_cast<const uint8_t*>(W8), q.absmax = scb, q.q_blocksize = 0, q.q_type = 3;
+      double us[2];
+      for (int arm = 0; arm < 2; ++arm) {
+        GemmProblem& r = arm ? q : p;
+        for (int i = 0; i < 2; ++i) launch_gemm(&r, 1, nullptr);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, nullptr);
+        for (int i = 0; i < iters; ++i) launch_gemm(&r, 1, nullptr);
+        hipEventRecord(e1, nullptr);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        us[arm] = ms / iters * 1e3;
+      }
+      hipMemset(d_mis, 0, 8);
+      count_mismatch<<<1024, 256>>>(O, O2, (size_t)s.M * s.N, d_mis);
+      unsigned long long mis = 0;
+      hipMemcpy(&mis, d_mis, 8, hipMemcpyDeviceToHost);
+      const double fl = 2.0 * s.M * s.N * s.K;
+      printf("int8 %-18s M=%5d N=%5d K=%5d  dense(on expanded W) %7.1f us %7.1f TF   fused int8 %7.1f us %7.1f TF  (%.2fx)   mismatching elements %llu%s\n", s.name, s.M, s.N, s.K,
              us[0], fl / us[0] * 1e-6, us[1], fl / us[1] * 1e-6, us[0] / us[1], mis, hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
     }
   }
