@@ -326,7 +326,13 @@ def main():
 
         fq = d.FluxModel(d.FLUX_DEV, local_rank)
         fill_flux(fq, "nf4")
-        leg(fq, wl, "nf4_c3", KDESC["nf4"], 2500.0, "bf16 MFMA on nf4 weights (bitsandbytes blocksize 64; every block + modulation linear packed, expanded inside the GEMM)")
+        # default policy (flux_model.hip: densify): only the packed codes are resident; the 4096 / 4608-row block linears expand per call
+        # into a 264 MB scratch (stand-alone dequant kernel) and run the dense GEMM, smaller launches multiply from the packed codes
+        leg(fq, wl, "nf4_c3", "dequant4_kernel + gemm_pp_kernel / gemm_w4_kernel (nf4 block linears expanded per call into a scratch, then the dense bf16 MFMA GEMM; "
+            "the expansions are inside the timed phases; dense-equivalent FLOPs)", 2500.0,
+            "bf16 MFMA on nf4 weights (bitsandbytes blocksize 64; every block + modulation linear packed; no bf16 copy resident)")
+        fq.set_quant_dense_cache(2)  # every launch on the fused dequant-GEMM (gemm_w4q_kernel): bit-identical, 0.8x the dense kernel per launch
+        leg(fq, wl, "nf4_c3_fused", KDESC["nf4"], 2500.0, "bf16 MFMA on nf4 weights, every block linear expanded inside the GEMM (fmi_flux_set_quant_dense_cache(2))")
         fq.close()
         del fq
         flux.quantize_fp8()  # last: the headline model itself switches to the fp8 path

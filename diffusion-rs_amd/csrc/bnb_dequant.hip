@@ -9,6 +9,9 @@
 // Semantics are bit-exact with dequant.cu: high nibble first, value = LUT[nibble] * absmax
 // (nf4) / tree(nibble) * absmax * sign (fp4) / code[byte] * absmax (int8) in f32, one RNE
 // rounding to the output type.
+#include <algorithm>
+#include <type_traits>
+
 #include "common.h"
 
 namespace fmi {
@@ -92,6 +95,37 @@ __global__ __launch_bounds__(256) void dequant4_kernel(const uint8_t* __restrict
   }
 }
 
+// Streaming form of the 4-bit expansion for the denoise loop (flux_model.hip: densify() expands a matrix right before its GEMM,
+// 152 times per step): bf16 out, power-of-two blocksize, n % 8 == 0.  A lane takes ONE packed dword (8 weights) per iteration and
+// stores 16 bytes, so a wave-instruction reads 256 contiguous bytes and writes 1 KiB contiguous (the general kernel above writes
+// 16-byte pieces at a 64-byte lane stride and divides by the blocksize per element).  Same arithmetic, so the same bits:
+// value = LUT[nibble] * absmax (nf4) / tree(nibble) * absmax * sign (fp4), one RNE rounding — the table holds both nibbles of a byte.
+template <int QT>
+__global__ __launch_bounds__(256) void dequant4_stream_bf16_kernel(const uint32_t* __restrict A, const float* __restrict absmax, uint4* __restrict out,
+                                                                   int dwords_per_block_shift, int64_t ndwords) {
+  __shared__ float2 lut[256];  // byte -> (value of the high nibble, value of the low nibble) for absmax = 1
+  {
+    const unsigned b = threadIdx.x;
+    lut[b] = QT == 2 ? make_float2(kNF4d[b >> 4], kNF4d[b & 15]) : make_float2(dq_fp4_tree(b >> 4, 1.0f), dq_fp4_tree(b & 15, 1.0f));
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ndwords; g += stride) {
+    const uint32_t w = A[g];
+    const float am = absmax[g >> dwords_per_block_shift];
+    uint32_t o[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float2 v = lut[(w >> (8 * b)) & 0xffu];
+      float hi, lo;
+      if (QT == 2) hi = v.x * am, lo = v.y * am;
+      else hi = dq_fp4_tree(((w >> (8 * b)) >> 4) & 15u, am), lo = dq_fp4_tree((w >> (8 * b)) & 15u, am);  // (abs * absmax) * sign: the order matters for the bits
+      o[b] = (uint32_t)f32_to_bf16(hi) | ((uint32_t)f32_to_bf16(lo) << 16);
+    }
+    out[g] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // General8bit: out[i] = code[A[i]] * absmax[i / blocksize]  (dequant.cu:132-137). 16 outputs per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void dequant8_kernel(const float* __restrict code, const uint8_t* __restrict A,
@@ -115,6 +149,14 @@ __global__ __launch_bounds__(256) void dequant_int8_scb_kernel(const int8_t* __r
 template <typename T, int QT>
 void launch_dq4(const uint8_t* A, const float* absmax, void* out, int blocksize, int n, void* stream) {
   if (n <= 0) return;
+  if (std::is_same<T, bf16_bits>::value && n >= (1 << 20) && n % 8 == 0 && blocksize >= 8 && (blocksize & (blocksize - 1)) == 0 &&
+      (reinterpret_cast<uintptr_t>(A) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const int64_t ndw = n / 8;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(ndw, 256 * 4), 8192);
+    hipLaunchKernelGGL((dequant4_stream_bf16_kernel<QT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(A), absmax,
+                       reinterpret_cast<uint4*>(out), __builtin_ctz(blocksize / 8), ndw);
+    return;
+  }
   const int64_t nbytes = ((int64_t)n + 1) / 2;
   const unsigned grid = (unsigned)cdiv64(nbytes, 256 * 16);
   hipLaunchKernelGGL((dequant4_kernel<T, QT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, A, absmax, (T*)out, blocksize / 2, n);

@@ -124,12 +124,14 @@ struct fmi_flux {
   size_t mod_steps_rows = 0;
   bool mod_gemm = true;  // fmi_flux_denoise: all steps' modulation vectors in one MFMA GEMM (else GEMV passes of 4 rows)
   bool fuse_qkv_relayout = true;  // QkNorm + RoPE + head/transposed relayout in the QKV GEMM's epilogue
-  // Quantised block linears (nf4 / fp4 / LLM.int8): by default the fused dequant-GEMM reads the packed codes on every call.
-  // Opt-in cache (fmi_flux_set_quant_dense_cache): expand ONCE into the layer's slot of the BLOCKS arena — allocated
+  // Quantised block linears (nf4 / fp4 / LLM.int8): only the packed codes are resident; small launches multiply from them
+  // (fused dequant-GEMM), large ones expand per call into a scratch and run the dense kernel (densify()).
+  // Opt-in cache (fmi_flux_set_quant_dense_cache(1)): expand ONCE into the layer's slot of the BLOCKS arena — allocated
   // on first use, 17 GB more — and run the dense kernels.
   bool dense_cache = false;
+  int quant_mode = 0;  // 0: by size (fused below the row thresholds of densify(), per-call expansion above); 1: dense cache; 2: always fused
   std::set<const void*> dense_ready;
-  bf16_t* wscratch[2] = {nullptr, nullptr};  // per-call expansion of LLM.int8 matrices at large M (densify)
+  bf16_t* wscratch[2] = {nullptr, nullptr};  // per-call expansion of quantised matrices at large M (densify)
   size_t wscratch_elems = 0;
   // fp8 mode (fmi_flux_quantize_fp8)
   bool fp8 = false;
@@ -488,16 +490,24 @@ void with_gate(GemmProblem& p, const float* gate, int rows_per_batch, int bstrid
 //   LLM.int8   -> up to INT8_FUSED_MAX_ROWS rows: expanded (w * SCB / 127) by the GEMM's weight-tile stage (gemm_bf16_kernel<1>: VALU
 //                 expansion into the swizzled LDS image, bit-identical to the stand-alone dequant); above: stand-alone expansion
 //                 into a reusable scratch + the dense kernel (faster, see densify); with the dense cache on, expanded once.
+// Above these row counts a quantised matrix is expanded per call into a reusable scratch (2 x the largest fused matrix,
+// 264 MB) and the dense kernel runs — measured faster than the fused kernels, because ONE stand-alone expansion is amortised
+// over all M rows while the fused expansion is repeated by every row tile:
+//   LLM.int8  fused stage 0.56-0.67x dense; 4608 x 21504 x 3072: 493 + 50 us against 765 us fused   -> from 257 rows
+//   nf4 / fp4 fused kernel 0.77-0.87x dense; same shape: 498 + 35 us against 598 us fused            -> from 1536 rows
+// (below, the GEMM is short or bound by weight bytes and the packed read wins).  Either way only the packed codes are resident.
 constexpr int INT8_FUSED_MAX_ROWS = 256;
+constexpr int Q4_FUSED_MAX_ROWS = 1535;
 int densify(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s) {
+  // one decision per launch group (the img + txt problems of a double block stay one grouped launch)
+  bool scratch = false;
+  for (int i = 0; i < n && i < 2; ++i)
+    if (dn[i] && p[i].q_type && m->quant_mode == 0)
+      scratch = scratch || p[i].M > (p[i].q_type == 3 ? INT8_FUSED_MAX_ROWS : Q4_FUSED_MAX_ROWS);
   for (int i = 0; i < n && i < 2; ++i) {
     Dense* d = dn[i];
     if (!d || !p[i].q_type) continue;
-    // LLM.int8 above INT8_FUSED_MAX_ROWS rows: expand per call into a scratch and run the dense kernel.  The fused int8 stage
-    // (VALU expansion inside the 8-wave kernel) is bit-identical but runs at 0.56-0.67x of the dense kernel, while one
-    // stand-alone expansion is amortised over all M rows (4608 x 21504 x 3072: 493 + 50 us against 765 us fused).
-    const bool int8_scratch = p[i].q_type == 3 && !m->dense_cache && p[i].M > INT8_FUSED_MAX_ROWS;
-    if (!m->dense_cache && !int8_scratch) continue;  // fused paths (launch_gemm picks the kernel)
+    if (!m->dense_cache && !scratch) continue;  // fused paths (launch_gemm picks the kernel)
     const size_t elems = (size_t)p[i].N * p[i].K;
     if (elems >= (1ull << 31)) return fail(FMI_ERR_UNSUPPORTED, "densify: weight too large");
     if (m->dense_cache) {
@@ -517,7 +527,9 @@ int densify(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s)
         }
         m->wscratch_elems = want;
       }
-      FMI_TRY(launch_dequant_int8_scb_bf16(reinterpret_cast<const int8_t*>(p[i].Wq), p[i].absmax, m->wscratch[i], p[i].K, (int64_t)elems, s));
+      if (p[i].q_type == 3) FMI_TRY(launch_dequant_int8_scb_bf16(reinterpret_cast<const int8_t*>(p[i].Wq), p[i].absmax, m->wscratch[i], p[i].K, (int64_t)elems, s));
+      else if (p[i].q_type == 2) dequantize_blockwise_bf16_nf4(nullptr, p[i].Wq, p[i].absmax, m->wscratch[i], p[i].q_blocksize, (int)elems, s);
+      else dequantize_blockwise_bf16_fp4(nullptr, p[i].Wq, p[i].absmax, m->wscratch[i], p[i].q_blocksize, (int)elems, s);
       p[i].W = m->wscratch[i];
     }
     p[i].ldw = p[i].K;
@@ -1197,10 +1209,12 @@ extern "C" int fmi_flux_set_modulation_gemm(fmi_flux* m, int enable) {
   m->mod_gemm = enable != 0;
   return FMI_OK;
 }
-// keep (1, default) or drop (0: per-call scratch expansion) the expanded bf16 copies of quantised block linears
-extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int enable) {
+// how quantised block linears are multiplied: 0 (default) by size, 1 expanded once into bf16 copies (dense cache), 2 always fused
+extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int mode) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
-  m->dense_cache = enable != 0;
+  if (mode < 0 || mode > 2) return fail(FMI_ERR_INVALID, "set_quant_dense_cache: mode must be 0 (by size), 1 (dense cache) or 2 (always fused)");
+  m->dense_cache = mode == 1;
+  m->quant_mode = mode;
   m->dense_ready.clear();
   return FMI_OK;
 }

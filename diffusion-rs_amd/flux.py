@@ -146,10 +146,11 @@ class FluxModel:
     def size_in_bytes(self) -> int:
         return self.lib.fmi_flux_size_in_bytes(self.h)
 
-    def set_quant_dense_cache(self, on: bool):
-        """Quantised linears: False (default) = fused dequant-GEMM on the packed codes, no bf16 copy resident;
-        True = expand each matrix once into the bf16 arena and run the dense kernels."""
-        L.check(self.lib.fmi_flux_set_quant_dense_cache(self.h, int(on)))
+    def set_quant_dense_cache(self, mode):
+        """Quantised linears: 0 / False (default) = only the packed codes are resident: fused dequant-GEMM for small launches,
+        per-call expansion into a 264 MB scratch + dense GEMM for large ones (whichever is measured faster, DESIGN 4.5);
+        1 / True = expand each matrix once into the bf16 arena and run the dense kernels; 2 = always the fused kernels."""
+        L.check(self.lib.fmi_flux_set_quant_dense_cache(self.h, int(mode)))
 
     # ---- the weights as flat device buffers (multi-GPU broadcast, dist.broadcast_state)
     def state_export(self) -> bytes:

@@ -122,15 +122,17 @@ int fmi_flux_set_linear_bnb4(fmi_flux*, const char* prefix, const uint8_t* packe
 /* Number of tensors still missing (never set); names via fmi_flux_missing_name(i). */
 /* LLM.int8 linear (BnbLinear::Int8, bitsandbytes/mod.rs:104-134,293-300): weight int8 (out,in) row
  * major + SCB f32 (out); effective weight = w * SCB[row] / 127 (dequant.cu:205-214), expanded to
- * bf16 right before the layer's GEMM.  Same prefix rules as fmi_flux_set_linear_bnb4. */
+ * bf16 inside the layer's GEMM (small launches) or right before it (see fmi_flux_set_quant_dense_cache).
+ * Same prefix rules as fmi_flux_set_linear_bnb4. */
 int fmi_flux_set_linear_int8(fmi_flux*, const char* prefix, const int8_t* weight, const float* scb, int out_features, int in_features);
-/* Quantised block / modulation linears.  Default (0): nf4 / fp4 matrices are multiplied straight from the
- * packed codes by the fused dequant-GEMM (the expansion is an LDS stage of the GEMM, gemm_w4q.h) and no
- * bf16 copy of them exists (an nf4 FLUX.1-dev occupies ~6.7 GB); LLM.int8 matrices are expanded into a
- * scratch before every GEMM call.  1: each quantised matrix is expanded ONCE into its slot of the bf16
- * arena (allocated on first use) and the dense kernels run — BnbLinear::forward's dequantize-then-matmul
- * (bitsandbytes/mod.rs:301-312) amortised over the denoise loop, at the price of the bf16 footprint. */
-int fmi_flux_set_quant_dense_cache(fmi_flux*, int enable);
+/* Quantised block / modulation linears (BnbLinear::forward = dequantize, then matmul: bitsandbytes/mod.rs:293-312).
+ * Only the packed codes are resident (an nf4 FLUX.1-dev occupies ~7 GB).  mode 0 (default): by size — launches of up
+ * to 1535 rows (nf4 / fp4) or 256 rows (LLM.int8) multiply straight from the codes with the fused dequant-GEMM (the
+ * expansion is an LDS stage of the GEMM); larger launches expand the matrix per call into a reusable scratch (2 x the
+ * largest fused matrix) and run the dense kernel, which is measured faster there.  mode 1: each quantised matrix is
+ * expanded ONCE into its slot of the bf16 arena (allocated on first use, +16 GB).  mode 2: every launch on the fused
+ * kernels.  All three produce the same bits. */
+int fmi_flux_set_quant_dense_cache(fmi_flux*, int mode);
 /* Process-wide: rows from which 4-bit GEMMs use the one-wave-per-SIMD fused kernel (default 256). */
 int fmi_set_bnb4_onewave_min_rows(int rows);
 /* Test hook of the attention kernel's deferred-rescale branch: 0 = rescale on every key tile, else the

@@ -123,8 +123,9 @@ def test_fused_nf4_gemm_is_deterministic_and_survives_small_row_dispatch(env):
 
 def test_nf4_model_at_c3_tokens_fused_equals_dense_cache_and_holds_no_bf16_copy(env):
     """FLUX.1 width (D = 3072) with nf4 block AND modulation linears at the C3 token counts (S = 4096, T = 512), one
-    double + one single block: the default path (fused dequant-GEMM, packed weights only) and the opt-in expanded cache
-    give the same prediction bit for bit, and only the cache allocates the bf16 arenas."""
+    double + one single block: the fused dequant-GEMM (packed weights only), the default policy (per-call expansion into a
+    scratch for launches this large) and the opt-in expanded cache give the same prediction bit for bit, and only the cache
+    allocates the bf16 arenas."""
     torch, d, L, lib, orc = env
     from tests.test_gpu_fullsize import WIDE
     from tests.util import flux_inputs
@@ -151,15 +152,22 @@ def test_nf4_model_at_c3_tokens_fused_equals_dense_cache_and_holds_no_bf16_copy(
     t = np.array([0.7], np.float32)
     gd = np.array([3.5], np.float32)
     args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(gd))
+    gm.set_quant_dense_cache(2)  # every launch on the fused kernels
     a = host(gm.forward(*args))
     bufs = gm.state_buffers()
     assert bufs[1][1] == 0 and bufs[2][1] == 0 and bufs[3][1] > 0  # no MOD / BLOCKS (bf16) arena, only BASE + Q4
+    fused_bytes = gm.size_in_bytes()
+    gm.set_quant_dense_cache(0)  # default: by size — these 4096 / 4608-row launches expand per call into the scratch
+    c = host(gm.forward(*args))
+    bufs = gm.state_buffers()
+    assert bufs[1][1] == 0 and bufs[2][1] == 0
     packed_bytes = gm.size_in_bytes()
-    gm.set_quant_dense_cache(True)
+    assert 0 < packed_bytes - fused_bytes <= 2 * (3 * 3072 + 12288) * 3072 * 2 + 4096  # the two scratch matrices, nothing else
+    gm.set_quant_dense_cache(1)
     b = host(gm.forward(*args))
     bufs = gm.state_buffers()
     assert bufs[1][1] > 0 and bufs[2][1] > 0
-    assert np.isfinite(a).all() and np.array_equal(a, b)
-    print(f"nf4 D=3072 1+1 blocks at S=4096,T=512: fused == dense-cache bit for bit; resident {packed_bytes / 2**20:.0f} MiB packed vs "
-          f"{gm.size_in_bytes() / 2**20:.0f} MiB with the expanded cache")
+    assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, c)
+    print(f"nf4 D=3072 1+1 blocks at S=4096,T=512: fused == per-call expansion == dense cache bit for bit; resident {fused_bytes / 2**20:.0f} MiB fused, "
+          f"{packed_bytes / 2**20:.0f} MiB with the scratch, {gm.size_in_bytes() / 2**20:.0f} MiB with the expanded cache")
     gm.close()

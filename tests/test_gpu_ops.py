@@ -125,9 +125,10 @@ _TD = {"f32": "float32", "f16": "float16", "bf16": "bfloat16"}
 
 @pytest.mark.parametrize("odt", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("qt", ["nf4", "fp4"])
-@pytest.mark.parametrize("n,blocksize", [(64 * 64, 64), (3072 * 40, 64), (1000, 128), (4096 * 3 + 2, 4096), (31, 64)])
+@pytest.mark.parametrize("n,blocksize", [(64 * 64, 64), (3072 * 40, 64), (1000, 128), (4096 * 3 + 2, 4096), (31, 64), (3072 * 1024, 64), (2048 * 1024 + 8, 128)])
 def test_dequant_4bit_bit_exact(env, odt, qt, n, blocksize):
-    """Integer / LUT work: bit-exact vs the oracle (CUDA-kernel semantics of dequant.cu)."""
+    """Integer / LUT work: bit-exact vs the oracle (CUDA-kernel semantics of dequant.cu).  The two sizes above 2^20 elements
+    take the streaming kernel in bf16 (the per-call expansion of the denoise loop), the others the general one."""
     torch, lib, orc = env["torch"], env["lib"], env["orc"]
     rng = np.random.default_rng(n)
     A = rng.integers(0, 256, (n + 1) // 2, dtype=np.uint8)
