@@ -15,12 +15,16 @@ lib: $(LIB)
 oracle:
 	$(MAKE) -C oracle -s
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h include/flux_mi355x.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h $(CSRC)/attention_w4_loop.inc include/flux_mi355x.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -Wl,-soname,libflux_mi355x.so
+
+# the KV loop of attention_w4_kernel is generated assembly (committed; regenerate after editing the generator)
+$(CSRC)/attention_w4_loop.inc: tools/gen_attention_w4_loop.py
+	python3 tools/gen_attention_w4_loop.py > /dev/null
 
 clean:
 	rm -rf build $(LIB)
