@@ -1064,13 +1064,18 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
   }
   const char* const a_base = reinterpret_cast<const char*>(P.A);
   const char* const w_base = reinterpret_cast<const char*>(P.W);
+  // LDS-DMA in the scalar-base form (SGPR pair + 32-bit lane offset), written as asm: from the builtin hipcc forms a 64-bit
+  // per-lane address with a v_lshl_add_u64 in front of every piece inside this loop (+1-2 % on the K loop, tools/gemm_bench).
+  // m0 = LDS destination of the 1-KiB piece; one wait state between the m0 write and the load.
   auto dma_a = [&](int kt, int i) {
     const char* base = a_base + (int64_t)kt * (BK * 2);
-    __builtin_amdgcn_global_load_lds((glb_void*)(base + a_off[i]), (lds_void*)(smem + A_RING + (kt & 1) * TILE + (wave * 8 + i) * 1024), 16, 0, 0);
+    const uint32_t l = lds0 + A_RING + (kt & 1) * TILE + (wave * 8 + i) * 1024;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(a_off[i]), "s"(base), "s"(l) : "memory");
   };
   auto dma_w = [&](int kt, int slot, int i) {
     const char* base = w_base + (int64_t)kt * (BK * 2);
-    __builtin_amdgcn_global_load_lds((glb_void*)(base + w_off[i]), (lds_void*)(smem + W_RING + slot * TILE + (wave * 8 + i) * 1024), 16, 0, 0);
+    const uint32_t l = lds0 + W_RING + slot * TILE + (wave * 8 + i) * 1024;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(w_off[i]), "s"(base), "s"(l) : "memory");
   };
   auto sync_all = [&]() {
     __builtin_amdgcn_sched_barrier(0);
