@@ -59,6 +59,40 @@ def test_full_width_blocks_match_oracle():
     gm.close()
 
 
+def test_c1_schnell_true_width_reduced_depth_matches_oracle():
+    """BASELINE configs[0] (C1: FLUX.1-schnell 256x256, 4 steps, batch 1) at the model's TRUE width — D = 3072, 24 heads, 4096-wide T5
+    and 768-wide CLIP inputs, no guidance embedder, T = 256 padded text tokens, S = 256 image tokens, the non-dynamic shift = 1.0
+    schedule — with the depth cut to 2 double + 4 single blocks so that the CPU oracle finishes in seconds (the full 19 + 38 depth
+    is covered at D = 512 by tests/test_gpu_fulldepth.py): the whole 4-step Euler loop against the oracle's."""
+    import torch
+    import diffusion_rs_amd as d
+    from oracle import oracle as orc
+    cfg = dict(WIDE, num_layers=2, num_single_layers=4, guidance_embeds=False)
+    sd = d.synth.flux_state_dict_numpy(cfg, seed=31)
+    assert not any("guidance_embedder" in k for k in sd)
+    gm = d.FluxModel(cfg)
+    gm.load_state_dict(sd)
+    assert not gm.is_guidance()
+    om = orc.Flux(cfg)
+    om.load(sd)
+    B, T = 1, 256
+    rng = np.random.default_rng(32)
+    lat = rng.standard_normal((B, 16, 32, 32)).astype(np.float32)  # 256x256 image -> 32x32 latent -> S = 256
+    t5 = bf16_round(rng.standard_normal((B, T, cfg["joint_attention_dim"])).astype(np.float32))
+    clip = rng.standard_normal((B, cfg["pooled_projection_dim"])).astype(np.float32)
+    img, ids = orc.pack_latents(lat)
+    assert img.shape[1] == 256
+    txt_ids = np.zeros((B, T, 3), np.float32)
+    ts = orc.get_timesteps(4, False, 0.0, 1.0)  # scheduler.rs:22-51 with use_dynamic_shifting = false, shift = 1.0
+    np.testing.assert_allclose(ts, [1.0, 0.75, 0.5, 0.25, 0.0], atol=1e-12)
+    ref = om.denoise(img, ids, t5, txt_ids, clip, None, ts)
+    got = host(gm.denoise(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(clip), None, ts))
+    err, moved = rel_l2(got, ref), rel_l2(ref, img)
+    print(f"C1 at true width (D=3072, 2+4 blocks, S=T=256, 4 steps): latents rel-L2 {err:.3e} (the loop moved them by {moved:.3f})")
+    assert np.isfinite(got).all() and err <= 3e-2
+    gm.close()
+
+
 @pytest.fixture(scope="module")
 def lib_env():
     import torch
