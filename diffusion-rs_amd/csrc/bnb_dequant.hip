@@ -146,6 +146,33 @@ __global__ __launch_bounds__(256) void dequant_int8_scb_kernel(const int8_t* __r
   for (int i = 0; i < 8 && i0 + i < n; ++i) out[i0 + i] = cvt_out<T>(((float)w[i0 + i] * scb[(i0 + i) / col]) / 127.f);
 }
 
+// Streaming form of the LLM.int8 expansion for the denoise loop (densify() expands a matrix right before its GEMM when the launch
+// has more than 256 rows): bf16 out, col % 8 == 0.  A lane takes 8 weights (one 8-byte load) and stores 16 bytes — 1 KiB contiguous
+// per wave-instruction — with the row's SCB read once and x / 127 as div127() (gemm_bf16.hip: correctly rounded, so the same bits as
+// the general kernel's IEEE division; that kernel divides twice per element and reaches ~1 TB/s).
+__device__ __forceinline__ float dq_div127(float x) {
+  const float r = 1.0f / 127.0f;
+  const float q = x * r;
+  return __builtin_fmaf(__builtin_fmaf(-127.0f, q, x), r, q);
+}
+__global__ __launch_bounds__(256) void dequant_int8_stream_bf16_kernel(const uint2* __restrict w, const float* __restrict scb, uint4* __restrict out,
+                                                                       uint32_t k8_per_row, uint32_t n8) {
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < n8; g += stride) {
+    const uint2 p = w[g];
+    const float s = scb[g / k8_per_row];
+    const uint32_t d[2] = {p.x, p.y};
+    uint32_t o[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t dw = d[b >> 1];
+      const int i0 = (int)(dw << (24 - 16 * (b & 1))) >> 24, i1 = (int)(dw << (16 - 16 * (b & 1))) >> 24;
+      o[b] = (uint32_t)f32_to_bf16(dq_div127((float)i0 * s)) | ((uint32_t)f32_to_bf16(dq_div127((float)i1 * s)) << 16);
+    }
+    out[g] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 template <typename T, int QT>
 void launch_dq4(const uint8_t* A, const float* absmax, void* out, int blocksize, int n, void* stream) {
   if (n <= 0) return;
@@ -167,9 +194,14 @@ void launch_dq8(const float* code, const uint8_t* A, const float* absmax, void* 
   hipLaunchKernelGGL((dequant8_kernel<T>), dim3((unsigned)cdiv64(n, 256 * 16)), dim3(256), 0, (hipStream_t)stream, code, A, absmax, (T*)out,
                      blocksize, n);
 }
+int launch_dequant_int8_scb_bf16(const int8_t* w, const float* scb, bf16_t* out, int col, int64_t n, hipStream_t stream);
 template <typename T>
 void launch_scb(const int8_t* w, const float* scb, void* out, int col, int n) {
   if (n <= 0) return;
+  if (std::is_same<T, bf16_bits>::value && n >= (1 << 20)) {  // large bf16 expansions: the streaming kernel when eligible (same bits)
+    launch_dequant_int8_scb_bf16(w, scb, (bf16_t*)out, col, n, nullptr);
+    return;
+  }
   // legacy default stream, like the reference (dequant.cu:221)
   hipLaunchKernelGGL((dequant_int8_scb_kernel<T>), dim3((unsigned)cdiv64(n, 256 * 8)), dim3(256), 0, (hipStream_t) nullptr, w, scb, (T*)out, col, n);
 }
@@ -178,6 +210,14 @@ void launch_scb(const int8_t* w, const float* scb, void* out, int col, int n) {
 int launch_dequant_int8_scb_bf16(const int8_t* w, const float* scb, bf16_t* out, int col, int64_t n, hipStream_t stream) {
   if (n <= 0) return FMI_OK;
   if (n >= (1ll << 31)) return fail(FMI_ERR_UNSUPPORTED, "dequant_int8_scb: more than 2^31 elements");
+  if (n >= (1 << 20) && col % 8 == 0 && (reinterpret_cast<uintptr_t>(w) & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const uint32_t n8 = (uint32_t)(n / 8);
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64(n8, 256 * 4), 8192);
+    hipLaunchKernelGGL(dequant_int8_stream_bf16_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const uint2*>(w), scb, reinterpret_cast<uint4*>(out),
+                       (uint32_t)(col / 8), n8);
+    FMI_LAUNCH_CHECK();
+    return FMI_OK;
+  }
   hipLaunchKernelGGL((dequant_int8_scb_kernel<bf16_bits>), dim3((unsigned)cdiv64(n, 256 * 8)), dim3(256), 0, stream, w, scb, (bf16_bits*)out, col, (int)n);
   FMI_LAUNCH_CHECK();
   return FMI_OK;

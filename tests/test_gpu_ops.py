@@ -155,16 +155,16 @@ def test_dequant_int8_bit_exact(env, odt):
     getattr(lib, f"dequantize_blockwise_{odt}_int8")(_p(cd), _p(Ad), _p(amd), _p(out), blocksize, n, None)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(host(out).view(np.uint32), ref.view(np.uint32))
-    # LLM.int8 SCB path
-    row, col = 37, 100
-    w = rng.integers(-128, 128, row * col, dtype=np.int8)
-    scb = (rng.random(row) * 2).astype(np.float32)
-    ref = orc.dequantize_8bit(w, scb, row, col, odt)
-    out = torch.zeros(row * col, dtype=getattr(torch, _TD[odt]), device="cuda")
-    wd, sd = dev(w), dev(scb)
-    getattr(lib, f"dequantize_8bit_kernel_{odt}")(_p(wd), _p(sd), _p(out), row, col, row * col)
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(host(out).view(np.uint32), ref.view(np.uint32))
+    # LLM.int8 SCB path (the second shape is large enough for the streaming bf16 kernel of the denoise loop)
+    for row, col in ((37, 100), (1024, 3072)):
+        w = rng.integers(-128, 128, row * col, dtype=np.int8)
+        scb = (rng.random(row) * 2).astype(np.float32)
+        ref = orc.dequantize_8bit(w, scb, row, col, odt)
+        out = torch.zeros(row * col, dtype=getattr(torch, _TD[odt]), device="cuda")
+        wd, sd = dev(w), dev(scb)
+        getattr(lib, f"dequantize_8bit_kernel_{odt}")(_p(wd), _p(sd), _p(out), row, col, row * col)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(host(out).view(np.uint32), ref.view(np.uint32))
 
 
 @pytest.mark.parametrize("qt", ["nf4", "fp4"])
