@@ -57,6 +57,64 @@ __global__ __launch_bounds__(512, 2) void mfma_tile(const uint4* in, float* out,
   out[(size_t)blockIdx.x * blockDim.x + tid] = s;
 }
 
+// The vendor library's choice: v_mfma_f32_16x16x32_bf16 on an NA x NB tile of 16 x 16 accumulators (4 registers each), the A
+// fragment held across NB consecutive MFMAs.  Same FLOPs per instruction-pair, half the pipe time per instruction.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int NA, int NB>
+__global__ __launch_bounds__(256, 1) void mfma_tile16(const uint4* in, float* out, int iters) {
+  const int tid = threadIdx.x;
+  bf16x8_t a[NA], b[NB];
+  for (int i = 0; i < NA; ++i) a[i] = __builtin_bit_cast(bf16x8_t, in[(tid + 64 * i) & 1023]);
+  for (int j = 0; j < NB; ++j) b[j] = __builtin_bit_cast(bf16x8_t, in[(tid + 64 * j + 512) & 1023]);
+  f32x4 acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    asm volatile("" : "+v"(a[0]));
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) s += acc[i][j][0] + acc[i][j][3];
+  out[(size_t)blockIdx.x * blockDim.x + tid] = s;
+}
+template <int NA, int NB>
+__global__ __launch_bounds__(256, 1) void mfma_tile32(const uint4* in, float* out, int iters) {
+  const int tid = threadIdx.x;
+  bf16x8_t a[NA], b[NB];
+  for (int i = 0; i < NA; ++i) a[i] = __builtin_bit_cast(bf16x8_t, in[(tid + 64 * i) & 1023]);
+  for (int j = 0; j < NB; ++j) b[j] = __builtin_bit_cast(bf16x8_t, in[(tid + 64 * j + 512) & 1023]);
+  f32x16 acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    asm volatile("" : "+v"(a[0]));
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) s += acc[i][j][0] + acc[i][j][7];
+  out[(size_t)blockIdx.x * blockDim.x + tid] = s;
+}
+
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 20000;
   uint4* in;
@@ -97,5 +155,21 @@ int main(int argc, char** argv) {
   run(mfma_loop<2>, "2 accumulators, 2 waves per SIMD", 2, 256, 512, iters * 10);
   run(mfma_tile<4, 2>, "4x2 tile, distinct A/B tuples, 1 w/SIMD", 8, 256, 256, iters * 10);
   run(mfma_tile<4, 2>, "4x2 tile, distinct A/B tuples, 2 w/SIMD", 8, 256, 512, iters * 10);
+  // 128 x 128 wave tile, one wave per SIMD: 4 x 4 of 32x32x16 (32 FLOP-units per round) vs 8 x 8 of 16x16x32 (same FLOPs per round)
+  auto run2 = [&](auto kern, const char* what, double flop_per_iter, int n) {
+    kern<<<256, 256>>>(in, out, 100);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    kern<<<256, 256>>>(in, out, n);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("%-44s %8.2f ms  %7.1f TFLOP/s\n", what, ms, 256.0 * 4 * n * flop_per_iter / (ms * 1e-3) / 1e12);
+  };
+  for (int rep = 0; rep < 2; ++rep) {
+    run2(mfma_tile32<4, 4>, "4x4 tile of 32x32x16 (256 acc regs), 1 w/SIMD", 16 * 2.0 * 32 * 32 * 16, iters * 5);
+    run2(mfma_tile16<8, 8>, "8x8 tile of 16x16x32 (256 acc regs), 1 w/SIMD", 64 * 2.0 * 16 * 16 * 32, iters * 5);
+  }
   return 0;
 }
