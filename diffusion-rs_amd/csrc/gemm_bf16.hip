@@ -147,6 +147,61 @@ __device__ __forceinline__ void stage_tile_q4(const GemmProblem& P, int n0, int 
 // Shared epilogue.  Lane holds, for accumulator (i, j): row m = m0 + wm*128 + i*32 + (lane&31) and
 // columns n = n0 + wn*32*NJ + j*32 + 8q + 4(lane>>5) + {0..3} in registers 4q..4q+3.
 // `smem` (>= 8 * 8192*NJ bytes) is free for staging once every wave has passed the leading barrier.
+// Accumulator views: which (row, 4 consecutive columns) of its wave's 128 x (32 NJ) sub-tile a lane owns, so that the epilogues
+// below are written once for both MFMA shapes.  each<HALF>(f) calls f(r, c, v) for every group the lane owns — r = row inside the
+// sub-tile, c = index of the 4-column group (column = 4 c), v = the four f32 — for all rows (HALF = -1) or one 64-row half.
+//   Acc32: v_mfma_f32_32x32x16_bf16 / 32x32x64_f8 with swapped operands: acc[i][j] is rows 32 i + (lane & 31), columns
+//          32 j + 8 q + 4 (lane >> 5) + {0..3} in registers 4 q .. 4 q + 3.
+//   Acc16: v_mfma_f32_16x16x32_bf16: acc[tm][tn] is rows 16 tm + (lane & 15), columns 16 tn + 4 (lane >> 4) + {0..3}.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int NJ>
+struct Acc32 {
+  f32x16 (&a)[4][NJ];
+  int lane;
+  static constexpr bool kFence = NJ == 4;
+  template <int HALF, class F>
+  __device__ __forceinline__ void each(F&& f) const {
+    const int hl = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (HALF >= 0 && (i >> 1) != HALF) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = a[i][j][q * 4 + e];
+          f(i * 32 + l31, j * 8 + q * 2 + hl, v);
+          // 4-wave kernels: the accumulators sit in AGPRs; without a fence the scheduler hoists all 256 reads and spills
+          if constexpr (kFence) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+  }
+};
+template <int NJ>
+struct Acc16 {
+  f32x4 (&a)[8][2 * NJ];
+  int lane;
+  static constexpr bool kFence = NJ == 4;
+  template <int HALF, class F>
+  __device__ __forceinline__ void each(F&& f) const {
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int tm = 0; tm < 8; ++tm) {
+      if (HALF >= 0 && (tm >> 2) != HALF) continue;
+#pragma unroll
+      for (int tn = 0; tn < 2 * NJ; ++tn) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a[tm][tn][e];
+        f(tm * 16 + l15, tn * 4 + l4, v);
+        if constexpr (kFence) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+};
+
 // Fused [q|k|v] relayout of one 256 x 256 tile (two heads of q, k or v); see GemmProblem::qk_*.
 // The arithmetic (bf16 rounding of the projection first, then f32 RMS / RoPE in the same operation
 // order, 16 lanes x 8 elements per head row) is that of qk_norm_rope_kernel, so both paths produce
@@ -154,9 +209,9 @@ __device__ __forceinline__ void stage_tile_q4(const GemmProblem& P, int n0, int 
 // Two halves, so that the 4-wave kernels (each wave = two of the eight 128 x 64 sub-tiles) run them as
 //   barrier; stage(sub-tile 0); stage(sub-tile 1); barrier; emit(row group 0); emit(row group 1)
 // over the same LDS image and the same stores: `wave` is the index 0..7 in the 2 x 4 layout.
-__device__ __forceinline__ void qkv_relayout_stage(const GemmProblem& P, f32x16 (&acc)[4][2], char* smem, int n0, int wave, int lane) {
+template <class ACC>
+__device__ __forceinline__ void qkv_relayout_stage(const GemmProblem& P, const ACC& acc, char* smem, int n0, int wave, int lane) {
   const int wm = wave >> 2, wn = wave & 3;
-  const int hl = lane >> 5, l31 = lane & 31;
   const int part = n0 / P.qk_D;                     // 0 q, 1 k, 2 v
   auto biased = [&](int n, float (&v)[4]) {
     if (P.bias) {
@@ -171,41 +226,23 @@ __device__ __forceinline__ void qkv_relayout_stage(const GemmProblem& P, f32x16 
     // ---- stage the bf16 tile in the wave-private swizzled regions of the normal store path
     char* cw = smem + wave * 16384;
     const int ncol0 = n0 + wn * 64;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-          biased(ncol0 + j * 32 + q * 8 + 4 * hl, v);
-          const int r = i * 32 + l31, c = j * 8 + q * 2 + hl;
-          *reinterpret_cast<uint2*>(cw + r * 128 + ((c ^ (r & 15)) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        }
+    acc.template each<-1>([&](int r, int c, float (&v)[4]) {
+      biased(ncol0 + 4 * c, v);
+      *reinterpret_cast<uint2*>(cw + r * 128 + ((c ^ (r & 15)) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    });
   } else {
     // ---- v: stage TRANSPOSED, [d column 0..255][tile-local token 0..255] bf16 (512-B rows), with the
     // attention kernel's kv permutation (swap bits 2,3 inside groups of 16) applied to the token
     // index on the way in, so that a row leaves as plain 16-B pieces of consecutive stored positions
     bf16_t* tp = reinterpret_cast<bf16_t*>(smem);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int tl = wm * 128 + i * 32 + l31;
+    acc.template each<-1>([&](int r, int c, float (&v)[4]) {
+      const int tl = wm * 128 + r;
       const int tpos = (tl & ~12) | ((tl & 4) << 1) | ((tl & 8) >> 1);
+      const int dc = wn * 64 + 4 * c;
+      biased(n0 + dc, v);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-          const int dc = wn * 64 + j * 32 + q * 8 + 4 * hl;
-          biased(n0 + dc, v);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) tp[(dc + e) * 256 + tpos] = f32_to_bf16(v[e]);
-        }
-    }
+      for (int e = 0; e < 4; ++e) tp[(dc + e) * 256 + tpos] = f32_to_bf16(v[e]);
+    });
   }
 }
 
@@ -290,7 +327,8 @@ __device__ __forceinline__ void qkv_relayout_emit(const GemmProblem& P, char* sm
   }
 }
 
-__device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int wave, int lane) {
+template <class ACC>
+__device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, const ACC& acc, char* smem, int m0, int n0, int wave, int lane) {
   __syncthreads();  // every wave is done with the operand tiles
   qkv_relayout_stage(P, acc, smem, n0, wave, lane);
   __syncthreads();
@@ -304,14 +342,13 @@ __device__ __forceinline__ void qkv_relayout_epilogue(const GemmProblem& P, f32x
 // must stay in registers), so a run-time switch inside them multiplies the code of every activation by 32-64
 // iterations: with 128-wide wave tiles the staged path alone was ~90 KB of instructions and ran out of the instruction
 // cache (measured on the 4-wave kernel: 45 000 clocks for 64 LDS writes).
-template <int NJ, int WN, int ACT>
-__device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, f32x16 (&acc)[4][NJ], char* smem, int m0, int n0, int wave, int lane) {
+template <int NJ, int WN, int ACT, class ACC>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, const ACC& acc, char* smem, int m0, int n0, int wave, int lane) {
   constexpr int BN = WN * 32 * NJ;
   const int wm = wave / WN, wn = wave % WN;
-  // ---- epilogue: lane holds row m = ..+(lane&31), columns n = ..+8q+4(lane>>5)+{0..3}
+  // ---- epilogue: which rows / 4-column groups a lane holds is the accumulator view's business (Acc32 / Acc16)
   const int epi = P.epi;
   const float alpha = P.alpha;
-  const int hl = lane >> 5, l31 = lane & 31;
   // alpha, bias, activation on 4 consecutive columns starting at n
   auto finish = [&](int n, float (&v)[4], bool full) {
     if constexpr (ACT == 3 || ACT == -1) {
@@ -367,21 +404,10 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, f32x16 
     if (!f32_out) {
       constexpr int RB = 64 * NJ;   // bytes per staged row (32*NJ bf16)
       constexpr int NS8 = 8 * NJ;   // 8-byte slots per row
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-            finish(ncol0 + j * 32 + q * 8 + 4 * hl, v, true);
-            const int r = i * 32 + l31, c = j * 8 + q * 2 + hl;
-            *reinterpret_cast<uint2*>(cw + r * RB + ((c ^ (r & (NS8 - 1))) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            // 4-wave kernel: the accumulators sit in AGPRs; without a fence the scheduler hoists all 256 reads and spills
-            if constexpr (NJ == 4) __builtin_amdgcn_sched_barrier(0);
-          }
+      acc.template each<-1>([&](int r, int c, float (&v)[4]) {
+        finish(ncol0 + 4 * c, v, true);
+        *reinterpret_cast<uint2*>(cw + r * RB + ((c ^ (r & (NS8 - 1))) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       constexpr int LPR = RB / 16, RPI = 64 / LPR;  // lanes per row, rows per wave-instruction
       bf16_t* ob = reinterpret_cast<bf16_t*>(P.out);
@@ -407,20 +433,11 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, f32x16 
       auto f32_pass = [&](auto pass_tag) {
         constexpr int pass = decltype(pass_tag)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float v[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = acc[pass * 2 + ii][j][q * 4 + e];
-              finish(ncol0 + j * 32 + q * 8 + 4 * hl, v, true);
-              const int r = ii * 32 + l31, c = j * 8 + q * 2 + hl;
-              *reinterpret_cast<float4*>(cw + r * RBF + ((c ^ (r & (NS16 - 1))) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
-              if constexpr (NJ == 4) __builtin_amdgcn_sched_barrier(0);
-            }
+        acc.template each<pass>([&](int rg, int c, float (&v)[4]) {
+          finish(ncol0 + 4 * c, v, true);
+          const int r = rg - pass * 64;  // row inside this 64-row pass
+          *reinterpret_cast<float4*>(cw + r * RBF + ((c ^ (r & (NS16 - 1))) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+        });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         constexpr int NIT = 64 / RPI;
         const int ch = lane % LPR, n = ncol0 + ch * 4;
@@ -471,48 +488,33 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, f32x16 
     return;
   }
   // ---- direct path (ragged N tile, unaligned output, bf16 residual add)
-  auto direct_rows = [&](auto i_tag) {
-    constexpr int i = decltype(i_tag)::value;
-    const int m = m0 + wm * 128 + i * 32 + l31;
-    if (m >= P.M) return;
+  acc.template each<-1>([&](int r, int c, float (&v)[4]) {
+    const int m = m0 + wm * 128 + r;
+    const int n = n0 + wn * 32 * NJ + 4 * c;
+    if (m >= P.M || n >= P.N) return;
     const float* gate = P.gate;
     if (epi == EPI_RESID_GATE_F32 && P.rows_per_batch > 0) gate += (int64_t)(m / P.rows_per_batch) * P.gate_bstride;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 32 * NJ + j * 32 + q * 8 + 4 * hl;
-        if (n >= P.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-        const bool full = (n + 3 < P.N) && (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias + n) & 7) == 0);
-        finish(n, v, full);
-        if (epi == EPI_RESID_GATE_F32) {
-          float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
-          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] += gate[n + e] * v[e];
-        } else if (epi == EPI_STORE_F32) {
-          float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
-          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = v[e];
-        } else {
-          bf16_t* o = reinterpret_cast<bf16_t*>(P.out) + (int64_t)m * P.ldo + n;
-          if (epi == EPI_RESID_ADD_BF16) {
-            const bf16_t* r = reinterpret_cast<const bf16_t*>(P.resid) + (int64_t)m * P.ldo + n;
-            for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(r[e]);
-          }
-          for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = f32_to_bf16(v[e]);
-        }
+    const bool full = (n + 3 < P.N) && (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias + n) & 7) == 0);
+    finish(n, v, full);
+    if (epi == EPI_RESID_GATE_F32) {
+      float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
+      for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] += gate[n + e] * v[e];
+    } else if (epi == EPI_STORE_F32) {
+      float* o = reinterpret_cast<float*>(P.out) + (int64_t)m * P.ldo + n;
+      for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = v[e];
+    } else {
+      bf16_t* o = reinterpret_cast<bf16_t*>(P.out) + (int64_t)m * P.ldo + n;
+      if (epi == EPI_RESID_ADD_BF16) {
+        const bf16_t* rs = reinterpret_cast<const bf16_t*>(P.resid) + (int64_t)m * P.ldo + n;
+        for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(rs[e]);
       }
+      for (int e = 0; e < 4 && n + e < P.N; ++e) o[e] = f32_to_bf16(v[e]);
     }
-  };
-  direct_rows(std::integral_constant<int, 0>{});
-  direct_rows(std::integral_constant<int, 1>{});
-  direct_rows(std::integral_constant<int, 2>{});
-  direct_rows(std::integral_constant<int, 3>{});
+  });
 }
 
-template <int NJ, int WN = 4, int ACT = -1>
-__device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, f32x16 (&acc)[4][NJ], char* smem, int m0, int n0, int wave, int lane) {
+template <int NJ, int WN = 4, int ACT = -1, class ACC>
+__device__ __forceinline__ void gemm_epilogue(const GemmProblem& P, const ACC& acc, char* smem, int m0, int n0, int wave, int lane) {
   if constexpr (NJ == 2 && WN == 4) {
     if (P.qk_qh != nullptr && n0 < 3 * P.qk_D) {
       qkv_relayout_epilogue(P, acc, smem, m0, n0, wave, lane);
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
   ktile(nk - 1, std::false_type{});
 
-  gemm_epilogue<NJ>(P, acc, smem, m0, n0, wave, lane);
+  gemm_epilogue<NJ>(P, Acc32<NJ>{acc, lane}, smem, m0, n0, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -775,20 +777,34 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = P.K * ES / (BK * 2);  // 128-byte K tiles
 
-  f32x16 acc[4][NJ];
+  // fp8: v_mfma_f32_32x32x64_f8f6f4, accumulators acc[4][NJ] of 32 x 32 (Acc32).  bf16: v_mfma_f32_16x16x32_bf16, accumulators
+  // acc16[8][2 NJ] of 16 x 16 (Acc16) — on this power-capped part the 16 x 16 x 32 form sustains 14 % more than 32 x 32 x 16
+  // (tools/mfma_peak); same LDS image, the fragment of a 16-row block is rows lane & 15 at k slot 4 s + (lane >> 4).
+  f32x16 acc[FP8 ? 4 : 1][NJ];
+  f32x4 acc16[FP8 ? 1 : 8][2 * NJ];
+  if constexpr (FP8) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+  }
 
-  const int sw = ((lane & 31) >> 1) & 7;
-  int koff[4];
+  const int rl = FP8 ? (lane & 31) : (lane & 15);  // fragment row inside its 32- / 16-row block
+  const int sw = (rl >> 1) & 7;
+  int koff[4];  // fp8: 16-byte k slots 2 s + (lane >> 5), s = 0..3; bf16: slots 4 s + (lane >> 4), s = 0..1
 #pragma unroll
-  for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + (lane >> 5)) ^ sw) << 4;
-  const int a_row_off = (g * 128 + (lane & 31)) * 128;
-  const int w_row_off = (wn * 64 + (lane & 31)) * 128;
+  for (int s = 0; s < 4; ++s) koff[s] = FP8 ? ((s * 2 + (lane >> 5)) ^ sw) << 4 : (((s & 1) * 4 + (lane >> 4)) ^ sw) << 4;
+  const int a_row_off = (g * 128 + rl) * 128;
+  const int w_row_off = (wn * 64 + rl) * 128;
 
   // chunks (8 rows, 1 KiB) this wave stages: A chunks of the other group's rows, W chunks wave*4+i
   const int a_chunk0 = (wave ^ 4) * 4, w_chunk0 = wave * 4;
@@ -837,7 +853,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
   slot_barrier();
   if (g == 1) slot_barrier();  // group 1 starts one slot late
 
-  bf16x8_t xf[4][4], wf[4][NJ];   // bf16: fragments of the 4 k-steps
+  bf16x8_t xf[2][8], wf[2][2 * NJ];  // bf16: fragments of the 2 k-steps of 32: 8 row blocks of A, 2 NJ of W (16 rows each)
   i32x8_t xq[2][4], wq[2][NJ];    // fp8: fragments of the 2 k-steps (two 16-byte reads each)
   int wr = 0;  // W slot of tile t = t % 3
   int wi = 2;  // W slot of tile t + 2
@@ -874,11 +890,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
         }
       } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) wf[s][j] = *reinterpret_cast<const bf16x8_t*>(lw + j * 32 * 128 + koff[s]);
+          for (int j = 0; j < 2 * NJ; ++j) wf[s][j] = *reinterpret_cast<const bf16x8_t*>(lw + j * 16 * 128 + koff[s]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) xf[s][i] = *reinterpret_cast<const bf16x8_t*>(la + i * 32 * 128 + koff[s]);
+          for (int i = 0; i < 8; ++i) xf[s][i] = *reinterpret_cast<const bf16x8_t*>(la + i * 16 * 128 + koff[s]);
         }
       }
     }
@@ -907,11 +923,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
             acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[s][j], xq[s][i], acc[i][j], 0, 0, 0, 0, 0, 0);  // e4m3 x e4m3, unscaled
     } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][j], xf[s][i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2 * NJ; ++j) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], xf[s][i], acc16[i][j], 0, 0, 0);
     }
     slot_barrier();
     wr = wr == 2 ? 0 : wr + 1;
@@ -940,7 +956,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
           for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] *= sa[i] * sn[c];
       }
   }
-  gemm_epilogue<NJ, 4, ACT>(P, acc, smem, m0, n0, wave, lane);
+  if constexpr (FP8) gemm_epilogue<NJ, 4, ACT>(P, Acc32<NJ>{acc, lane}, smem, m0, n0, wave, lane);
+  else gemm_epilogue<NJ, 4, ACT>(P, Acc16<NJ>{acc16, lane}, smem, m0, n0, wave, lane);
 }
 
 
@@ -983,7 +1000,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmProblem& P, f32x16 (&acc)[
       for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][0], hacc[i][1] = acc[i][1];
 #pragma clang loop unroll(disable)
       for (int r = 0; r < 2; ++r) {
-        qkv_relayout_stage(P, hacc, smem, n0, wm * 4 + wn * 2 + r, lane_e);
+        qkv_relayout_stage(P, Acc32<2>{hacc, lane_e}, smem, n0, wm * 4 + wn * 2 + r, lane_e);
 #pragma unroll
         for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][2], hacc[i][1] = acc[i][3];
         asm volatile("" : "+v"(lane_e));
@@ -1002,7 +1019,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmProblem& P, f32x16 (&acc)[
   for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][0], hacc[i][1] = acc[i][1];
 #pragma clang loop unroll(disable)
   for (int r = 0; r < 2; ++r) {
-    gemm_epilogue_impl<2, 4, ACT>(P, hacc, smem, m0, n0, wm * 4 + wn * 2 + r, lane_e);
+    gemm_epilogue_impl<2, 4, ACT>(P, Acc32<2>{hacc, lane_e}, smem, m0, n0, wm * 4 + wn * 2 + r, lane_e);
 #pragma unroll
     for (int i = 0; i < 4; ++i) hacc[i][0] = acc[i][2], hacc[i][1] = acc[i][3];
     asm volatile("" : "+v"(lane_e));  // keep the second round's address math out of the first
@@ -1194,12 +1211,13 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
 namespace fmi {
 
 static bool g_pingpong = true;
-// Default ON for the launches `w4_pays` selects below (the residual-update GEMMs: proj, mlp2, linear2).  Bit-identical
-// to the ping-pong kernel; in the denoise loop -0.45 ms per step and -2.3 % joules per image (alternating A/B on one
-// box).  FMI_GEMM_W4=0 in the environment (or set_gemm_w4(false)) sends everything to the 8-wave kernel.
+// Default OFF since the 8-wave ping-pong kernel moved to v_mfma_f32_16x16x32_bf16 (round 2): with that instruction it is faster
+// than this 32x32x16 kernel on every launch (denoise loop: proj 14.3 vs 15.8 ms, mlp 11.6 vs 12.0 ms per step).
+// Bit-identical to the ping-pong kernel; FMI_GEMM_W4=1 in the environment (or set_gemm_w4(true)) sends the launches `w4_pays`
+// selects below (the residual-update GEMMs: proj, mlp2, linear2) to it.
 static bool g_w4 = [] {
   const char* e = getenv("FMI_GEMM_W4");
-  return e ? atoi(e) != 0 : true;
+  return e ? atoi(e) != 0 : false;
 }();
 static int g_w4q_min_rows = 256;
 static int g_w4_qkv_min_n = 1 << 30;  // never for dense weights (measured: slower, see launch_gemm); the packed 4-bit kernel always fuses

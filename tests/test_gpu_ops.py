@@ -322,9 +322,10 @@ def test_empty_and_null_inputs_fail_cleanly(env):
 
 
 def test_gemm_4wave_kernel_is_bit_identical(tmp_path):
-    """Eligible dense launches (N > 128: the f32 residual epilogue, or any epilogue at K >= 8192) go to the 4-wave
-    128x128-per-wave kernel unless FMI_GEMM_W4=0.  Same accumulation order as the ping-pong kernel -> the
-    outputs must be bit-identical.  The switch is read when the library loads, so each setting runs in its own process."""
+    """With FMI_GEMM_W4=1 eligible dense launches (N > 128: the f32 residual epilogue, or any epilogue at K >= 8192) go to the
+    4-wave 128x128-per-wave kernel (v_mfma_f32_32x32x16_bf16), otherwise to the 8-wave ping-pong kernel (v_mfma_f32_16x16x32_bf16,
+    the default since round 2).  Same accumulation order -> the outputs must be bit-identical — which also pins that the two MFMA
+    shapes accumulate identically.  The switch is read when the library loads, so each setting runs in its own process."""
     import subprocess
     import sys
     script = r'''
