@@ -1026,6 +1026,46 @@ __device__ __forceinline__ void w4_epilogue(const GemmProblem& P, f32x16 (&acc)[
   }
 }
 
+// The same tail for 16 x 16 accumulators (gemm_w4_kernel): acc[tm][tn], the half r = column tiles 4 r .. 4 r + 3.
+template <int ACT>
+__device__ __forceinline__ void w4_epilogue16(const GemmProblem& P, f32x4 (&acc)[8][8], char* smem, int m0, int n0, int wave, int wm, int wn, int lane) {
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  f32x4 hacc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hacc[i][j] = acc[i][j];
+  if (P.qk_qh != nullptr && n0 < 3 * P.qk_D) {
+    __syncthreads();
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < 2; ++r) {
+      qkv_relayout_stage(P, Acc16<2>{hacc, lane_e}, smem, n0, wm * 4 + wn * 2 + r, lane_e);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hacc[i][j] = acc[i][4 + j];
+      asm volatile("" : "+v"(lane_e));
+    }
+    __syncthreads();
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < 2; ++r) {
+      qkv_relayout_emit(P, smem, m0, n0, wave * 2 + r, lane_e);
+      asm volatile("" : "+v"(lane_e));
+    }
+    return;
+  }
+#pragma clang loop unroll(disable)
+  for (int r = 0; r < 2; ++r) {
+    gemm_epilogue_impl<2, 4, ACT>(P, Acc16<2>{hacc, lane_e}, smem, m0, n0, wm * 4 + wn * 2 + r, lane_e);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hacc[i][j] = acc[i][4 + j];
+    asm volatile("" : "+v"(lane_e));  // keep the second round's address math out of the first
+  }
+}
+
 template <bool FP8, int ACT>
 __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch batch) {
   constexpr int NJ = 4, BN = 256;
@@ -1055,21 +1095,23 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = P.K * ES / (BK * 2);
 
-  f32x16 acc[4][NJ];
+  // v_mfma_f32_16x16x32_bf16: the wave's 128 x 128 is 8 x 8 accumulators of 16 x 16 (the 16 x 16 x 32 form sustains 14 % more than
+  // 32 x 32 x 16 on this power-capped part, tools/mfma_peak; same results bit for bit, same LDS image)
+  f32x4 acc[8][8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-  const int sw = ((lane & 31) >> 1) & 7;
+  const int sw = ((lane & 15) >> 1) & 7;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-  uint32_t koff[4];
+  uint32_t koff[2];  // k-step s of 32: 16-byte slot 4 s + (lane >> 4) of the row
 #pragma unroll
-  for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + (lane >> 5)) ^ sw) << 4;
-  const uint32_t a_row = lds0 + A_RING + (wm * 128 + (lane & 31)) * 128;
-  const uint32_t w_row = lds0 + W_RING + (wn * 128 + (lane & 31)) * 128;
+  for (int s = 0; s < 2; ++s) koff[s] = ((s * 4 + (lane >> 4)) ^ sw) << 4;
+  const uint32_t a_row = lds0 + A_RING + (wm * 128 + (lane & 15)) * 128;
+  const uint32_t w_row = lds0 + W_RING + (wn * 128 + (lane & 15)) * 128;
 
   // DMA pieces of this wave: 1-KiB chunks wave*8 + i of the A tile and of the W tile
   uint32_t a_off[8], w_off[8];
@@ -1114,96 +1156,97 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
   sync_all();
 
   typedef __attribute__((ext_vector_type(4))) int frag_t;  // 16 bytes: 8 bf16 of one row
-  frag_t xf[4][4], wf[4][4];  // fragment buffer s holds k-step s of a tile (read two steps ahead of its MFMAs)
-  // LDS read addresses: one VGPR per (operand, k-step), rebased once per tile; the row block is the immediate offset
-  uint32_t a_ad[4], w_ad[4];
+  frag_t xf[2][8], wf[2][8];  // fragment buffer s holds k-step s of a tile: 8 row blocks of A, 8 of W (16 rows each)
+  // LDS read addresses: one VGPR per (operand, k-step), rebased once per tile; the row block is the immediate offset (2 KiB apart)
+  uint32_t a_ad[2], w_ad[2];
   auto rebase = [&](int aslot, int wslot_) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 2; ++s) {
       a_ad[s] = a_row + koff[s] + aslot * TILE;
       w_ad[s] = w_row + koff[s] + wslot_ * TILE;
     }
   };
 #define FMI_W4_RD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
-  auto read_frag = [&](int s, int which) {  // k-step s (= buffer s); which: 0..3 = A row block i, 4..7 = W row block j
+  auto read_frag = [&](int s, int which) {  // k-step s (= buffer s); which: 0..7 = A row block, 8..15 = W row block
     switch (which) {
       case 0: FMI_W4_RD(xf[s][0], a_ad[s], 0); break;
-      case 1: FMI_W4_RD(xf[s][1], a_ad[s], 4096); break;
-      case 2: FMI_W4_RD(xf[s][2], a_ad[s], 8192); break;
-      case 3: FMI_W4_RD(xf[s][3], a_ad[s], 12288); break;
-      case 4: FMI_W4_RD(wf[s][0], w_ad[s], 0); break;
-      case 5: FMI_W4_RD(wf[s][1], w_ad[s], 4096); break;
-      case 6: FMI_W4_RD(wf[s][2], w_ad[s], 8192); break;
-      default: FMI_W4_RD(wf[s][3], w_ad[s], 12288); break;
+      case 1: FMI_W4_RD(xf[s][1], a_ad[s], 2048); break;
+      case 2: FMI_W4_RD(xf[s][2], a_ad[s], 4096); break;
+      case 3: FMI_W4_RD(xf[s][3], a_ad[s], 6144); break;
+      case 4: FMI_W4_RD(xf[s][4], a_ad[s], 8192); break;
+      case 5: FMI_W4_RD(xf[s][5], a_ad[s], 10240); break;
+      case 6: FMI_W4_RD(xf[s][6], a_ad[s], 12288); break;
+      case 7: FMI_W4_RD(xf[s][7], a_ad[s], 14336); break;
+      case 8: FMI_W4_RD(wf[s][0], w_ad[s], 0); break;
+      case 9: FMI_W4_RD(wf[s][1], w_ad[s], 2048); break;
+      case 10: FMI_W4_RD(wf[s][2], w_ad[s], 4096); break;
+      case 11: FMI_W4_RD(wf[s][3], w_ad[s], 6144); break;
+      case 12: FMI_W4_RD(wf[s][4], w_ad[s], 8192); break;
+      case 13: FMI_W4_RD(wf[s][5], w_ad[s], 10240); break;
+      case 14: FMI_W4_RD(wf[s][6], w_ad[s], 12288); break;
+      default: FMI_W4_RD(wf[s][7], w_ad[s], 14336); break;
     }
   };
-  // LDS reads retire in order: with the 8 reads of the following step allowed to be pending, this step's have landed.
+  // LDS reads retire in order: with at most N reads of the other buffer pending, buffer s has landed.
   // The "+v" ties make the fragments depend on the wait so no MFMA is scheduled above it.
-#define FMI_W4_WAIT(N, s)                                                                                                                    \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                                   \
-               : "+v"(xf[s][0]), "+v"(xf[s][1]), "+v"(xf[s][2]), "+v"(xf[s][3]), "+v"(wf[s][0]), "+v"(wf[s][1]), "+v"(wf[s][2]), "+v"(wf[s][3]))
+#define FMI_W4_WAIT(N, s)                                                                                                                         \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                                                        \
+               : "+v"(xf[s][0]), "+v"(xf[s][1]), "+v"(xf[s][2]), "+v"(xf[s][3]), "+v"(xf[s][4]), "+v"(xf[s][5]), "+v"(xf[s][6]), "+v"(xf[s][7]), \
+                 "+v"(wf[s][0]), "+v"(wf[s][1]), "+v"(wf[s][2]), "+v"(wf[s][3]), "+v"(wf[s][4]), "+v"(wf[s][5]), "+v"(wf[s][6]), "+v"(wf[s][7]))
+  // (inline asm pins the 64 accumulators to the AGPR half; with the builtin hipcc spread them over both halves and moved ~500
+  // registers per K tile between them.  An accumulator is touched once per k-step, 64 MFMAs apart: no dependent-issue hazard.)
   auto mfma = [&](int s, int i, int j) {
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[s][j]), __builtin_bit_cast(bf16x8_t, xf[s][i]), acc[i][j], 0, 0, 0);
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(wf[s][j]), "v"(xf[s][i]));
   };
 
-  // steps 0 and 1 of tile 0
+  // k-step 0 of tile 0
   rebase(0, 0);
 #pragma unroll
-  for (int w = 0; w < 8; ++w) read_frag(0, w);
-#pragma unroll
-  for (int w = 0; w < 8; ++w) read_frag(1, w);
+  for (int w = 0; w < 16; ++w) read_frag(0, w);
   int wslot = 0;  // W slot of tile t = t % 3
   // Branch-free body: past the end of K the DMA re-fetches the last tile into slots nobody reads again, and the
   // fragment reads of the "next tile" fetch garbage nobody multiplies; every count below is the same for all t.
-  // (A separate tail loop made hipcc park all 256 accumulators in scratch across the loop boundary.)
-  //   step 0, 1 : reads of steps 2, 3 (every other MFMA); W(t+2) -> slot (t+2)%3, free since barrier(t-1) (every 4th MFMA)
-  //   step 2    : 4 MFMAs; all of this tile's reads are in -> vmcnt(8): A(t+1), W(t+1) landed -> BARRIER(t);
-  //               then reads of tile t+1 step 0; A(t+2) -> slot t&1 (4 pieces)
-  //   step 3    : reads of tile t+1 step 1; A(t+2) (4 pieces)
+  //   k-step 0 (64 MFMAs): the 16 reads of this tile's k-step 1 (every 3rd MFMA); W(t+2) -> slot (t+2)%3, free since
+  //                        barrier(t-1) (every 8th MFMA)
+  //   k-step 1 (64 MFMAs): its fragments are in = all of this tile's reads -> vmcnt(8): A(t+1), W(t+1) landed -> BARRIER(t);
+  //                        then the 16 reads of tile t+1's k-step 0 (every 3rd MFMA, done 16 MFMAs before they are needed)
+  //                        and A(t+2) -> slot t&1 (every 8th MFMA)
   for (int t = 0; t < nk; ++t) {
     const int wnext = wslot == 2 ? 0 : wslot + 1;   // W slot of tile t+1
     const int wnn = wnext == 2 ? 0 : wnext + 1;     // W slot of tile t+2
     const int kt2 = min(t + 2, klast);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (s == 0) FMI_W4_WAIT(8, 0); else FMI_W4_WAIT(8, 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        mfma(s, q >> 2, q & 3);
-        if ((q & 1) == 0) read_frag(s + 2, q >> 1);
-        if ((q & 3) == 1) dma_w(kt2, wnn, (s * 16 + q) >> 2);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    FMI_W4_WAIT(8, 2);
+    FMI_W4_WAIT(0, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      if (q == 4) {
-        FMI_W4_WAIT(0, 3);  // the tile's last reads are in: its LDS slots are free
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // oldest first: ..., A(t+1) x8, W(t+2) x8
-        sync_all();
-        rebase((t + 1) & 1, wnext);
-      }
-      mfma(2, q >> 2, q & 3);
-      if (q >= 8) read_frag(0, q - 8);
-      if (q >= 9 && (q & 1)) dma_a(kt2, (q - 9) >> 1);
+    for (int q = 0; q < 64; ++q) {
+      mfma(0, q >> 3, q & 7);
+      if (q % 3 == 1 && q / 3 < 16) read_frag(1, q / 3);
+      if ((q & 7) == 3) dma_w(kt2, wnn, q >> 3);
       __builtin_amdgcn_sched_barrier(0);
     }
+    FMI_W4_WAIT(0, 1);  // the tile's last reads are in: its LDS slots are free
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // oldest first: ..., A(t+1) x8, W(t+2) x8
+    sync_all();
+    rebase((t + 1) & 1, wnext);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      mfma(3, q >> 2, q & 3);
-      if ((q & 1) == 0) read_frag(1, q >> 1);
-      if ((q & 3) == 3) dma_a(kt2, 4 + (q >> 2));
+    for (int q = 0; q < 64; ++q) {
+      mfma(1, q >> 3, q & 7);
+      if (q % 3 == 1 && q / 3 < 16) read_frag(0, q / 3);
+      if ((q & 7) == 5) dma_a(kt2, q >> 3);
       __builtin_amdgcn_sched_barrier(0);
     }
     wslot = wnext;
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the trailing dummy DMA / reads must not land in the epilogue's staging
+  // the trailing dummy DMA / reads must not land in the epilogue's staging; the last MFMAs drain before the epilogue reads the
+  // accumulators (hipcc knows nothing of an asm MFMA's latency: every tile passes through a volatile asm behind the nops)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
 #undef FMI_W4_RD
 #undef FMI_W4_WAIT
-  w4_epilogue<ACT>(P, acc, smem, m0, n0, wave, wm, wn, lane);
+  w4_epilogue16<ACT>(P, acc, smem, m0, n0, wave, wm, wn, lane);
 }
 
 }  // namespace fmi
@@ -1211,10 +1254,11 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
 namespace fmi {
 
 static bool g_pingpong = true;
-// Default OFF since the 8-wave ping-pong kernel moved to v_mfma_f32_16x16x32_bf16 (round 2): with that instruction it is faster
-// than this 32x32x16 kernel on every launch (denoise loop: proj 14.3 vs 15.8 ms, mlp 11.6 vs 12.0 ms per step).
-// Bit-identical to the ping-pong kernel; FMI_GEMM_W4=1 in the environment (or set_gemm_w4(true)) sends the launches `w4_pays`
-// selects below (the residual-update GEMMs: proj, mlp2, linear2) to it.
+// Default OFF since both kernels moved to v_mfma_f32_16x16x32_bf16 (round 2): with twice the MFMA instructions per K tile the
+// one-wave-per-SIMD stream no longer beats two waves per SIMD (tools/gemm_bench, f32 residual epilogue: 4608x3072x15360 1280 vs
+// 1385 TF, 4096x3072x12288 1259 vs 1353 TF; it was +5-8 % with 32x32x16).  Bit-identical to the ping-pong kernel;
+// FMI_GEMM_W4=1 in the environment (or set_gemm_w4(true)) sends the launches `w4_pays` selects below (the residual-update
+// GEMMs: proj, mlp2, linear2) to it.
 static bool g_w4 = [] {
   const char* e = getenv("FMI_GEMM_W4");
   return e ? atoi(e) != 0 : false;
