@@ -569,21 +569,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   auto bufA = [&](int b) -> char* { return smem + b * BUF_BYTES; };
   auto bufW = [&](int b) -> char* { return smem + b * BUF_BYTES + A_TILE_BYTES; };
 
-  f32x16 acc[4][NJ];
+  // v_mfma_f32_16x16x32_bf16 (see gemm_pp_kernel): the wave's 128 x 32 NJ is 8 x 2 NJ accumulators of 16 x 16
+  f32x4 acc[8][2 * NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < 2 * NJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-  // per-lane swizzled column-slot byte offsets for the 4 k-steps of a tile
-  const int sw = ((lane & 31) >> 1) & 7;
-  int koff[4];
+  // per-lane swizzled column-slot byte offsets for the 2 k-steps (32 wide) of a tile: slot 4 s + (lane >> 4) of row lane & 15
+  const int sw = ((lane & 15) >> 1) & 7;
+  int koff[2];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) koff[s] = ((s * 2 + (lane >> 5)) ^ sw) << 4;
-  const int a_row_off = (wm * 128 + (lane & 31)) * 128;
-  const int w_row_off = (wn * 32 * NJ + (lane & 31)) * 128;
+  for (int s = 0; s < 2; ++s) koff[s] = ((s * 4 + (lane >> 4)) ^ sw) << 4;
+  const int a_row_off = (wm * 128 + (lane & 15)) * 128;
+  const int w_row_off = (wn * 32 * NJ + (lane & 15)) * 128;
 
   // CONV: this lane stages rows chunk*8 + (lane>>3), chunk = wave*4 + i; precompute their pixels
   int cv_y[4], cv_x[4];
@@ -689,24 +690,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
     const char* la = bufA(cur) + a_row_off;
     const char* lw = bufW(cur) + w_row_off;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8_t xf[4], wf[NJ];
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t xf[8], wf[2 * NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(lw + j * 32 * 128 + koff[s]);
+      for (int j = 0; j < 2 * NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(lw + j * 16 * 128 + koff[s]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(la + i * 32 * 128 + koff[s]);
+      for (int i = 0; i < 8; ++i) xf[i] = *reinterpret_cast<const bf16x8_t*>(la + i * 16 * 128 + koff[s]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 8; ++i) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        if (MORE && INTERLEAVE && s * 4 + i < 4 + CPWN) dma_piece(kt + 1, s * 4 + i, cur ^ 1);
+        for (int j = 0; j < 2 * NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        if (MORE && INTERLEAVE && s * 8 + i < 4 + CPWN) dma_piece(kt + 1, s * 8 + i, cur ^ 1);
       }
     }
   };
   for (int kt = 0; kt < nk - 1; ++kt) ktile(kt, std::true_type{});
   ktile(nk - 1, std::false_type{});
 
-  gemm_epilogue<NJ>(P, Acc32<NJ>{acc, lane}, smem, m0, n0, wave, lane);
+  gemm_epilogue<NJ>(P, Acc16<NJ>{acc, lane}, smem, m0, n0, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -115,6 +115,51 @@ __global__ __launch_bounds__(256, 1) void mfma_tile32(const uint4* in, float* ou
   out[(size_t)blockIdx.x * blockDim.x + tid] = s;
 }
 
+// fp8 (e4m3) forms: 32x32x64 (the fp8 GEMM's) vs 16x16x128, 128 x 128 wave tile, one wave per SIMD
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+template <int SHAPE>  // 32 or 16
+__global__ __launch_bounds__(256, 1) void mfma_tile_fp8(const uint4* in, float* out, int iters) {
+  const int tid = threadIdx.x;
+  constexpr int NT = SHAPE == 32 ? 4 : 8;
+  i32x8 a[NT], b[NT];
+  for (int i = 0; i < NT; ++i) {
+    const uint4 x = in[(tid + 64 * i) & 1023], y = in[(tid + 64 * i + 512) & 1023];
+    a[i] = i32x8{(int)x.x & 0x3f3f3f3f, (int)x.y & 0x3f3f3f3f, (int)x.z & 0x3f3f3f3f, (int)x.w & 0x3f3f3f3f, (int)y.x & 0x3f3f3f3f, (int)y.y & 0x3f3f3f3f, (int)y.z & 0x3f3f3f3f, (int)y.w & 0x3f3f3f3f};
+    b[i] = i32x8{(int)y.x & 0x3f3f3f3f, (int)y.y & 0x3f3f3f3f, (int)x.z & 0x3f3f3f3f, (int)x.w & 0x3f3f3f3f, (int)x.x & 0x3f3f3f3f, (int)y.z & 0x3f3f3f3f, (int)y.w & 0x3f3f3f3f, (int)x.y & 0x3f3f3f3f};
+  }
+  float s = 0.f;
+  if constexpr (SHAPE == 32) {
+    f32x16 acc[NT][NT];
+    for (int i = 0; i < NT; ++i)
+      for (int j = 0; j < NT; ++j)
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[j], a[i], acc[i][j], 0, 0, 0, 0, 0, 0);
+      asm volatile("" : "+v"(a[0]));
+    }
+    for (int i = 0; i < NT; ++i)
+      for (int j = 0; j < NT; ++j) s += acc[i][j][0] + acc[i][j][7];
+  } else {
+    f32x4 acc[NT][NT];
+    for (int i = 0; i < NT; ++i)
+      for (int j = 0; j < NT; ++j)
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[j], a[i], acc[i][j], 0, 0, 0, 0, 0, 0);
+      asm volatile("" : "+v"(a[0]));
+    }
+    for (int i = 0; i < NT; ++i)
+      for (int j = 0; j < NT; ++j) s += acc[i][j][0] + acc[i][j][3];
+  }
+  out[(size_t)blockIdx.x * blockDim.x + tid] = s;
+}
+
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 20000;
   uint4* in;
@@ -170,6 +215,10 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < 2; ++rep) {
     run2(mfma_tile32<4, 4>, "4x4 tile of 32x32x16 (256 acc regs), 1 w/SIMD", 16 * 2.0 * 32 * 32 * 16, iters * 5);
     run2(mfma_tile16<8, 8>, "8x8 tile of 16x16x32 (256 acc regs), 1 w/SIMD", 64 * 2.0 * 16 * 16 * 32, iters * 5);
+  }
+  for (int rep = 0; rep < 2; ++rep) {
+    run2(mfma_tile_fp8<32>, "fp8: 4x4 tile of 32x32x64 f8f6f4, 1 w/SIMD", 16 * 2.0 * 32 * 32 * 64, iters * 5);
+    run2(mfma_tile_fp8<16>, "fp8: 8x8 tile of 16x16x128 f8f6f4, 1 w/SIMD", 64 * 2.0 * 16 * 16 * 128, iters * 5);
   }
   return 0;
 }
