@@ -326,7 +326,7 @@ def main():
 
         fq = d.FluxModel(d.FLUX_DEV, local_rank)
         fill_flux(fq, "nf4")
-        # default policy (flux_model.hip: densify): only the packed codes are resident; the 4096 / 4608-row block linears expand per call
+        # default policy (flux_model.hip: densify): only the packed codes are resident; the block linears (launches above 383 rows) expand per call
         # into a 264 MB scratch (stand-alone dequant kernel) and run the dense GEMM, smaller launches multiply from the packed codes
         leg(fq, wl, "nf4_c3", "dequant4_kernel + gemm_pp_kernel / gemm_w4_kernel (nf4 block linears expanded per call into a scratch, then the dense bf16 MFMA GEMM; "
             "the expansions are inside the timed phases; dense-equivalent FLOPs)", 2500.0,

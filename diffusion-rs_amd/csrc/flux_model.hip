@@ -493,11 +493,13 @@ void with_gate(GemmProblem& p, const float* gate, int rows_per_batch, int bstrid
 // Above these row counts a quantised matrix is expanded per call into a reusable scratch (2 x the largest fused matrix,
 // 264 MB) and the dense kernel runs — measured faster than the fused kernels, because ONE stand-alone expansion is amortised
 // over all M rows while the fused expansion is repeated by every row tile:
-//   LLM.int8  fused stage 0.56-0.67x dense; 4608 x 21504 x 3072: 493 + 50 us against 765 us fused   -> from 257 rows
-//   nf4 / fp4 fused kernel 0.77-0.87x dense; same shape: 498 + 35 us against 598 us fused            -> from 1536 rows
-// (below, the GEMM is short or bound by weight bytes and the packed read wins).  Either way only the packed codes are resident.
+//   LLM.int8  fused stage 0.44-0.59x dense; 4608 x 21504 x 3072: 432 + 38 us against 728 us fused   -> from 257 rows
+//   nf4 / fp4 fused kernel 0.61-0.76x dense; same shape: 436 + 35 us against 626 us fused; 512 x 9216 x 3072: 53 + 15 us
+//             against 87 us                                                                          -> from 384 rows
+// (profiles/r02_gemm_bench_quantised.txt, dense = the 16x16x32 kernel; below these sizes the GEMM is short or bound by weight
+// bytes and the packed read wins).  Either way only the packed codes are resident.
 constexpr int INT8_FUSED_MAX_ROWS = 256;
-constexpr int Q4_FUSED_MAX_ROWS = 1535;
+constexpr int Q4_FUSED_MAX_ROWS = 383;
 int densify(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s) {
   // one decision per launch group (the img + txt problems of a double block stay one grouped launch)
   bool scratch = false;

@@ -127,7 +127,7 @@ int fmi_flux_set_linear_bnb4(fmi_flux*, const char* prefix, const uint8_t* packe
 int fmi_flux_set_linear_int8(fmi_flux*, const char* prefix, const int8_t* weight, const float* scb, int out_features, int in_features);
 /* Quantised block / modulation linears (BnbLinear::forward = dequantize, then matmul: bitsandbytes/mod.rs:293-312).
  * Only the packed codes are resident (an nf4 FLUX.1-dev occupies ~7 GB).  mode 0 (default): by size — launches of up
- * to 1535 rows (nf4 / fp4) or 256 rows (LLM.int8) multiply straight from the codes with the fused dequant-GEMM (the
+ * to 383 rows (nf4 / fp4) or 256 rows (LLM.int8) multiply straight from the codes with the fused dequant-GEMM (the
  * expansion is an LDS stage of the GEMM); larger launches expand the matrix per call into a reusable scratch (2 x the
  * largest fused matrix) and run the dense kernel, which is measured faster there.  mode 1: each quantised matrix is
  * expanded ONCE into its slot of the bf16 arena (allocated on first use, +16 GB).  mode 2: every launch on the fused

@@ -211,9 +211,10 @@ int main(int argc, char** argv) {
       GemmProblem q = p;
       q.out = O, q.W = nullptr, q.Wq = Wq, q.absmax = am, q.q_blocksize = 64, q.q_type = 2;
       if (qkv) q.qk_qh = qh[1], q.qk_kh = kh[1], q.qk_vt = vt[1];
-      double us[2];
-      for (int arm = 0; arm < 2; ++arm) {
+      double us[3];
+      for (int arm = 0; arm < 3; ++arm) {  // dense on the expanded weights; fused one-wave kernel; fused 8-wave kernel (VALU expansion)
         GemmProblem& r = arm ? q : p;
+        set_gemm_w4q_min_rows(arm == 2 ? (1 << 30) : 256);
         for (int i = 0; i < 2; ++i) launch_gemm(&r, 1, nullptr);
         hipDeviceSynchronize();
         hipEventRecord(e0, nullptr);
@@ -224,6 +225,8 @@ int main(int argc, char** argv) {
         hipEventElapsedTime(&ms, e0, e1);
         us[arm] = ms / iters * 1e3;
       }
+      set_gemm_w4q_min_rows(256);
+      printf("nf4 %-18s 8-wave fused (VALU expansion) %7.1f us  (%.2fx of dense)\n", s.name, us[2], us[0] / us[2]);
       hipMemset(d_mis, 0, 8);
       count_mismatch<<<1024, 256>>>(O, O2, (size_t)s.M * s.N, d_mis);
       if (qkv) {
