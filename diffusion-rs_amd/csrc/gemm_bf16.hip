@@ -1,4 +1,4 @@
-// gemm_bf16.hip — grouped bf16 GEMM  y = epi(x · Wᵀ + bias)  on v_mfma_f32_32x32x16_bf16,
+// gemm_bf16.hip — grouped bf16 GEMM  y = epi(x · Wᵀ + bias)  on v_mfma_f32_16x16x32_bf16 (fp8: 32x32x64_f8f6f4),
 // plus the implicit-GEMM 3x3 / 1x1 convolution of the VAE decoder on the same main loop.
 //
 // Replaces every Linear on the FLUX hot path: UnquantLinear::forward
@@ -9,7 +9,9 @@
 //
 // CDNA4 design (not a port of the reference's cuBLAS call):
 //   * 256 x (128|256) x 64 macro tile, 8 waves (2 along M x 4 along N), each wave owns
-//     128 x (32|64) of C as 4 x NJ accumulators of the 32x32x16 MFMA.
+//     128 x (32|64) of C as 8 x 2 NJ accumulators of the 16x16x32 MFMA (this part sustains that form 14 % better than
+//     32x32x16, tools/mfma_peak; the results are bit-identical).  The epilogues are written over accumulator views
+//     (Acc32 / Acc16) so that the fp8 kernel and the fused nf4 kernel, which stay on 32 x 32 tiles, share them.
 //   * A and W tiles are DMA'd HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip),
 //     double buffered.  The LDS image is lane-linear, so the bank-conflict XOR swizzle (16-B
 //     slot c -> c ^ ((row>>1)&7) inside each 128-B row) is applied on the per-lane *source*
