@@ -212,6 +212,13 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t*
 int launch_v_transpose(const bf16_t* v, int ldv, int64_t v_bstride, bf16_t* vt, int B, int H, int rows,
                        int row_off, int Lpad, hipStream_t stream);
 int launch_vt_zero_pad(bf16_t* vt, int BH, int L, int Lpad, hipStream_t stream);
+// sequence-parallel exchange buffers (seq_parallel.hip): q|k|vt of the local tokens <-> all tokens of H/N heads
+size_t sp_qkv_bytes_per_peer(int Hr, int Ll);
+size_t sp_o_bytes_per_peer(int Hr, int Ll);
+int launch_sp_pack_qkv(const bf16_t* q, const bf16_t* k, const bf16_t* vt, void* send, int H, int Tl, int Sl, int N, hipStream_t s);
+int launch_sp_unpack_qkv(const void* recv, bf16_t* qf, bf16_t* kf, bf16_t* vtf, int H, int Tl, int Sl, int N, hipStream_t s);
+int launch_sp_pack_o(const bf16_t* o, void* send, int H, int Tl, int Sl, int N, hipStream_t s);
+int launch_sp_unpack_o(const void* recv, const AttnOut& out, int H, int Ll, int N, hipStream_t s);
 // q/k RMSNorm (eps 1e-6, weight (128)) + RoPE, token-major in (row stride ld, head h at col h*128)
 // -> head-major (B,H,Ltot,128) at row offset row_off.  pe: (B or 1, Ltot, 64, 2) f32 {cos,sin}
 int launch_qk_norm_rope(const bf16_t* q, const bf16_t* k, int ld, int64_t in_bstride, const bf16_t* wq,

@@ -133,6 +133,15 @@ struct fmi_flux {
   std::set<const void*> dense_ready;
   bf16_t* wscratch[2] = {nullptr, nullptr};  // per-call expansion of quantised matrices at large M (densify)
   size_t wscratch_elems = 0;
+  // single-image sequence parallelism (fmi_flux_set_sequence_parallel; seq_parallel.hip)
+  int sp_rank = 0, sp_world = 1;
+  fmi_all_to_all_fn sp_a2a = nullptr;
+  void* sp_user = nullptr;
+  char* sp_base = nullptr;  // [send | recv | Qf | Kf | Vtf | O]
+  size_t sp_bytes = 0;
+  int sp_Tl = 0, sp_Sl = 0;
+  void *sp_send = nullptr, *sp_recv = nullptr;
+  bf16_t *sp_Qf = nullptr, *sp_Kf = nullptr, *sp_Vtf = nullptr, *sp_O = nullptr;
   // fp8 mode (fmi_flux_quantize_fp8)
   bool fp8 = false;
   char* fp8_arena = nullptr;
@@ -553,6 +562,46 @@ int gemm1(fmi_flux* m, GemmProblem& p, Dense& d, hipStream_t s) {
   return gemm2(m, &p, dn, 1, s);
 }
 
+// Sequence-parallel joint attention: the local (H, Ll) q|k|v go out, (H/N heads, all L tokens) come in, attention runs on
+// this rank's heads, and the output rows travel back to their owners.  `out` = where the local rows of the result go.
+int ensure_sp_buffers(fmi_flux* m, int Tl, int Sl) {
+  if (m->sp_base && m->sp_Tl == Tl && m->sp_Sl == Sl) return FMI_OK;
+  const int N = m->sp_world, Hr = m->H / N, Ll = Tl + Sl, L = N * Ll, Lp = (L + 63) / 64 * 64;
+  const size_t xb = align_up((size_t)N * std::max(sp_qkv_bytes_per_peer(Hr, Ll), sp_o_bytes_per_peer(Hr, Ll)), 256);
+  const size_t qb = align_up((size_t)Hr * L * 128 * 2, 256), vb = align_up((size_t)Hr * 128 * Lp * 2, 256);
+  const size_t total = 2 * xb + 2 * qb + vb + qb;
+  FMI_HIP_TRY(hipDeviceSynchronize());
+  if (m->sp_base) FMI_HIP_TRY(hipFree(m->sp_base));
+  m->sp_base = nullptr;
+  FMI_HIP_TRY(hipMalloc((void**)&m->sp_base, total));
+  char* c = m->sp_base;
+  m->sp_send = c, c += xb;
+  m->sp_recv = c, c += xb;
+  m->sp_Qf = reinterpret_cast<bf16_t*>(c), c += qb;
+  m->sp_Kf = reinterpret_cast<bf16_t*>(c), c += qb;
+  m->sp_Vtf = reinterpret_cast<bf16_t*>(c), c += vb;
+  m->sp_O = reinterpret_cast<bf16_t*>(c);
+  m->sp_bytes = total, m->sp_Tl = Tl, m->sp_Sl = Sl;
+  return FMI_OK;
+}
+int attention_sp(fmi_flux* m, const AttnOut& out, int Tl, int Sl, float scale, hipStream_t s) {
+  auto& w = m->ws;
+  const int N = m->sp_world, H = m->H, Hr = H / N, Ll = Tl + Sl, L = N * Ll, Lp = (L + 63) / 64 * 64;
+  FMI_TRY(ensure_sp_buffers(m, Tl, Sl));
+  FMI_TRY(launch_sp_pack_qkv(w.Qh, w.Kh, w.Vt, m->sp_send, H, Tl, Sl, N, s));
+  if (m->sp_a2a(m->sp_user, m->sp_send, m->sp_recv, sp_qkv_bytes_per_peer(Hr, Ll), s) != 0)
+    return fail(FMI_ERR_STATE, "flux: the sequence-parallel all-to-all callback failed (q|k|v exchange)");
+  FMI_TRY(launch_sp_unpack_qkv(m->sp_recv, m->sp_Qf, m->sp_Kf, m->sp_Vtf, H, Tl, Sl, N, s));
+  AttnOut o{};
+  o.p0 = nullptr, o.rows0 = 0;
+  o.p1 = m->sp_O, o.ld1 = Hr * 128, o.bstride1 = (int64_t)L * Hr * 128;
+  FMI_TRY(launch_attention_ex(m->sp_Qf, m->sp_Kf, m->sp_Vtf, o, 1, Hr, L, L, Lp, scale, m->attn_thr, s, 0));
+  FMI_TRY(launch_sp_pack_o(m->sp_O, m->sp_send, H, Tl, Sl, N, s));
+  if (m->sp_a2a(m->sp_user, m->sp_send, m->sp_recv, sp_o_bytes_per_peer(Hr, Ll), s) != 0)
+    return fail(FMI_ERR_STATE, "flux: the sequence-parallel all-to-all callback failed (attention output exchange)");
+  return launch_sp_unpack_o(m->sp_recv, out, H, Ll, N, s);
+}
+
 struct PhaseTimer {
   fmi_flux* m;
   hipStream_t s;
@@ -622,6 +671,9 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
   const int64_t pe_bs = in->ids_per_sample ? (int64_t)L * 128 : 0;
   const float att_scale = 1.0f / sqrtf(128.0f);
   const bool fp8 = m->fp8;
+  // sequence parallel: S, T (and the ids) are this rank's shard; only the attention sees the other ranks (attention_sp)
+  const bool sp = m->sp_world > 1 && m->sp_a2a;
+  if (sp && (B != 1 || fp8)) return fail(FMI_ERR_UNSUPPORTED, "flux: sequence parallelism runs one image (B = 1) in bf16 mode");
   const int BT = B * T;  // a8 / a8s rows: [txt (B*T) | img (B*S)]
 
   {
@@ -700,7 +752,8 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       o.p0 = w.attn_txt, o.rows0 = T, o.ld0 = D, o.bstride0 = (int64_t)T * D;
       o.p1 = w.attn_img, o.ld1 = D, o.bstride1 = (int64_t)S * D;
       const float sc = qk8 ? att_scale / (m->q8_dbl[i] * m->k8_dbl[i]) : att_scale;
-      FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0));
+      if (sp) FMI_TRY(attention_sp(m, o, T, S, sc, s));
+      else FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0));
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
@@ -791,7 +844,8 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       o.p0 = nullptr, o.rows0 = 0;
       o.p1 = w.big + 2 * D, o.ld1 = ldbig, o.bstride1 = (int64_t)L * ldbig;
       const float sc = qk8 ? att_scale / (m->q8_sgl[i] * m->k8_sgl[i]) : att_scale;
-      FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0));
+      if (sp) FMI_TRY(attention_sp(m, o, T, S, sc, s));
+      else FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0));
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
@@ -876,6 +930,7 @@ extern "C" void fmi_flux_destroy(fmi_flux* m) {
     if (m->arena[a].base) hipFree(m->arena[a].base);
   for (int k = 0; k < 2; ++k)
     if (m->wscratch[k]) hipFree(m->wscratch[k]);
+  if (m->sp_base) hipFree(m->sp_base);
   if (m->mod_steps) hipFree(m->mod_steps);
   if (m->vec_steps) hipFree(m->vec_steps);
   if (m->vec_steps_bf) hipFree(m->vec_steps_bf);
@@ -1212,6 +1267,15 @@ extern "C" int fmi_flux_set_modulation_gemm(fmi_flux* m, int enable) {
   return FMI_OK;
 }
 // how quantised block linears are multiplied: 0 (default) by size, 1 expanded once into bf16 copies (dense cache), 2 always fused
+extern "C" int fmi_flux_set_sequence_parallel(fmi_flux* m, int rank, int world_size, fmi_all_to_all_fn a2a, void* user) {
+  if (!m) return fail(FMI_ERR_INVALID, "set_sequence_parallel: null handle");
+  if (world_size < 1 || rank < 0 || rank >= world_size) return fail(FMI_ERR_INVALID, "set_sequence_parallel: rank outside [0, world_size)");
+  if (world_size > 1 && !a2a) return fail(FMI_ERR_INVALID, "set_sequence_parallel: world_size > 1 needs the all-to-all callback");
+  if (m->H % world_size) return fail(FMI_ERR_INVALID, "set_sequence_parallel: " + std::to_string(m->H) + " heads do not split over " + std::to_string(world_size) + " ranks");
+  m->sp_rank = rank, m->sp_world = world_size;
+  m->sp_a2a = world_size > 1 ? a2a : nullptr, m->sp_user = user;
+  return FMI_OK;
+}
 extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int mode) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
   if (mode < 0 || mode > 2) return fail(FMI_ERR_INVALID, "set_quant_dense_cache: mode must be 0 (by size), 1 (dense cache) or 2 (always fused)");

@@ -185,3 +185,77 @@ def _all_to_all(recv: List[torch.Tensor], send: List[torch.Tensor], group=None):
     for t in recv:
         t.copy_(flat_recv[off:off + t.numel()].view_as(t))
         off += t.numel()
+
+
+# ---------------------------------------------------------------------------------------------
+# The wired path: FluxModel.set_sequence_parallel + this class.  The C library packs the exchange buffers and calls
+# back for the collective (include/flux_mi355x.h: fmi_all_to_all_fn); here the collective is torch.distributed's
+# all_to_all_single — RCCL over xGMI with the "nccl" backend (equal splits: one message of bytes_per_peer to each peer),
+# a host-staged exchange with gloo (tests: two ranks sharing one GPU).
+class _DeviceBytes:
+    """A device buffer known by address, visible to torch without a copy (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class SequenceParallel:
+    """Sequence-parallel group for ONE image: rank r holds txt tokens [r*T/N, (r+1)*T/N) and img tokens [r*S/N, (r+1)*S/N)."""
+
+    def __init__(self, device, group=None):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("SequenceParallel needs an initialised torch.distributed process group")
+        self.group = group
+        self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
+        self.device = torch.device(device)
+        self.backend = dist.get_backend(group)
+        self._views = {}
+        self.exchanges = 0
+        self.bytes_sent = 0
+
+    def _view(self, ptr: int, nbytes: int) -> torch.Tensor:
+        key = (ptr, nbytes)
+        t = self._views.get(key)
+        if t is None:
+            t = self._views[key] = torch.as_tensor(_DeviceBytes(ptr, nbytes), device=self.device)
+        return t
+
+    def all_to_all(self, send: int, recv: int, bytes_per_peer: int, stream) -> None:
+        n = bytes_per_peer * self.world_size
+        st, rt = self._view(send, n), self._view(recv, n)
+        ext = torch.cuda.ExternalStream(int(stream), device=self.device) if stream else torch.cuda.default_stream(self.device)
+        with torch.cuda.stream(ext):
+            if self.backend == "nccl":
+                dist.all_to_all_single(rt, st, group=self.group)  # ordered on `ext` by the process group
+            else:  # gloo has no device all-to-all: stage through the host (st.cpu() waits for the packing kernel on `ext`)
+                hs = st.cpu()
+                hr = torch.empty_like(hs)
+                dist.all_to_all_single(hr, hs, group=self.group)
+                rt.copy_(hr)
+        self.exchanges += 1
+        self.bytes_sent += n - bytes_per_peer
+
+    def attach(self, flux_model) -> None:
+        flux_model.set_sequence_parallel(self.rank, self.world_size, self.all_to_all)
+
+    def detach(self, flux_model) -> None:
+        flux_model.set_sequence_parallel(0, 1, None)
+
+    def shard(self, x: torch.Tensor, dim: int = 1) -> torch.Tensor:
+        """This rank's equal share of axis `dim` (the token axis)."""
+        n = x.shape[dim]
+        if n % self.world_size:
+            raise ValueError(f"{n} tokens do not split evenly over {self.world_size} ranks")
+        per = n // self.world_size
+        return x.narrow(dim, self.rank * per, per).contiguous()
+
+    def gather(self, x_local: torch.Tensor, dim: int = 1) -> torch.Tensor:
+        """Inverse of shard: every rank gets the full axis back (all_gather; host-staged for gloo)."""
+        if self.backend == "nccl":
+            parts = [torch.empty_like(x_local) for _ in range(self.world_size)]
+            dist.all_gather(parts, x_local.contiguous(), group=self.group)
+            return torch.cat(parts, dim)
+        h = x_local.contiguous().cpu()
+        parts = [torch.empty_like(h) for _ in range(self.world_size)]
+        dist.all_gather(parts, h, group=self.group)
+        return torch.cat(parts, dim).to(x_local.device)

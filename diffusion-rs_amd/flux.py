@@ -152,6 +152,27 @@ class FluxModel:
         1 / True = expand each matrix once into the bf16 arena and run the dense kernels; 2 = always the fused kernels."""
         L.check(self.lib.fmi_flux_set_quant_dense_cache(self.h, int(mode)))
 
+    def set_sequence_parallel(self, rank: int, world_size: int, all_to_all=None):
+        """Single-image sequence parallelism (fmi_flux_set_sequence_parallel): from now on forward / denoise take THIS rank's
+        token shard (dist.sp_shard) and the joint attention trades heads for tokens through `all_to_all`
+        (callable(send_ptr, recv_ptr, bytes_per_peer, stream_ptr) -> None; dist.SequenceParallel provides it on
+        torch.distributed).  world_size 1 switches it off."""
+        if world_size > 1 and all_to_all is None:
+            raise L.FmiError("set_sequence_parallel: world_size > 1 needs an all_to_all callable")
+
+        def _cb(_user, send, recv, nbytes, stream):
+            try:
+                all_to_all(send, recv, nbytes, stream)
+                return 0
+            except Exception as e:  # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                self._sp_error = e
+                return 1
+
+        self._sp_cb = L.ALL_TO_ALL_FN(_cb) if world_size > 1 else L.ALL_TO_ALL_FN()  # keep the thunk alive with the model
+        L.check(self.lib.fmi_flux_set_sequence_parallel(self.h, int(rank), int(world_size), self._sp_cb, None))
+
     # ---- the weights as flat device buffers (multi-GPU broadcast, dist.broadcast_state)
     def state_export(self) -> bytes:
         n = C.c_size_t()

@@ -251,6 +251,12 @@ class Pipeline:
             raise ValueError("sample_ids must name one stream per prompt")
         if B == 0:
             return torch.empty((0, 3, params.height, params.width), dtype=torch.uint8, device=self.device)
+        sp = getattr(self, "_sp", None)
+        if sp is not None and B > 1:  # sequence parallel: the ranks of the group work on ONE image at a time
+            return torch.cat([self.generate_tensor(
+                prompts[b:b + 1], params, embeddings=None if embeddings is None else (embeddings[0][b:b + 1], embeddings[1][b:b + 1]),
+                latents=None if latents is None else latents[b:b + 1], seed=seed,
+                token_ids=None if token_ids is None else (token_ids[0][b:b + 1], token_ids[1][b:b + 1]), sample_ids=ids[b:b + 1]) for b in range(B)], 0)
         if B > self.MAX_BATCH:  # the reference accepts any batch (pipelines/mod.rs:241-270)
             outs = []
             for a in range(0, B, self.MAX_BATCH):
@@ -288,10 +294,27 @@ class Pipeline:
             mu = self.scheduler.calculate_shift(img.shape[1])
             timesteps = self.scheduler.get_timesteps(params.num_steps, mu)
             guidance = torch.full((B,), float(params.guidance_scale), dtype=torch.float32, device=dev) if self.flux.is_guidance() else None
-            img = self.flux.denoise(img, img_ids, t5_emb, txt_ids, clip_emb, guidance, timesteps)
+            if sp is not None:  # every rank holds the same inputs; each denoises its token shard, then all get the latents
+                img = sp.gather(self.flux.denoise(sp.shard(img), sp.shard(img_ids), sp.shard(t5_emb), sp.shard(txt_ids), clip_emb, guidance, timesteps))
+            else:
+                img = self.flux.denoise(img, img_ids, t5_emb, txt_ids, clip_emb, guidance, timesteps)
             z = F.unpack_latents(img, 16, h, w, self.vae.scale_factor(), self.vae.shift_factor())
             image = self.vae.decode(z)
             return F.postprocess_u8(image)
+
+    def enable_sequence_parallel(self, group=None):
+        """Single-image latency mode: the ranks of `group` (default: all of torch.distributed) denoise every
+        image TOGETHER, each on 1/N of its tokens (dist.SequenceParallel; two all-to-alls per transformer block), instead of
+        sharding the prompt list.  Every rank must call forward / generate_tensor with the same arguments."""
+        from . import dist as D
+        self._sp = D.SequenceParallel(self.device, group)
+        self._sp.attach(self.flux)
+        return self._sp
+
+    def disable_sequence_parallel(self):
+        if getattr(self, "_sp", None) is not None:
+            self._sp.detach(self.flux)
+            self._sp = None
 
     def forward(self, prompts: List[str], params: DiffusionGenerationParams, *, output: str = "png", **kw):
         """== Pipeline::forward (pipelines/mod.rs:241-270) + the PNG encode of the pyo3 binding.
@@ -299,7 +322,11 @@ class Pipeline:
         the images are gathered to rank 0; every rank must make the same call, ranks != 0 return None."""
         from . import dist as D
         rank, world = D.world()
-        if world > 1:
+        if getattr(self, "_sp", None) is not None:  # all ranks produce every image together; rank 0 returns them
+            u8 = self.generate_tensor(prompts, params, **kw)
+            if rank != 0:
+                return None
+        elif world > 1:
             n = len(prompts)
 
             def pick(x, ids):

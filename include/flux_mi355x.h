@@ -133,6 +133,19 @@ int fmi_flux_set_linear_int8(fmi_flux*, const char* prefix, const int8_t* weight
  * expanded ONCE into its slot of the bf16 arena (allocated on first use, +16 GB).  mode 2: every launch on the fused
  * kernels.  All three produce the same bits. */
 int fmi_flux_set_quant_dense_cache(fmi_flux*, int mode);
+/* Single-image sequence parallelism.  The reference runs one image on one device
+ * (pipelines/mod.rs:214-217 "This will need to be updated!"); here the tokens of ONE image are sharded over the
+ * world_size ranks of a group: rank r passes ONLY its token shard to fmi_flux_forward / fmi_flux_denoise
+ * (txt rows [r*T/N, (r+1)*T/N), img rows [r*S/N, (r+1)*S/N), the matching txt_ids / img_ids rows; B = 1) and gets
+ * its shard of the prediction / latents back.  Everything per token runs on the local rows; the joint attention
+ * (model.rs:540-552) is made head-local by two all-to-alls per block, which the library asks the caller to run:
+ *   a2a(user, send, recv, bytes_per_peer, stream): block p (bytes_per_peer bytes) of `send` goes to rank p, block p
+ *   of `recv` comes from rank p; device buffers owned by the library; the exchange must be ordered on `stream`
+ *   (hipStream_t) like a kernel launch (RCCL: all_to_all on that stream).  Returns 0 on success.
+ * Needs heads % world_size == 0 and equal shards (T, S divisible by world_size); bf16 mode.  world_size 1 (or a
+ * null callback) switches it off.  Results are bit-identical to the single-device forward. */
+typedef int (*fmi_all_to_all_fn)(void* user, const void* send, void* recv, size_t bytes_per_peer, void* stream);
+int fmi_flux_set_sequence_parallel(fmi_flux*, int rank, int world_size, fmi_all_to_all_fn a2a, void* user);
 /* Process-wide: rows from which 4-bit GEMMs use the one-wave-per-SIMD fused kernel (default 256). */
 int fmi_set_bnb4_onewave_min_rows(int rows);
 /* Test hook of the attention kernel's deferred-rescale branch: 0 = rescale on every key tile, else the
