@@ -20,8 +20,9 @@
 //     In the generated steady-state loop the slices are levelled to ~6 instructions per gap (an MFMA occupies the pipe
 //     for 32 clocks: a gap that needs more stalls it) and two pairs are in flight, because a v_exp_f32 result read two
 //     or three instructions later is stale in half of the lanes (tools/gen_attention_w4_loop.py).
-//   * The (fragment read -> MFMA) stream is continuous across phases: the read for MFMA i + 8 is issued behind MFMA i,
-//     whichever phase it belongs to, so no phase starts with an exposed LDS latency.
+//   * The (fragment read -> MFMA) stream is continuous across phases: the read for MFMA i + 7 is issued behind MFMA i,
+//     whichever phase it belongs to, so no phase starts with an exposed LDS latency.  It lands in the buffer MFMA i - 1
+//     consumed, never in MFMA i's own operand (nothing orders the LDS return behind a queued MFMA's operand read).
 //   * K (64 keys x 128 d) and V^T (128 d x 64 keys) tiles arrive by LDS-DMA into 4-deep rings (128 KiB), K three
 //     tiles ahead, V^T two; ONE barrier per KV tile, in the middle of A(t): it publishes K(t+1) / V^T(t) half a phase
 //     before their first read and, with four slots, a slot is rewritten a whole tile after its last read; waits are
@@ -46,7 +47,7 @@ struct Aw4Phase {  // one phase of the MFMA stream: PV of query block b_pv and /
 template <int THR_X16>
 __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16_t* __restrict Q, const bf16_t* __restrict K, const bf16_t* __restrict Vt,
                                                                       AttnOut out, int H, int Lq, int Lk, int Lkpad, float scale_log2e) {
-  constexpr int TILE = 16384, VT_RING = 4 * TILE, PF = 8;  // PF fragment reads in flight; PF divides the phase lengths, so buffer i % PF lines up across phases
+  constexpr int TILE = 16384, VT_RING = 4 * TILE, PF = 8;  // PF fragment buffers, PF - 1 reads in flight; PF divides the phase lengths, so buffer i % PF lines up across phases
   __shared__ __attribute__((aligned(16))) char smem[8 * TILE];  // K ring [4][64 x 128] at 0, V^T ring [4][128 x 64] at 64 KiB
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
   // that refills the buffer the MFMA has just consumed — ONE asm statement, so the MFMA stays below the wait without a
   // register tie and hipcc pads no s_nop between the three.  rd_imm < 0: no read.
 #define FMI_AW4_G3(WAIT, CSTR, OUT, B, IMM)                                                                                                  \
-  asm volatile(WAIT "v_mfma_f32_32x32x16_bf16 %0, %1, %2, " CSTR "\n\tds_read_b128 %1, %3 offset:" #IMM : OUT, "+v"(f) : B, "v"(ra))
+  asm volatile(WAIT "v_mfma_f32_32x32x16_bf16 %0, %2, %3, " CSTR "\n\tds_read_b128 %1, %4 offset:" #IMM : OUT, "=&v"(g) : "v"(f), B, "v"(ra))
 #define FMI_AW4_G2(WAIT, CSTR, OUT, B) asm volatile(WAIT "v_mfma_f32_32x32x16_bf16 %0, %1, %2, " CSTR : OUT : "v"(f), B)
 #define FMI_AW4_G2D(WAIT, CSTR, OUT, B) asm volatile(WAIT "v_mfma_f32_32x32x16_bf16 %0, %1, %2, " CSTR "\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : OUT : "v"(f), B)
 #define FMI_AW4_GAP(WAIT, CSTR, OUT, B)                        \
@@ -269,9 +270,9 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
   // accumulator half (AGPRs), S^T, P and the streamed K / V^T fragments in the architectural VGPRs the softmax VALU works on.
   // (With builtins hipcc put S^T into AGPRs and moved it back and forth: ~280 v_accvgpr moves per KV tile.)  hipcc pads no
   // hazards around asm: every consumer of an MFMA result sits >= 3 MFMAs behind its producer by construction of the
-  // schedule (noted at each site); the first d-step of S^T starts from the constant 0.  The refill read overwrites the
-  // MFMA's own A operand: the MFMA has read it long before the LDS data returns.
-  auto mfma_step = [&](const Aw4Phase& p, int i, frag_t& f, int wait, uint32_t ra, int rd_imm) __attribute__((always_inline)) {
+  // schedule (noted at each site); the first d-step of S^T starts from the constant 0.  The read in a gap refills the
+  // buffer of the PREVIOUS MFMA (see `phase`).
+  auto mfma_step = [&](const Aw4Phase& p, int i, frag_t& f, frag_t& g, int wait, uint32_t ra, int rd_imm) __attribute__((always_inline)) {
     const bool pv = p.has_pv && (!p.has_qk || (i & 1) == 0);
     const int j = (p.has_pv && p.has_qk) ? (i >> 1) : i;
     if (pv) {
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
     return pv ? (j & 3) * 4096 : (j & 1) * 8192;
   };
   // One phase; its product mix (has_pv, has_qk, blocks) is a literal at every call site, so the gaps below specialise at
-  // compile time.  `nx` = the phase that follows (its first PF fragment reads are issued behind this phase's last MFMAs;
+  // compile time.  `nx` = the phase that follows (its first PF - 1 fragment reads are issued behind this phase's last MFMAs;
   // its QK^T part may be a run-time choice).  sm: softmax of block b_sm / tile t_sm in the gaps.  bar_gap >= 0: the tile
   // barrier sits in that gap, after waiting until at most bar_vm of this wave's DMA pieces are outstanding.  dma: 1 = the
   // pieces of V^T(dma_tile) in the second half (behind the barrier), 2 = those of K(dma_tile), one every 8 gaps.
@@ -308,23 +309,29 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
     for (int i = 0; i < 32; ++i) {
       if (i < n) {
         // every fourth gap waits for the fragments of gaps i .. i+3: at most PF - 4 younger reads may be pending
+        // The read behind MFMA i fetches fragment i + RD of the stream (RD = PF - 1) into the buffer MFMA i - 1 consumed — never
+        // into MFMA i's own A operand: an MFMA can still be waiting for the matrix pipe when the LDS data returns, and nothing
+        // orders that register write behind the operand read (with other work on the CU the MFMA then multiplied the fragment
+        // meant for MFMA i + 8: tools/attn_race.hip).  MFMA i has issued, so MFMA i - 1 has left the front of the pipe.
+        constexpr int RD = PF - 1;
         const int ahead = n - i - 4 + nn;  // stream reads issued beyond gap i + 3
-        const int wait = (i & 3) == 0 ? min(PF - 4, max(ahead, 0)) : -1;
-        if (adv && i + PF == n) {  // all own reads are out: move the address registers to the next iteration's slots
+        const int wait = (i & 3) == 0 ? min(RD - 4, max(ahead, 0)) : -1;
+        if (adv && i + RD == n) {  // all own reads are out: move the address registers to the next iteration's slots
           if (adv & 1) advance_k(adv_u);  // A(u): K leaves slot u, V^T slot u - 1
           if (adv & 2) advance_v(adv_u - 1);
         }
-        if (i + PF < n) {
-          mfma_step(p, i, fr[i % PF], wait, frag_reg(has_pv, has_qk, i + PF), frag_imm(has_pv, has_qk, i + PF));
-        } else if (i + PF - n < nn) {  // the next phase's first fragments (its product mix may be a run-time choice)
-          const int k = i + PF - n;
-          if (nx.has_pv && nx.has_qk) mfma_step(p, i, fr[i % PF], wait, frag_reg(true, true, k), frag_imm(true, true, k));
-          else if (nx.has_pv) mfma_step(p, i, fr[i % PF], wait, frag_reg(true, false, k), frag_imm(true, false, k));
-          else mfma_step(p, i, fr[i % PF], wait, frag_reg(false, true, k), frag_imm(false, true, k));
+        frag_t& dst = fr[(i + RD) % PF];
+        if (i + RD < n) {
+          mfma_step(p, i, fr[i % PF], dst, wait, frag_reg(has_pv, has_qk, i + RD), frag_imm(has_pv, has_qk, i + RD));
+        } else if (i + RD - n < nn) {  // the next phase's first fragments (its product mix may be a run-time choice)
+          const int k = i + RD - n;
+          if (nx.has_pv && nx.has_qk) mfma_step(p, i, fr[i % PF], dst, wait, frag_reg(true, true, k), frag_imm(true, true, k));
+          else if (nx.has_pv) mfma_step(p, i, fr[i % PF], dst, wait, frag_reg(true, false, k), frag_imm(true, false, k));
+          else mfma_step(p, i, fr[i % PF], dst, wait, frag_reg(false, true, k), frag_imm(false, true, k));
         } else {
           // no read; rd_imm -2 on the phase's last MFMA = drain inside the statement (used in front of the pinned loop statement:
           // hipcc may copy S^T / O^T right behind this statement and knows nothing of the MFMAs in flight)
-          mfma_step(p, i, fr[i % PF], wait, 0u, (tail_drain && i == n - 1) ? -2 : -1);
+          mfma_step(p, i, fr[i % PF], dst, wait, 0u, (tail_drain && i == n - 1) ? -2 : -1);
         }
         const int g0 = n == 32 ? i : 2 * i;  // a 16-MFMA phase carries two softmax slices per gap
         // (its first max step would sit one MFMA behind the previous phase's last write of S^T: drain once, untied asm order)
@@ -354,8 +361,8 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
   const Aw4Phase none{false, false, 0, 0};
   {
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      switch (i) {  // the first PF fragments of pre: K(0), key half i & 1, d-step i >> 1
+    for (int i = 0; i < PF - 1; ++i) {
+      switch (i) {  // the first PF - 1 fragments of pre: K(0), key half i & 1, d-step i >> 1
         case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(fr[0]) : "v"(k_ad[0])); break;
         case 1: asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fr[1]) : "v"(k_ad[0])); break;
         case 2: asm volatile("ds_read_b128 %0, %1" : "=v"(fr[2]) : "v"(k_ad[1])); break;

@@ -182,11 +182,7 @@ def _pipeline_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import diffusion_rs_amd as d
-        from diffusion_rs_amd import _lib as L
         from tests.util import SMALL_VAE
-        # two processes share this GPU: use the 8-wave attention kernel, whose results do not depend on what else runs on the
-        # device (the one-wave kernel's do, DESIGN 4.4 "GPU sharing")
-        L.check(L.load().fmi_set_attention_kernel(1))
         pipe = d.Pipeline.load(d.ModelSource.Synthetic("dev", seed=4, flux_cfg=FLUX4, vae_cfg=SMALL_VAE))
         params = d.DiffusionGenerationParams(height=128, width=128, num_steps=3, guidance_scale=3.5)
         prompts = ["a red fox", "a blue heron"]

@@ -246,27 +246,31 @@ def phase(name, b_pv, b_qk, b_sm, is_a, uid):
             pre.append(f"s_add_i32 m0, {S_M0V}, {piece * 1024}")
             dma = f"global_load_lds_dwordx4 v{144 + piece}, {S_VP}"
         # ---- address registers move to the next ring slot behind this phase's last own read (A only).  The fragments of the
-        # next phase fetched in gaps 24..31 need v_ad[0], k_ad[0] (from gap 24 / 25) and k_ad[1] (gap 29); the other nine
-        # follow one per gap.
-        if is_a and i == 24:
+        # next phase fetched in gaps 25..31 need v_ad[0] (gap 25), k_ad[0] (gap 26) and k_ad[1] (gap 30); the other nine
+        # follow one per gap (the own reads end with gap 24's: fragment 31, k_ad[7]).
+        if is_a and i == 25:
             pre += [f"v_xor_b32 {VAD(0)}, {S_MKV}, {VAD(0)}", f"v_xor_b32 {KAD(0)}, {S_MKK}, {KAD(0)}"]
             lazy_xor = [f"v_xor_b32 {KAD(1)}, {S_MKK}, {KAD(1)}"] + [f"v_xor_b32 {VAD(c)}, {S_MKV}, {VAD(c)}" for c in (1, 2, 3)] + \
                        [f"v_xor_b32 {KAD(s)}, {S_MKK}, {KAD(s)}" for s in range(2, 8)]
         # ---- the MFMA of gap i, behind a counted wait every fourth gap
         if (i & 3) == 0:
-            pre.append("s_waitcnt lgkmcnt(2)" if os.environ.get("AW4_X") == "halfreads" else "s_waitcnt lgkmcnt(4)")
+            pre.append("s_waitcnt lgkmcnt(2)" if os.environ.get("AW4_X") == "halfreads" else f"s_waitcnt lgkmcnt({PF - 5})")
         j = i >> 1
         if i % 2 == 0:
             mf = f"v_mfma_f32_32x32x16_bf16 {OT(b_pv, j & 3)}, {FR(i)}, {PFt(b_pv, j >> 2)}, {OT(b_pv, j & 3)}"
         else:
             u, s = j & 1, j >> 1
             mf = f"v_mfma_f32_32x32x16_bf16 {SC(b_qk, u)}, {FR(i)}, {QF(b_qk, s)}, {'0' if s == 0 else SC(b_qk, u)}"
-        # ---- the read that refills the buffer this MFMA consumed: fragment i + PF of this phase or i + PF - 32 of the next
-        reg, imm = frag_src((i + PF) % 32)
-        rd = f"ds_read_b128 {FR(i)}, {reg} offset:{imm}"
+        # ---- the read behind MFMA i refills the buffer that MFMA i - 1 consumed (fragment i + PF - 1 of this phase, or
+        # i + PF - 1 - 32 of the next).  Never the buffer of MFMA i itself: an MFMA can still be waiting for the matrix pipe
+        # when the LDS data returns, and nothing orders the LDS write to its A operand behind the operand read — with other
+        # work on the CU the MFMA then multiplied the fragment meant for MFMA i + 8 (tools/attn_race.hip).  MFMA i has
+        # issued, so MFMA i - 1 has left the pipe's front: its operands are free by construction, not by timing.
+        reg, imm = frag_src((i + PF - 1) % 32)
+        rd = f"ds_read_b128 {FR(i + PF - 1)}, {reg} offset:{imm}"
         # ---- softmax slice of gap i (see `softmax_plan`)
         post += sm_plan[i]
-        if lazy_xor and i >= 24:
+        if lazy_xor and i >= 25:
             post.append(lazy_xor.pop(0))
         if is_a and i == 31:
             post += lazy_xor
@@ -292,8 +296,8 @@ def phase(name, b_pv, b_qk, b_sm, is_a, uid):
 
 def loop():
     o = []
-    # the first PF fragments of B(0) (the statement is entered with nothing in flight), then zero iterations when ntiles == 2
-    for k in range(PF):
+    # the first PF - 1 fragments of B(0) (the statement is entered with nothing in flight), then zero iterations when ntiles == 2
+    for k in range(PF - 1):
         reg, imm = frag_src(k)
         o.append(f"ds_read_b128 {FR(k)}, {reg} offset:{imm}")
     o += [f"s_mov_b32 {S_T}, 0",
