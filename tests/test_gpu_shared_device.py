@@ -86,6 +86,48 @@ def test_attention_and_gemm_reproduce_their_idle_results_while_another_process_u
             L.check(lib.fmi_linear_bf16(_p(x), _p(w), _p(b), _p(y), M, N, K, epi, None))
             return y
         cases.append((f"linear {M}x{N}x{K} epi {epi}", run))
+    # the fused quantised GEMMs (nf4 one-wave and two-workgroup kernels, LLM.int8 stage), the fp8 GEMM and the fp8-QK attention
+    for (M, N, K) in ((4608, 3072, 3072), (300, 3072, 3072), (128, 9216, 3072)):
+        x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+        packed = torch.randint(0, 256, (N * K // 2,), generator=g, device="cuda", dtype=torch.uint8)  # any byte is a pair of nf4 codes
+        absmax = torch.rand((N * K // 64,), generator=g, device="cuda") * 0.05 + 0.01
+        w8 = torch.randint(-127, 128, (N, K), generator=g, device="cuda", dtype=torch.int8)
+        scb = torch.rand((N,), generator=g, device="cuda") * 0.05 + 0.01
+
+        def run_nf4(x=x, packed=packed, absmax=absmax, M=M, N=N, K=K):
+            y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            L.check(lib.fmi_linear_bnb4_bf16(_p(x), _p(packed), _p(absmax), 64, 2, None, _p(y), M, N, K, 0, None))
+            return y
+
+        def run_int8(x=x, w8=w8, scb=scb, M=M, N=N, K=K):
+            y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            L.check(lib.fmi_linear_int8_bf16(_p(x), _p(w8), _p(scb), None, _p(y), M, N, K, 0, None))
+            return y
+        cases.append((f"linear nf4 {M}x{N}x{K}", run_nf4))
+        cases.append((f"linear int8 {M}x{N}x{K}", run_int8))
+    M, N, K = 4608, 3072, 3072
+    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    wq, ws = torch.empty((N, K), dtype=torch.uint8, device="cuda"), torch.empty((N,), dtype=torch.float32, device="cuda")
+    L.check(lib.fmi_quantize_rows_fp8(_p(w), N, K, _p(wq), _p(ws), None))
+
+    def run_fp8(x=x, wq=wq, ws=ws, M=M, N=N, K=K):
+        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        L.check(lib.fmi_linear_fp8(_p(x), _p(wq), _p(ws), None, _p(y), M, N, K, 0, None))
+        return y
+    cases.append((f"linear fp8 {M}x{N}x{K}", run_fp8))
+    H, Lq = 24, 4608
+    q, k, v = (torch.randn((1, H, Lq, 128), generator=g, device="cuda").to(torch.bfloat16) for _ in range(3))
+    q8, k8 = (torch.empty((1, H, Lq, 128), dtype=torch.uint8, device="cuda") for _ in range(2))
+    sq, sk = (torch.empty((H * Lq,), dtype=torch.float32, device="cuda") for _ in range(2))
+    L.check(lib.fmi_quantize_rows_fp8(_p(q), H * Lq, 128, _p(q8), _p(sq), None))  # (per-row scales: only the codes are used here)
+    L.check(lib.fmi_quantize_rows_fp8(_p(k), H * Lq, 128, _p(k8), _p(sk), None))
+
+    def run_fp8_attn(q8=q8, k8=k8, v=v, H=H, Lq=Lq):
+        o = torch.full((1, Lq, H * 128), float("nan"), dtype=torch.bfloat16, device="cuda")
+        L.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o), 1, H, Lq, Lq, 128, 1e-5, 1, None))
+        return o
+    cases.append(("sdpa fp8 QK", run_fp8_attn))
     try:
         idle = []
         for name, run in cases:
@@ -97,7 +139,7 @@ def test_attention_and_gemm_reproduce_their_idle_results_while_another_process_u
             bad = {}
             reps = 0
             t0 = time.time()
-            while time.time() - t0 < 12:
+            while time.time() - t0 < 15:
                 for (name, run), ref in zip(cases, idle):
                     out = run()
                     if not torch.equal(out.view(torch.int16), ref.view(torch.int16)):
