@@ -153,6 +153,36 @@ int launch_split_rows_f32(const float* src, float* dst, int B, int rows_src_per_
   return FMI_OK;
 }
 
+namespace {
+__global__ void splitk_resid_gate_kernel(const float4* __restrict__ parts, int S, const bf16_t* __restrict__ bias, const float* __restrict__ gate,
+                                         int rows_per_batch, int gate_bstride, float* __restrict__ out, int ldo, int M, int N4) {
+  const int64_t total = (int64_t)M * N4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / N4), n = (int)(i % N4) * 4;
+    float4 v = parts[i];
+    for (int s = 1; s < S; ++s) {  // fixed order: the result does not depend on the launch
+      const float4 w = parts[(int64_t)s * total + i];
+      v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+    }
+    if (bias) v.x += bf16_to_f32(bias[n]), v.y += bf16_to_f32(bias[n + 1]), v.z += bf16_to_f32(bias[n + 2]), v.w += bf16_to_f32(bias[n + 3]);
+    const float* g = gate + (rows_per_batch > 0 ? (int64_t)(m / rows_per_batch) * gate_bstride : 0) + n;
+    float4* o = reinterpret_cast<float4*>(out + (int64_t)m * ldo + n);
+    float4 x = *o;
+    x.x += g[0] * v.x, x.y += g[1] * v.y, x.z += g[2] * v.z, x.w += g[3] * v.w;
+    *o = x;
+  }
+}
+}  // namespace
+int launch_splitk_resid_gate(const float* parts, int S, const bf16_t* bias, const float* gate, int rows_per_batch, int gate_bstride, float* out, int ldo,
+                             int M, int N, hipStream_t stream) {
+  if (N % 4 || ldo % 4) return fail(FMI_ERR_INVALID, "splitk reduce: N and ldo must be multiples of 4");
+  const int64_t total = (int64_t)M * (N / 4);
+  splitk_resid_gate_kernel<<<(int)std::min<int64_t>((total + 255) / 256, 2048), 256, 0, stream>>>(reinterpret_cast<const float4*>(parts), S, bias, gate, rows_per_batch,
+                                                                                                 gate_bstride, out, ldo, M, N / 4);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
 }  // namespace fmi
 
 using namespace fmi;
