@@ -142,6 +142,10 @@ struct fmi_flux {
   int sp_Tl = 0, sp_Sl = 0;
   void *sp_send = nullptr, *sp_recv = nullptr;
   bf16_t *sp_Qf = nullptr, *sp_Kf = nullptr, *sp_Vtf = nullptr, *sp_O = nullptr;
+  // latency mode for small launches (fmi_flux_set_split_k): see gemm_split_k
+  bool split_k = false;
+  float* splitk_scratch = nullptr;
+  size_t splitk_floats = 0;
   // fp8 mode (fmi_flux_quantize_fp8)
   bool fp8 = false;
   char* fp8_arena = nullptr;
@@ -548,9 +552,69 @@ int densify(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s)
   }
   return FMI_OK;
 }
+// Latency mode (opt-in, fmi_flux_set_split_k): a residual projection whose launch is less than half a wave of 256 x 256 tiles —
+// a sequence-parallel shard of 576 rows x 3072 columns is 36 tiles on 256 CUs, and a tile's K loop (K up to 15 360) takes as long
+// as in the full-size launch — is cut along K into S problems of the SAME grouped launch (A and W advanced by s * K / S columns,
+// partial products stored as f32), and a second kernel adds the S parts in index order, the bias, and applies the gated residual
+// update.  Deterministic (fixed order), but NOT the bits of the unsplit launch: the f32 sum is associated differently.  That is
+// why it is opt-in: by default a sequence-parallel forward reproduces the single-device one bit for bit.
+int gemm_split_k(fmi_flux* m, const GemmProblem* p, int n, hipStream_t s, bool* done) {
+  *done = false;
+  if (!m->split_k || n < 1 || n > 2) return FMI_OK;
+  int tiles = 0;
+  size_t floats = 0;
+  for (int i = 0; i < n; ++i) {
+    const GemmProblem& q = p[i];
+    if (q.epi != EPI_RESID_GATE_F32 || q.q_type || q.fp8 || q.cv_ks || q.qk_qh || q.alpha != 1.0f || q.N % 4 || q.ldo % 4) return FMI_OK;
+    tiles += ((q.M + 255) / 256) * ((q.N + 255) / 256);
+    floats += (size_t)q.M * q.N;
+  }
+  if (tiles >= 128) return FMI_OK;
+  int S = 8;
+  auto fits = [&](int S_) {
+    if (tiles * S_ > 256 || n * S_ > 8) return false;
+    for (int i = 0; i < n; ++i)
+      if (p[i].K % (64 * S_) || p[i].K / S_ < 256) return false;
+    return true;
+  };
+  while (S > 1 && !fits(S)) S >>= 1;
+  if (S == 1) return FMI_OK;
+  if (floats * S > m->splitk_floats) {
+    FMI_HIP_TRY(hipStreamSynchronize(s));
+    if (m->splitk_scratch) FMI_HIP_TRY(hipFree(m->splitk_scratch));
+    m->splitk_scratch = nullptr, m->splitk_floats = 0;
+    FMI_HIP_TRY(hipMalloc((void**)&m->splitk_scratch, floats * S * sizeof(float)));
+    m->splitk_floats = floats * S;
+  }
+  GemmProblem parts[8];
+  const float* base[2];
+  float* cur = m->splitk_scratch;
+  int np = 0;
+  for (int i = 0; i < n; ++i) {
+    base[i] = cur;
+    const int Kc = p[i].K / S;
+    for (int k = 0; k < S; ++k) {
+      GemmProblem q = p[i];
+      q.A = p[i].A + (size_t)k * Kc, q.W = p[i].W + (size_t)k * Kc, q.K = Kc;
+      q.bias = nullptr, q.gate = nullptr, q.rows_per_batch = 0, q.gate_bstride = 0;
+      q.epi = EPI_STORE_F32, q.out = cur, q.ldo = p[i].N;
+      parts[np++] = q;
+      cur += (size_t)p[i].M * p[i].N;
+    }
+  }
+  FMI_TRY(launch_gemm(parts, np, s));
+  for (int i = 0; i < n; ++i)
+    FMI_TRY(launch_splitk_resid_gate(base[i], S, p[i].bias, p[i].gate, p[i].rows_per_batch, p[i].gate_bstride, reinterpret_cast<float*>(p[i].out), p[i].ldo, p[i].M,
+                                     p[i].N, s));
+  *done = true;
+  return FMI_OK;
+}
 // launch 1 or 2 problems (dn[i] = the weight matrix of problem i); quantised and dense problems cannot share a grid
 int gemm2(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s) {
   FMI_TRY(densify(m, p, dn, n, s));
+  bool split = false;
+  FMI_TRY(gemm_split_k(m, p, n, s, &split));
+  if (split) return FMI_OK;
   if (n == 2 && (p[0].q_type != 0) != (p[1].q_type != 0)) {
     FMI_TRY(launch_gemm(p, 1, s));
     return launch_gemm(p + 1, 1, s);
@@ -931,6 +995,7 @@ extern "C" void fmi_flux_destroy(fmi_flux* m) {
   for (int k = 0; k < 2; ++k)
     if (m->wscratch[k]) hipFree(m->wscratch[k]);
   if (m->sp_base) hipFree(m->sp_base);
+  if (m->splitk_scratch) hipFree(m->splitk_scratch);
   if (m->mod_steps) hipFree(m->mod_steps);
   if (m->vec_steps) hipFree(m->vec_steps);
   if (m->vec_steps_bf) hipFree(m->vec_steps_bf);
@@ -1274,6 +1339,11 @@ extern "C" int fmi_flux_set_sequence_parallel(fmi_flux* m, int rank, int world_s
   if (m->H % world_size) return fail(FMI_ERR_INVALID, "set_sequence_parallel: " + std::to_string(m->H) + " heads do not split over " + std::to_string(world_size) + " ranks");
   m->sp_rank = rank, m->sp_world = world_size;
   m->sp_a2a = world_size > 1 ? a2a : nullptr, m->sp_user = user;
+  return FMI_OK;
+}
+extern "C" int fmi_flux_set_split_k(fmi_flux* m, int enable) {
+  if (!m) return fail(FMI_ERR_INVALID, "set_split_k: null handle");
+  m->split_k = enable != 0;
   return FMI_OK;
 }
 extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int mode) {

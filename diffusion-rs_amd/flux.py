@@ -152,6 +152,11 @@ class FluxModel:
         1 / True = expand each matrix once into the bf16 arena and run the dense kernels; 2 = always the fused kernels."""
         L.check(self.lib.fmi_flux_set_quant_dense_cache(self.h, int(mode)))
 
+    def set_split_k(self, on: bool):
+        """Latency mode for launches of few rows (sequence-parallel shards): residual projections with fewer than 128 tiles are
+        split along K and reduced in a fixed order — deterministic, equal to the unsplit result to rounding (not bit for bit)."""
+        L.check(self.lib.fmi_flux_set_split_k(self.h, int(bool(on))))
+
     def set_sequence_parallel(self, rank: int, world_size: int, all_to_all=None):
         """Single-image sequence parallelism (fmi_flux_set_sequence_parallel): from now on forward / denoise take THIS rank's
         token shard (dist.sp_shard) and the joint attention trades heads for tokens through `all_to_all`

@@ -148,6 +148,43 @@ def test_sequence_parallel_denoise_is_bit_identical_and_switches_off(env):
     assert torch.equal(again, ref)
 
 
+def test_split_k_latency_mode_is_deterministic_and_equal_to_rounding(env):
+    """fmi_flux_set_split_k: residual projections of small launches are cut along K and reduced in a fixed order — the same
+    result to f32 rounding (stated: rel-L2 <= 1e-3 on a forward), identical from run to run, and the oracle tolerance holds."""
+    torch, d = env["torch"], env["d"]
+    from oracle import oracle as orc
+    from tests.util import host, rel_l2
+    cfg = FLUX4
+    sd = d.synth.flux_state_dict_numpy(cfg, seed=8)
+    img, ids, txt, txt_ids, y = flux_inputs(cfg, 1, (16, 16), 64, seed=4)
+    t, g = np.array([0.8], np.float32), np.array([3.5], np.float32)
+    args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
+    m = d.FluxModel(cfg)
+    m.load_state_dict(sd)
+    plain = m.forward(*args)
+    m.set_split_k(True)
+    a, b = m.forward(*args), m.forward(*args)
+    assert torch.equal(a, b)
+    err = rel_l2(host(a), host(plain))
+    n_diff = int((a != plain).sum())
+    om = orc.Flux(cfg)
+    om.load(sd)
+    err_o = rel_l2(host(a), om.forward(img, ids, txt, txt_ids, t, y, g))
+    print(f"split-K vs unsplit: rel-L2 {err:.2e}, {n_diff} of {a.numel()} f32 outputs differ; vs oracle {err_o:.2e}")
+    assert n_diff > 0, "the latency mode did not engage on this shape"
+    assert err <= 1e-3 and err_o <= 1e-2
+    # with sequence parallelism on top (2 ranks): equal to the single-device result to the same tolerance
+    ranks = ThreadRanks(d, torch, cfg, sd, 2)
+    for mm in ranks.models:
+        mm.set_split_k(True)
+    got = torch.cat(ranks.run(lambda r, mm: mm.forward(dev(_shard(img, r, 2)), dev(_shard(ids, r, 2)), dev(_shard(txt, r, 2), torch.bfloat16),
+                                                       dev(_shard(txt_ids, r, 2)), dev(t), dev(y), dev(g))), 1)
+    torch.cuda.synchronize()
+    assert rel_l2(host(got), host(plain)) <= 1e-3
+    m.set_split_k(False)
+    assert torch.equal(m.forward(*args), plain)
+
+
 def test_sequence_parallel_rejects_what_it_cannot_split(env):
     torch, d = env["torch"], env["d"]
     m = d.FluxModel(SMALL_FLUX)  # 2 heads

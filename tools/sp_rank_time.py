@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--split-k", action="store_true", help="latency mode: FluxModel.set_split_k(True)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     flux = d.FluxModel(d.FLUX_DEV, 0)
@@ -40,6 +41,7 @@ def main():
         flux.set_tensor(name, t)
         del t
     flux.assert_complete()
+    flux.set_split_k(args.split_k)
     S, T, NS = 4096, 512, args.steps
     sched = d.SchedulerConfig()
     ts = sched.get_timesteps(NS, sched.calculate_shift(S))
@@ -73,7 +75,7 @@ def main():
         flux.denoise(lat, ids, txt, tids, y, gd, ts)
         torch.cuda.synchronize()
         ms = (time.time() - t0) * 1e3 / NS
-        row = {"ranks": N, "tokens_per_rank": Sl + Tl, "heads_per_rank": 24 // N, "ms_per_step_compute": round(ms, 2),
+        row = {"ranks": N, "split_k": bool(args.split_k), "tokens_per_rank": Sl + Tl, "heads_per_rank": 24 // N, "ms_per_step_compute": round(ms, 2),
                "exchanges_per_step": stats["calls"] // NS, "MB_sent_per_rank_per_step": round(stats["bytes"] / NS / 1e6, 1)}
         flux.set_profiling(True)  # second pass with a device sync per phase: where the time goes
         flux.denoise(lat, ids, txt, tids, y, gd, ts)
