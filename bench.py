@@ -12,8 +12,9 @@ rank generates its own image (weak scaling, no data-path collective); weights ar
 rank 0 and broadcast over RCCL/xGMI, the decoded u8 images are gathered to rank 0 after the
 timed region.
 
-With N = 1 the same run appends two short legs under "secondary" (2 images each, own roofline): BASELINE config C3
-(nf4 weights, fused dequant-GEMM) and the C5 shape (fp8 e4m3 block linears, 1280x720, batch 2) — `--no-secondary` skips them.
+With N = 1 the same run appends short legs under "secondary" (2 images each, own roofline): BASELINE config C3
+(nf4 weights, fused dequant-GEMM) and the C5 shape (fp8 e4m3 block linears, 1280x720, batch 2), plus the per-rank compute of
+single-image sequence parallelism at 8 ranks (loopback exchange, 10 denoise steps) — `--no-secondary` skips them.
 
 One JSON line is printed by rank 0 (contract in the task statement) with two extra objects:
   roofline     — the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / device time from
@@ -324,6 +325,16 @@ def main():
                                "output_ok": bool(int(out.max()) > int(out.min())), "roofline": r, "weights_resident_gib": round(model.size_in_bytes() / 2**30, 2),
                                "phase_ms_per_denoise_step": ex["phase_ms_per_denoise_step"], "attention_tflops": ex["attention_tflops"]}
 
+        # single-image sequence parallelism: what one of 8 ranks computes per denoise step, exchange as a loopback copy
+        # of the right size (everything but the xGMI wire time) — bit-identical default and the opt-in split-K latency mode
+        ts10 = sched.get_timesteps(10, sched.calculate_shift(4096))
+        sp = {"note": "per-rank compute of ONE image on 8 ranks, measured on this one GPU with a loopback all-to-all "
+                      "(dist.sequence_parallel_rank_time); one device runs the same step in ms_per_denoise_step above; wire time not included"}
+        sp["default_bit_identical"] = fdist.sequence_parallel_rank_time(flux, 8, ts10, dev)
+        flux.set_split_k(True)
+        sp["split_k_latency_mode"] = fdist.sequence_parallel_rank_time(flux, 8, ts10, dev)
+        flux.set_split_k(False)
+        secondary["sequence_parallel_rank"] = sp
         fq = d.FluxModel(d.FLUX_DEV, local_rank)
         fill_flux(fq, "nf4")
         # default policy (flux_model.hip: densify): only the packed codes are resident; the block linears (launches above 383 rows) expand per call

@@ -259,3 +259,56 @@ class SequenceParallel:
         parts = [torch.empty_like(h) for _ in range(self.world_size)]
         dist.all_gather(parts, h, group=self.group)
         return torch.cat(parts, dim).to(x_local.device)
+
+
+def sequence_parallel_rank_time(flux, world_size: int, timesteps, device, S: int = 4096, T: int = 512, seed: int = 0) -> dict:
+    """What ONE rank of an N-rank sequence-parallel group computes per denoise step, measured on one GPU: the model on 1/N of the
+    tokens, the pack / unpack kernels and the attention of H/N heads over all tokens, with the all-to-all replaced by a loopback
+    (the rank's own first send block copied into every receive block: right sizes, one kernel per exchange, meaningless pixels).
+    Wire time of the 2 exchanges per block comes on top; `MB_sent_per_step` says how much would travel.  Measurement aid
+    (tools/sp_rank_time.py, bench.py's `secondary.sequence_parallel_rank`), not a substitute for a multi-GPU run."""
+    import time
+    dev = torch.device(device)
+    cfg = flux.cfg
+    N = int(world_size)
+    stats = {"calls": 0, "bytes": 0}
+    views = {}
+
+    def loopback(send, recv, nbytes, stream):
+        key = (send, recv, nbytes)
+        if key not in views:
+            views[key] = (torch.as_tensor(_DeviceBytes(send, nbytes), device=dev).expand(N, nbytes),
+                          torch.as_tensor(_DeviceBytes(recv, nbytes * N), device=dev).view(N, nbytes))
+        src, dst = views[key]
+        dst.copy_(src)
+        stats["calls"] += 1
+        stats["bytes"] += nbytes * (N - 1)
+
+    flux.set_sequence_parallel(0, N, loopback if N > 1 else None)
+    try:
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        Sl, Tl = S // N, T // N
+        lat = torch.randn((1, Sl, cfg["in_channels"]), generator=g, device=dev)
+        ids = torch.zeros((1, Sl, 3), device=dev)
+        txt = torch.randn((1, Tl, cfg["joint_attention_dim"]), generator=g, device=dev).to(torch.bfloat16)
+        tids = torch.zeros((1, Tl, 3), device=dev)
+        y = torch.randn((1, cfg["pooled_projection_dim"]), generator=g, device=dev)
+        gd = torch.full((1,), 3.5, device=dev) if flux.is_guidance() else None
+        ns = len(timesteps) - 1
+        flux.denoise(lat, ids, txt, tids, y, gd, list(timesteps[:3]))  # warm-up: workspace and exchange buffers
+        torch.cuda.synchronize(dev)
+        stats["calls"] = stats["bytes"] = 0
+        t0 = time.perf_counter()
+        flux.denoise(lat, ids, txt, tids, y, gd, list(timesteps))
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) * 1e3 / ns
+        calls, sent = stats["calls"], stats["bytes"]
+        flux.set_profiling(True)  # second pass with a device sync per phase: where the time goes
+        flux.denoise(lat, ids, txt, tids, y, gd, list(timesteps))
+        phases = {k: round(v / ns, 2) for k, v in flux.phase_ms().items() if v > 0}
+        flux.set_profiling(False)
+    finally:
+        flux.set_sequence_parallel(0, 1, None)
+    return {"ranks": N, "tokens_per_rank": Sl + Tl, "heads_per_rank": cfg["num_attention_heads"] // N, "ms_per_step_compute": round(ms, 2),
+            "exchanges_per_step": calls // ns, "MB_sent_per_step": round(sent / ns / 1e6, 1), "phase_ms_per_step": phases}

@@ -6,7 +6,6 @@ unpack kernels, and the attention over all L tokens of 24/N heads.  The all-to-a
 send block copied into every receive block: right sizes and kernels, meaningless pixels), so the number printed is the
 compute a rank adds per denoise step; the wire time of the two exchanges per block comes on top (sizes printed)."""
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -17,7 +16,7 @@ import torch  # noqa: E402
 
 import diffusion_rs_amd as d  # noqa: E402
 from diffusion_rs_amd import synth  # noqa: E402
-from diffusion_rs_amd.dist import _DeviceBytes  # noqa: E402
+from diffusion_rs_amd import dist as fdist  # noqa: E402
 
 
 def main():
@@ -42,50 +41,18 @@ def main():
         del t
     flux.assert_complete()
     flux.set_split_k(args.split_k)
-    S, T, NS = 4096, 512, args.steps
+    NS = args.steps
     sched = d.SchedulerConfig()
-    ts = sched.get_timesteps(NS, sched.calculate_shift(S))
-    out = []
+    ts = sched.get_timesteps(NS, sched.calculate_shift(4096))
+    first = None
     for N in [int(x) for x in args.worlds.split(",")]:
-        stats = {"calls": 0, "bytes": 0}
-        views = {}
-
-        def loopback(send, recv, nbytes, stream, N=N, stats=stats, views=views):
-            key = (send, recv, nbytes)
-            if key not in views:  # block 0 of the send buffer stands in for every peer's block: ONE copy kernel per exchange
-                views[key] = (torch.as_tensor(_DeviceBytes(send, nbytes), device=dev).expand(N, nbytes),
-                              torch.as_tensor(_DeviceBytes(recv, nbytes * N), device=dev).view(N, nbytes))
-            src, dst = views[key]
-            dst.copy_(src)
-            stats["calls"] += 1
-            stats["bytes"] += nbytes * (N - 1)
-
-        flux.set_sequence_parallel(0, N, loopback if N > 1 else None)
-        Sl, Tl = S // N, T // N
-        lat = torch.randn((1, Sl, 64), generator=g, device=dev)
-        ids = torch.zeros((1, Sl, 3), device=dev)
-        txt = torch.randn((1, Tl, 4096), generator=g, device=dev).to(torch.bfloat16)
-        tids = torch.zeros((1, Tl, 3), device=dev)
-        y = torch.randn((1, 768), generator=g, device=dev)
-        gd = torch.full((1,), 3.5, device=dev)
-        flux.denoise(lat, ids, txt, tids, y, gd, ts[:3])  # warm-up (workspace, exchange buffers)
-        torch.cuda.synchronize()
-        stats["calls"] = stats["bytes"] = 0
-        t0 = time.time()
-        flux.denoise(lat, ids, txt, tids, y, gd, ts)
-        torch.cuda.synchronize()
-        ms = (time.time() - t0) * 1e3 / NS
-        row = {"ranks": N, "split_k": bool(args.split_k), "tokens_per_rank": Sl + Tl, "heads_per_rank": 24 // N, "ms_per_step_compute": round(ms, 2),
-               "exchanges_per_step": stats["calls"] // NS, "MB_sent_per_rank_per_step": round(stats["bytes"] / NS / 1e6, 1)}
-        flux.set_profiling(True)  # second pass with a device sync per phase: where the time goes
-        flux.denoise(lat, ids, txt, tids, y, gd, ts)
-        row["phase_ms_per_step"] = {k: round(v / NS, 2) for k, v in flux.phase_ms().items() if v > 0}
-        flux.set_profiling(False)
-        if out:
-            row["speedup_vs_1_before_wire_time"] = round(out[0]["ms_per_step_compute"] / ms, 2)
-        out.append(row)
+        row = fdist.sequence_parallel_rank_time(flux, N, ts, dev)
+        row["split_k"] = bool(args.split_k)
+        if first is None:
+            first = row["ms_per_step_compute"]
+        else:
+            row["speedup_vs_first_row_before_wire_time"] = round(first / row["ms_per_step_compute"], 2)
         print(json.dumps(row), flush=True)
-    flux.set_sequence_parallel(0, 1, None)
 
 
 if __name__ == "__main__":
