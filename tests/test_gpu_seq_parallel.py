@@ -185,6 +185,26 @@ def test_split_k_latency_mode_is_deterministic_and_equal_to_rounding(env):
     assert torch.equal(m.forward(*args), plain)
 
 
+def test_rank_time_measurement_aid_runs_and_counts_the_exchanges(env):
+    """dist.sequence_parallel_rank_time (bench.py's `secondary.sequence_parallel_rank`, tools/sp_rank_time.py)."""
+    torch, d = env["torch"], env["d"]
+    from diffusion_rs_amd import dist as fdist
+    m = d.FluxModel(FLUX4)
+    m.load_state_dict(d.synth.flux_state_dict_numpy(FLUX4, seed=0))
+    sched = d.SchedulerConfig()
+    ts = sched.get_timesteps(4, sched.calculate_shift(64))
+    row = fdist.sequence_parallel_rank_time(m, 4, ts, "cuda:0", S=64, T=32)
+    assert row["ranks"] == 4 and row["tokens_per_rank"] == 24 and row["heads_per_rank"] == 1
+    assert row["exchanges_per_step"] == 2 * (FLUX4["num_layers"] + FLUX4["num_single_layers"])
+    Ll, Hr, Lpl = 24, 1, 64
+    assert abs(row["MB_sent_per_step"] - 4 * 3 * ((2 * Hr * Ll * 128 + Hr * 128 * Lpl) * 2 + Ll * Hr * 128 * 2) / 1e6) < 0.06
+    assert row["ms_per_step_compute"] > 0 and "attention" in row["phase_ms_per_step"]
+    # the handle is an ordinary single-device model again afterwards
+    img, ids, txt, txt_ids, y = flux_inputs(FLUX4, 1, (8, 8), 32, seed=1)
+    out = m.forward(dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(np.array([0.5], np.float32)), dev(y), dev(np.array([3.5], np.float32)))
+    assert torch.isfinite(out).all()
+
+
 def test_sequence_parallel_rejects_what_it_cannot_split(env):
     torch, d = env["torch"], env["d"]
     m = d.FluxModel(SMALL_FLUX)  # 2 heads
