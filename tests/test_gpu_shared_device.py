@@ -176,3 +176,46 @@ def test_flux_forward_reproduces_its_idle_result_while_another_process_uses_the_
         co.stop()
     print(f"{reps} forward passes next to the co-runner, {bad} differ from the idle result")
     assert bad == 0
+
+
+def test_vae_and_text_encoders_reproduce_their_idle_results_while_another_process_uses_the_gpu(env):
+    """The callers either side of the denoise loop: VAE decode / encode (implicit-GEMM convs, GroupNorm, the mid-block attention)
+    and the T5 / CLIP encoders."""
+    torch, d = env["torch"], env["d"]
+    from tests.test_gpu_text import SMALL_CLIP, SMALL_T5
+    from tests.util import SMALL_VAE
+    vae = d.AutoEncoderKl(SMALL_VAE)
+    vae.load_state_dict(d.synth.vae_state_dict_numpy(SMALL_VAE, seed=0, encoder=True))
+    t5 = d.T5EncoderModel(SMALL_T5)
+    t5.load_state_dict(d.synth.text_state_dict_numpy(d.synth.t5_tensor_shapes(SMALL_T5), seed=0))
+    clip = d.ClipTextTransformer(SMALL_CLIP)
+    clip.load_state_dict(d.synth.text_state_dict_numpy(d.synth.clip_tensor_shapes(SMALL_CLIP), seed=0))
+    rng = np.random.default_rng(0)
+    z = dev(rng.standard_normal((1, 16, 32, 32)).astype(np.float32))
+    image = dev(rng.standard_normal((1, 3, 128, 128)).astype(np.float32) * 0.5)
+    t5_ids = torch.from_numpy(rng.integers(0, SMALL_T5["vocab_size"], (2, 300)).astype(np.int32)).cuda()
+    clip_ids = torch.from_numpy(rng.integers(0, SMALL_CLIP["vocab_size"], (2, 77)).astype(np.int32)).cuda()
+    cases = [("vae decode 256x256", lambda: vae.decode(z)),
+             ("vae encode 128x128 (moments)", lambda: vae.encode(image, return_moments=True)),
+             ("t5 2x300", lambda: t5.forward(t5_ids, dtype=torch.float32)),
+             ("clip 2x77", lambda: clip.forward(clip_ids))]
+
+    def flat(x):
+        return torch.cat([t.reshape(-1).float() for t in x]) if isinstance(x, (tuple, list)) else x.reshape(-1).float()
+    idle = [flat(run()).clone() for _, run in cases]
+    torch.cuda.synchronize()
+    co = CoRunner(30)
+    try:
+        time.sleep(0.5)
+        bad, reps = {}, 0
+        t0 = time.time()
+        while time.time() - t0 < 8:
+            for (name, run), ref in zip(cases, idle):
+                if not torch.equal(flat(run()), ref):
+                    bad[name] = bad.get(name, 0) + 1
+            reps += 1
+        assert co.alive()
+    finally:
+        co.stop()
+    print(f"{reps} repetitions of {[n for n, _ in cases]} next to the co-runner; differing: {bad or 'none'}")
+    assert not bad
