@@ -557,11 +557,23 @@ static bool g_att_w4 = [] {
 void set_attention_w4(bool on) { g_att_w4 = on; }
 
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
-                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8) {
+                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8, float* lse, int k_hstride) {  // (k_hstride: see the lse branch)
   if (Lq <= 0 || Lk <= 0) return fail(FMI_ERR_INVALID, "attention: empty sequence");
   if (Lkpad % ATT_KV != 0 || Lkpad < Lk) return fail(FMI_ERR_INVALID, "attention: Lkpad must be a multiple of 64 and >= Lk");
   dim3 grid(cdiv(Lq, ATT_QBLK) * B * H);
   const float sl = scale * 1.4426950408889634f;
+  if (lse) {  // key-split launch (k_hstride = number of key ranges): only the one-wave kernel writes the log-sum-exp
+    const int nsplit = k_hstride;
+    if (qk_fp8 || B != 1 || out.head_major || out.rows0 != 0 || nsplit < 2 || cdiv(Lk, ATT_KV) < 2 * nsplit)
+      return fail(FMI_ERR_UNSUPPORTED, "attention: a key-split launch needs bf16 operands, B = 1, one token-major output and >= 2 KV tiles per part");
+    const dim3 gs(grid.x * nsplit);
+    if (rescale_thr_x16 == 0)
+      hipLaunchKernelGGL((attention_w4_kernel<0, true>), gs, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, Lk, lse, nsplit);
+    else
+      hipLaunchKernelGGL((attention_w4_kernel<96, true>), gs, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, Lk, lse, nsplit);
+    FMI_LAUNCH_CHECK();
+    return FMI_OK;
+  }
   if (qk_fp8) {
     if (rescale_thr_x16 == 0)
       hipLaunchKernelGGL((attention_pp_kernel<0, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
@@ -569,9 +581,9 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
       hipLaunchKernelGGL((attention_pp_kernel<96, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
   } else if (g_att_w4 && Lk > ATT_KV) {  // (a single KV tile has no steady state to pipeline: the 8-wave kernel serves it)
     if (rescale_thr_x16 == 0)
-      hipLaunchKernelGGL((attention_w4_kernel<0>), grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+      hipLaunchKernelGGL((attention_w4_kernel<0>), grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, 0, nullptr, 1);
     else
-      hipLaunchKernelGGL((attention_w4_kernel<96>), grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+      hipLaunchKernelGGL((attention_w4_kernel<96>), grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, 0, nullptr, 1);
   } else if (g_att_pingpong) {
     if (rescale_thr_x16 == 0)
       hipLaunchKernelGGL((attention_pp_kernel<0, false>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);

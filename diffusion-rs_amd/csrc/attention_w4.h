@@ -44,21 +44,37 @@ struct Aw4Phase {  // one phase of the MFMA stream: PV of query block b_pv and /
   __device__ int n() const { return (has_pv && has_qk) ? 32 : (has_pv || has_qk) ? 16 : 0; }
 };
 
-template <int THR_X16>
+// LSE = true (key-split launches of the sequence-parallel latency mode, flux_model.hip: attention_sp): K may be a range of a
+// longer per-head sequence (`k_hstride` rows per head) and the kernel also writes the row's log2-sum-exp, m + log2(l), to
+// lse[bh * Lq + q], from which sp_merge_splits combines the partial outputs.  The default instantiation is unchanged.
+template <int THR_X16, bool LSE = false>
 __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16_t* __restrict Q, const bf16_t* __restrict K, const bf16_t* __restrict Vt,
-                                                                      AttnOut out, int H, int Lq, int Lk, int Lkpad, float scale_log2e) {
+                                                                      AttnOut out, int H, int Lq, int Lk, int Lkpad, float scale_log2e, int k_hstride = 0,
+                                                                      float* __restrict lse = nullptr, int nsplit = 1) {
   constexpr int TILE = 16384, VT_RING = 4 * TILE, PF = 8;  // PF fragment buffers, PF - 1 reads in flight; PF divides the phase lengths, so buffer i % PF lines up across phases
   __shared__ __attribute__((aligned(16))) char smem[8 * TILE];  // K ring [4][64 x 128] at 0, V^T ring [4][128 x 64] at 64 KiB
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqb = (Lq + ATT_QBLK - 1) / ATT_QBLK;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  if (LSE) {
+    // key-split launch: the grid is nsplit x (heads x query blocks); part `sp` walks the KV tiles [nt * sp / nsplit, nt * (sp + 1) / nsplit)
+    // of the full sequence (Lk = its length on entry, k_hstride = rows per head of K), writes its normalised output to slice sp of
+    // out.p1 (slices of Lq * out.ld1 elements) and its log-sum-exp to slice sp of lse
+    const int per = gridDim.x / nsplit, sp = lid / per, nt = (Lk + ATT_KV - 1) / ATT_KV;
+    lid -= sp * per;
+    const int t0 = (int)((int64_t)nt * sp / nsplit), t1 = (int)((int64_t)nt * (sp + 1) / nsplit);
+    const int k0 = t0 * ATT_KV, k1 = min(Lk, t1 * ATT_KV);
+    K += (int64_t)k0 * HD, Vt += k0, Lk = k1 - k0;
+    out.p1 += (int64_t)sp * Lq * out.ld1;
+    lse += (int64_t)sp * (per / nqb) * Lq;
+  }
   const int bh = lid / nqb;
   const int b_ = bh / H, h = bh % H;
   const int q0 = (lid % nqb) * ATT_QBLK + wave * 64;
   const int hl = lane >> 5, l31 = lane & 31;
-  const bf16_t* Kb = K + (int64_t)bh * Lk * HD;
+  const bf16_t* Kb = K + (int64_t)bh * (LSE ? k_hstride : Lk) * HD;
   const bf16_t* Vb = Vt + (int64_t)bh * HD * Lkpad;
   const int ntiles = (Lk + ATT_KV - 1) / ATT_KV;  // >= 2 (the launcher sends single-tile problems to the 8-wave kernel)
 
@@ -477,6 +493,7 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[b]), __float_as_uint(l_run[b]), false, false);
     const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
     const int r = 32 * b + l31;
+    if (LSE && hl == 0 && q0 + r < Lq) lse[(int64_t)bh * Lq + q0 + r] = m_run[b] + __log2f(__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll

@@ -200,7 +200,7 @@ struct AttnOut {
 };
 // qk_fp8 != 0: q and k are e4m3 bytes (B,H,L,128), QK^T runs on the fp8 MFMA (scale must already hold 1 / (q scale * k scale))
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
-                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8 = 0);
+                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8 = 0, float* lse = nullptr, int nsplit = 0);
 void set_attention_pingpong(bool on);  // 8-wave kernels: ping-pong (default) or the single-barrier one
 void set_attention_w4(bool on);        // bf16 operands: one-wave-per-SIMD kernel (default) or the 8-wave ones
 // flash attention, d = 128.  q,k: (BH, L, 128) bf16; vt: (BH, 128, Lpad) bf16 with the kv axis
@@ -219,6 +219,9 @@ int launch_sp_pack_qkv(const bf16_t* q, const bf16_t* k, const bf16_t* vt, void*
 int launch_sp_unpack_qkv(const void* recv, bf16_t* qf, bf16_t* kf, bf16_t* vtf, int H, int Tl, int Sl, int N, hipStream_t s);
 int launch_sp_pack_o(const bf16_t* o, void* send, int H, int Tl, int Sl, int N, hipStream_t s);
 int launch_sp_unpack_o(const void* recv, const AttnOut& out, int H, int Ll, int N, hipStream_t s);
+// key-split attention: parts (S, L, W) bf16 normalised partial outputs, lse (S, W/128 heads, L) f32 (log2 domain) ->
+// out (L, W) = sum_s 2^(lse_s - max) parts_s / sum_s 2^(lse_s - max)
+int launch_sp_merge_splits(const bf16_t* parts, const float* lse, int S, bf16_t* out, int heads, int L, hipStream_t s);
 // q/k RMSNorm (eps 1e-6, weight (128)) + RoPE, token-major in (row stride ld, head h at col h*128)
 // -> head-major (B,H,Ltot,128) at row offset row_off.  pe: (B or 1, Ltot, 64, 2) f32 {cos,sin}
 int launch_qk_norm_rope(const bf16_t* q, const bf16_t* k, int ld, int64_t in_bstride, const bf16_t* wq,

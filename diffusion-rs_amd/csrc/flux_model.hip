@@ -137,11 +137,13 @@ struct fmi_flux {
   int sp_rank = 0, sp_world = 1;
   fmi_all_to_all_fn sp_a2a = nullptr;
   void* sp_user = nullptr;
-  char* sp_base = nullptr;  // [send | recv | Qf | Kf | Vtf | O]
+  char* sp_base = nullptr;  // [send | recv | Qf | Kf | Vtf | O (+ SP_SPLITS partial outputs) | lse]
   size_t sp_bytes = 0;
   int sp_Tl = 0, sp_Sl = 0;
   void *sp_send = nullptr, *sp_recv = nullptr;
   bf16_t *sp_Qf = nullptr, *sp_Kf = nullptr, *sp_Vtf = nullptr, *sp_O = nullptr;
+  float* sp_lse = nullptr;
+  static constexpr int SP_SPLITS = 4;  // key ranges of the latency mode's attention (attention_sp)
   // latency mode for small launches (fmi_flux_set_split_k): see gemm_split_k
   bool split_k = false;
   float* splitk_scratch = nullptr;
@@ -633,7 +635,8 @@ int ensure_sp_buffers(fmi_flux* m, int Tl, int Sl) {
   const int N = m->sp_world, Hr = m->H / N, Ll = Tl + Sl, L = N * Ll, Lp = (L + 63) / 64 * 64;
   const size_t xb = align_up((size_t)N * std::max(sp_qkv_bytes_per_peer(Hr, Ll), sp_o_bytes_per_peer(Hr, Ll)), 256);
   const size_t qb = align_up((size_t)Hr * L * 128 * 2, 256), vb = align_up((size_t)Hr * 128 * Lp * 2, 256);
-  const size_t total = 2 * xb + 2 * qb + vb + qb;
+  const size_t lb = align_up((size_t)fmi_flux::SP_SPLITS * Hr * L * sizeof(float), 256);
+  const size_t total = 2 * xb + 2 * qb + vb + (1 + fmi_flux::SP_SPLITS) * qb + lb;
   FMI_HIP_TRY(hipDeviceSynchronize());
   if (m->sp_base) FMI_HIP_TRY(hipFree(m->sp_base));
   m->sp_base = nullptr;
@@ -644,7 +647,8 @@ int ensure_sp_buffers(fmi_flux* m, int Tl, int Sl) {
   m->sp_Qf = reinterpret_cast<bf16_t*>(c), c += qb;
   m->sp_Kf = reinterpret_cast<bf16_t*>(c), c += qb;
   m->sp_Vtf = reinterpret_cast<bf16_t*>(c), c += vb;
-  m->sp_O = reinterpret_cast<bf16_t*>(c);
+  m->sp_O = reinterpret_cast<bf16_t*>(c), c += (1 + fmi_flux::SP_SPLITS) * qb;
+  m->sp_lse = reinterpret_cast<float*>(c);
   m->sp_bytes = total, m->sp_Tl = Tl, m->sp_Sl = Sl;
   return FMI_OK;
 }
@@ -659,7 +663,23 @@ int attention_sp(fmi_flux* m, const AttnOut& out, int Tl, int Sl, float scale, h
   AttnOut o{};
   o.p0 = nullptr, o.rows0 = 0;
   o.p1 = m->sp_O, o.ld1 = Hr * 128, o.bstride1 = (int64_t)L * Hr * 128;
-  FMI_TRY(launch_attention_ex(m->sp_Qf, m->sp_Kf, m->sp_Vtf, o, 1, Hr, L, L, Lp, scale, m->attn_thr, s, 0));
+  const int ntiles = (L + 63) / 64, wgs = Hr * ((L + 255) / 256);
+  int S = fmi_flux::SP_SPLITS;
+  while (S > 1 && (wgs * S > 256 || ntiles < 4 * S)) S >>= 1;
+  if (m->split_k && S > 1) {
+    // Latency mode: H/N heads are too few workgroups for 256 CUs (3 heads x 18 query blocks = 54, each walking all 72 KV tiles).
+    // The keys are cut into S <= SP_SPLITS ranges of whole tiles (as many as keep the grid within one wave of workgroups): ONE launch of the one-wave kernel with SP_SPLITS x the workgroups,
+    // each walking its range and also writing the rows' log-sum-exp, and sp_merge_splits combines the normalised partial outputs
+    // with the weights 2^(lse_s - max) in a fixed order.  Equal to the unsplit attention to bf16 rounding of the partial
+    // outputs, not bit for bit (the mode is opt-in: fmi_flux_set_split_k).
+    const size_t part = (size_t)L * Hr * 128;
+    AttnOut parts = o;
+    parts.p1 = m->sp_O + part;  // slices 1 .. S of the buffer; slice 0 receives the merged result
+    FMI_TRY(launch_attention_ex(m->sp_Qf, m->sp_Kf, m->sp_Vtf, parts, 1, Hr, L, L, Lp, scale, m->attn_thr, s, 0, m->sp_lse, S));
+    FMI_TRY(launch_sp_merge_splits(m->sp_O + part, m->sp_lse, S, m->sp_O, Hr, L, s));
+  } else {
+    FMI_TRY(launch_attention_ex(m->sp_Qf, m->sp_Kf, m->sp_Vtf, o, 1, Hr, L, L, Lp, scale, m->attn_thr, s, 0));
+  }
   FMI_TRY(launch_sp_pack_o(m->sp_O, m->sp_send, H, Tl, Sl, N, s));
   if (m->sp_a2a(m->sp_user, m->sp_send, m->sp_recv, sp_o_bytes_per_peer(Hr, Ll), s) != 0)
     return fail(FMI_ERR_STATE, "flux: the sequence-parallel all-to-all callback failed (attention output exchange)");

@@ -98,6 +98,33 @@ __global__ void sp_unpack_o_kernel(const chunk_t* __restrict__ recv, AttnOut out
   }
 }
 
+// one thread per (token, head, 8-wide d chunk)
+__global__ void sp_merge_splits_kernel(const chunk_t* __restrict__ parts, const float* __restrict__ lse, int S, chunk_t* __restrict__ out, int heads, int L) {
+  const int rc = heads * 16;
+  const int64_t total = (int64_t)L * rc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % rc), t = (int)(i / rc), h = c >> 4;
+    float ls[8], mx = -3.0e38f;
+    for (int s = 0; s < S; ++s) ls[s] = lse[((int64_t)s * heads + h) * L + t], mx = fmaxf(mx, ls[s]);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, den = 0.f;
+    for (int s = 0; s < S; ++s) {  // fixed order
+      const float w = exp2f(ls[s] - mx);
+      const chunk_t v = parts[(int64_t)s * total + i];
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] += w * __uint_as_float(u[e] << 16);
+        acc[2 * e + 1] += w * __uint_as_float(u[e] & 0xffff0000u);
+      }
+      den += w;
+    }
+    const float inv = 1.0f / den;
+    chunk_t o;
+    o.x = pack_bf16x2(acc[0] * inv, acc[1] * inv), o.y = pack_bf16x2(acc[2] * inv, acc[3] * inv);
+    o.z = pack_bf16x2(acc[4] * inv, acc[5] * inv), o.w = pack_bf16x2(acc[6] * inv, acc[7] * inv);
+    out[i] = o;
+  }
+}
+
 int grid_for(int64_t total) { return (int)std::min<int64_t>((total + 255) / 256, 4096); }
 
 }  // namespace
@@ -133,6 +160,13 @@ int launch_sp_pack_o(const bf16_t* o, void* send, int H, int Tl, int Sl, int N, 
 int launch_sp_unpack_o(const void* recv, const AttnOut& out, int H, int Ll, int N, hipStream_t s) {
   const int Hr = H / N;
   sp_unpack_o_kernel<<<grid_for((int64_t)N * Ll * Hr * 16), 256, 0, s>>>(reinterpret_cast<const chunk_t*>(recv), out, Hr, Ll, N);
+  FMI_HIP_TRY(hipGetLastError());
+  return FMI_OK;
+}
+
+int launch_sp_merge_splits(const bf16_t* parts, const float* lse, int S, bf16_t* out, int heads, int L, hipStream_t s) {
+  if (S < 2 || S > 8) return fail(FMI_ERR_INVALID, "sp_merge_splits: 2..8 parts");
+  sp_merge_splits_kernel<<<grid_for((int64_t)L * heads * 16), 256, 0, s>>>(reinterpret_cast<const chunk_t*>(parts), lse, S, reinterpret_cast<chunk_t*>(out), heads, L);
   FMI_HIP_TRY(hipGetLastError());
   return FMI_OK;
 }

@@ -154,7 +154,8 @@ class FluxModel:
 
     def set_split_k(self, on: bool):
         """Latency mode for launches of few rows (sequence-parallel shards): residual projections with fewer than 128 tiles are
-        split along K and reduced in a fixed order — deterministic, equal to the unsplit result to rounding (not bit for bit)."""
+        split along K and reduced in a fixed order, and the sequence-parallel attention of few heads walks key ranges in parallel
+        (log-sum-exp merge) — deterministic, equal to the unsplit result to rounding (not bit for bit)."""
         L.check(self.lib.fmi_flux_set_split_k(self.h, int(bool(on))))
 
     def set_sequence_parallel(self, rank: int, world_size: int, all_to_all=None):

@@ -146,9 +146,10 @@ int fmi_flux_set_quant_dense_cache(fmi_flux*, int mode);
  * null callback) switches it off.  Results are bit-identical to the single-device forward. */
 /* Latency mode for small launches (default off).  A residual projection (attention output projection, MLP down projection,
  * single-block linear2) launched on so few rows that it has fewer than 128 tiles of 256 x 256 — the shards of sequence
- * parallelism — is split along K into up to 8 parts of one grouped launch and reduced in a fixed order by a second kernel.
- * Deterministic, but the f32 sum is associated differently from the unsplit launch: results agree to rounding, not bit
- * for bit (which is why it is opt-in).  Measured per-rank effect: profiles/r02_sp_rank_time.txt. */
+ * parallelism — is split along K into up to 8 parts of one grouped launch and reduced in a fixed order by a second kernel;
+ * and the sequence-parallel attention of few heads walks up to 4 key ranges in parallel workgroups whose partial outputs
+ * are merged by their log-sum-exp.  Deterministic, but sums are associated differently from the unsplit launches: results
+ * agree to rounding, not bit for bit (which is why it is opt-in).  Per-rank effect: profiles/r02_sp_rank_time.txt. */
 int fmi_flux_set_split_k(fmi_flux*, int enable);
 typedef int (*fmi_all_to_all_fn)(void* user, const void* send, void* recv, size_t bytes_per_peer, void* stream);
 int fmi_flux_set_sequence_parallel(fmi_flux*, int rank, int world_size, fmi_all_to_all_fn a2a, void* user);

@@ -183,6 +183,20 @@ def test_split_k_latency_mode_is_deterministic_and_equal_to_rounding(env):
     assert rel_l2(host(got), host(plain)) <= 1e-3
     m.set_split_k(False)
     assert torch.equal(m.forward(*args), plain)
+    # long enough for the attention's key split (>= 16 KV tiles, few heads per rank): 4 ranges of whole tiles + log-sum-exp merge
+    img, ids, txt, txt_ids, y = flux_inputs(cfg, 1, (32, 34), 64, seed=6)  # L = 1152: 18 tiles
+    args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
+    plain = m.forward(*args)
+    ref_o = om.forward(img, ids, txt, txt_ids, t, y, g)
+    outs = []
+    for rep in range(2):
+        outs.append(torch.cat(ranks.run(lambda r, mm: mm.forward(dev(_shard(img, r, 2)), dev(_shard(ids, r, 2)), dev(_shard(txt, r, 2), torch.bfloat16),
+                                                                 dev(_shard(txt_ids, r, 2)), dev(t), dev(y), dev(g))), 1))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    e_plain, e_or, e_plain_or = rel_l2(host(outs[0]), host(plain)), rel_l2(host(outs[0]), ref_o), rel_l2(host(plain), ref_o)
+    print(f"2 ranks, split-K + key-split attention, L = 1152: vs unsplit single device {e_plain:.2e}; vs oracle {e_or:.2e} (unsplit vs oracle {e_plain_or:.2e})")
+    assert e_plain <= 3e-3 and e_or <= 1e-2
 
 
 def test_rank_time_measurement_aid_runs_and_counts_the_exchanges(env):
