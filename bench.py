@@ -3,6 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    ... bench.py --gpus N --sequence-parallel [--split-k]      (opt-in: ONE image on all N ranks, strong scaling)
 
 A "step" is ONE IMAGE: the full hot path over one batch of synthetic input — 50 denoise
 steps (Flux::forward + Euler update), unpack, VAE decode, u8 post-process — with inputs
@@ -91,6 +92,9 @@ def main():
     ap.add_argument("--quant", choices=["none", "nf4", "fp8"], default="none",
                     help="nf4: block linears stored bitsandbytes-nf4, fused dequant-GEMM (config C3); fp8: block linears on the e4m3 MFMA path (config C5)")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU per image step (C5: 2)")
+    ap.add_argument("--sequence-parallel", action="store_true",
+                    help="N > 1: all ranks denoise ONE image together (token shards, two all-to-alls per block; strong scaling) instead of one image each")
+    ap.add_argument("--split-k", action="store_true", help="with --sequence-parallel: the opt-in latency mode (fmi_flux_set_split_k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the nf4 (C3) and fp8 (C5 shape) legs appended to the N = 1 line")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -164,6 +168,14 @@ def main():
     synth.fill_vae_random_device(vae, seed=1, device=dev)
     torch.cuda.synchronize()
     load_s = time.time() - t_load
+    # single-image sequence parallelism: the ranks work on the SAME image, each on 1/N of its tokens
+    spg = None
+    if args.sequence_parallel and world > 1:
+        if args.quant == "fp8" or args.batch != 1:
+            raise SystemExit("--sequence-parallel runs one bf16 / nf4 image at a time (batch 1)")
+        spg = fdist.SequenceParallel(dev)
+        spg.attach(flux)
+        flux.set_split_k(args.split_k)
 
     # ---------------- synthetic inputs resident in HBM (per rank: its own prompt / seed)
     NS, T = args.denoise_steps, args.txt_tokens
@@ -177,7 +189,7 @@ def main():
             self.h, self.w = (H + 15) // 16 * 2, (W + 15) // 16 * 2
             self.S = (self.h // 2) * (self.w // 2)
             gi = torch.Generator(device=dev)
-            gi.manual_seed(1234 + rank)
+            gi.manual_seed(1234 + (0 if spg is not None else rank))  # sequence parallel: every rank holds the same prompt
             self.txt = torch.randn((B, T, 4096), generator=gi, device=dev, dtype=torch.float32).to(torch.bfloat16)
             self.y = torch.randn((B, 768), generator=gi, device=dev, dtype=torch.float32)
             self.guidance = torch.full((B,), 3.5, dtype=torch.float32, device=dev)
@@ -185,6 +197,13 @@ def main():
             self.timesteps = sched.get_timesteps(NS, sched.calculate_shift(self.S))
 
         def one_image(self, model, i):
+            if spg is not None and model is flux:  # same latents everywhere; each rank denoises its token shard, all get the result
+                lat = d.randn_latents(self.B, 16, self.h, self.w, seed=1234, first_sample=i * self.B, device=dev)
+                img, img_ids = d.pack_latents(lat)
+                img = spg.gather(model.denoise(spg.shard(img), spg.shard(img_ids), spg.shard(self.txt), spg.shard(self.txt_ids), self.y, self.guidance,
+                                               self.timesteps))
+                z = d.unpack_latents(img, 16, self.h, self.w, vae.scale_factor(), vae.shift_factor())
+                return d.postprocess_u8(vae.decode(z))
             lat = d.randn_latents(self.B, 16, self.h, self.w, seed=1234, first_sample=(rank + world * i) * self.B, device=dev)
             img, img_ids = d.pack_latents(lat)
             img = model.denoise(img, img_ids, self.txt, self.txt_ids, self.y, self.guidance, self.timesteps)
@@ -259,7 +278,7 @@ def main():
 
     # gather the decoded images to rank 0 (outside the timed region; 3 MB/sample over xGMI)
     gather_ms = None
-    if world > 1:
+    if world > 1 and spg is None:
         torch.cuda.synchronize()
         tg = time.perf_counter()
         gathered = fdist.gather_to_rank0(u8, world * B)
@@ -279,7 +298,7 @@ def main():
              "nf4": "gemm_w4q_kernel (fused nf4 dequant-GEMM on the packed weights: the 152 block-linear launches of a step; dense-equivalent FLOPs)",
              "fp8": "gemm_pp_kernel<fp8> (e4m3 MFMA GEMM, all block linears)"}
     PEAK_NOTE = "2500 = dense bf16 MFMA peak at 2.4 GHz; a register-only MFMA loop (tools/mfma_peak.hip) sustains 2020-2160 on this part (power cap, ~1.95 GHz)"
-    if rank == 0 and not args.no_profile_pass:
+    if rank == 0 and not args.no_profile_pass and spg is None:  # (the profiled pass is a single-device pass)
         traffic = tnote = None
         if args.quant == "none":
             try:  # HBM-side bytes per launch from the separate rocprofv3 --pmc passes of this round (gpurun refuses counters beside traces)
@@ -430,16 +449,18 @@ def main():
 
     if rank == 0:
         ms_per_image = elapsed / args.steps * 1e3
-        total_images = args.steps * world * B
+        total_images = args.steps * B * (1 if spg is not None else world)
         out = {
             "metric": "images/sec, FLUX.1-dev 1024x1024 50-step" if (H, W, NS) == (1024, 1024, 50) else f"images/sec, FLUX.1-dev {W}x{H} {NS}-step",
             "value": total_images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"none": "bf16", "nf4": "bf16 MFMA on nf4 weights (fused dequant-GEMM, packed weights only)",
+            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "strong" if spg is not None else "weak", "vs_baseline": None, "dtype": {"none": "bf16", "nf4": "bf16 MFMA on nf4 weights (fused dequant-GEMM, packed weights only)",
                                                                                                                  "fp8": "fp8 e4m3 block linears (per-channel weight / per-token activation scales, f32 accumulate), bf16 attention, f32 residual stream"}[args.quant],
             "data": "synthetic (random-init FLUX.1-dev + FLUX VAE weights, N(0,1) embeddings, Philox latents)",
             "config": {"workload": f"FLUX.1-dev {'fp8' if args.quant == 'fp8' else 'bf16'} {W}x{H} {NS}-step, batch={B} per GPU, S={S} img + T={T} txt tokens, step = one image "
                                    "(50x Flux::forward + Euler, unpack, VAE decode, u8)",
-                       "global_batch": world * B, "parallelism": f"batch-sharded x{world}" if world > 1 else "single GPU"},
+                       "global_batch": B if spg is not None else world * B,
+                       "parallelism": (f"sequence-parallel x{world} (one image on all ranks{', split-K latency mode' if args.split_k else ''})" if spg is not None
+                                       else f"batch-sharded x{world}" if world > 1 else "single GPU")},
             "ms_per_denoise_step": round((ms_per_image - extra.get("vae_decode_ms", 0.0)) / NS, 2),
             "ms_per_image": round(ms_per_image, 1),
             "output_ok": finite, "load_s": round(load_s, 1), "weights_generated_s": round(gen_s, 1),
@@ -450,7 +471,11 @@ def main():
             out["broadcast_s"] = round(bcast["seconds"], 2)
             out["broadcast_gib"] = round(bcast["bytes"] / 2**30, 2)
             out["broadcast_messages"] = bcast["messages"]
-            out["gather_ms"] = round(gather_ms, 2)
+            if gather_ms is not None:
+                out["gather_ms"] = round(gather_ms, 2)
+            if spg is not None:
+                out["exchanges"] = spg.exchanges
+                out["exchange_gb_sent_rank0"] = round(spg.bytes_sent / 1e9, 2)
         if secondary is not None:
             out["secondary"] = secondary
         out.update(extra)
