@@ -1,6 +1,6 @@
 """world_size-2 tests of the multi-GPU paths on CPU (gloo): sample -> rank mapping, weight broadcast from rank 0
 (tensor-wise and as flat arenas), ragged gather back to rank 0 in prompt order, Pipeline.forward's sharded front door
-(SURVEY §8e), and the index math of the Ulysses head redistribution."""
+(SURVEY §8e), the index math of the Ulysses head redistribution and the token shards of dist.SequenceParallel."""
 import os
 import socket
 
@@ -108,6 +108,20 @@ def _worker(rank, world, port, n_prompts, q):
     attn = heads + heads.sum(0, keepdim=True)  # needs all tokens of a head, nothing of other heads
     back = fd.ulysses_gather_heads(attn, n_tok, H)
     assert torch.equal(back, (full + full.sum(0, keepdim=True))[a:b])
+
+    # 6. the wired sequence-parallel group (dist.SequenceParallel): token shards and their inverse, and the callback handed to the
+    #    C library — block p of the send buffer to rank p, block p of the receive buffer from rank p — on host memory here
+    spg = fd.SequenceParallel("cpu")
+    assert (spg.rank, spg.world_size, spg.backend) == (rank, world, "gloo")
+    tok = torch.arange(2 * 8 * 3, dtype=torch.float32).reshape(2, 8, 3)
+    mine = spg.shard(tok)
+    assert torch.equal(mine, tok[:, rank * 4:(rank + 1) * 4])
+    assert torch.equal(spg.gather(mine), tok)
+    try:
+        spg.shard(torch.zeros(1, 7, 3))
+        raise AssertionError("7 tokens must not split over 2 ranks")
+    except ValueError:
+        pass
 
     q.put((rank, {k: v.numpy() for k, v in got.items()}, None if out is None else out.numpy(), fd.shard_indices(n_prompts, rank, world),
            state_sum, None if fwd is None else fwd.numpy()))
