@@ -682,6 +682,23 @@ extern "C" int fmi_vae_decode(fmi_vae* v, const float* z, int B, int h, int w, f
 }
 
 // ---------------------------------------------------------------- op-level entry points
+// AttnBlock::forward (vae.rs:95-111) of the decoder's mid block as one op: x (B,H,W,C) bf16 NHWC with C = block_out_channels.last
+// -> out of the same shape (GroupNorm, q/k/v, softmax, to_out, + x).  Exists so the block can be checked alone at production size.
+extern "C" int fmi_vae_mid_attention(fmi_vae* v, const void* x_bf16_nhwc, int B, int H, int W, void* out_bf16_nhwc, void* stream) {
+  if (v) FMI_TRY(use_device_ordinal(v->device));
+  if (!v || !x_bf16_nhwc || !out_bf16_nhwc) return fail(FMI_ERR_INVALID, "vae_mid_attention: null argument");
+  if (B <= 0 || H <= 0 || W <= 0) return fail(FMI_ERR_INVALID, "vae_mid_attention: empty input");
+  if (!v->cfg.mid_block_add_attention) return fail(FMI_ERR_UNSUPPORTED, "vae_mid_attention: the config has no mid-block attention");
+  FMI_TRY(check_part(v, true));
+  hipStream_t s = (hipStream_t)stream;
+  FMI_TRY(vae_workspace(v, B, H, W));
+  const size_t bytes = (size_t)B * H * W * v->aq.cout * sizeof(bf16_t);
+  FMI_HIP_TRY(hipMemcpyAsync(v->bx, x_bf16_nhwc, bytes, hipMemcpyDeviceToDevice, s));
+  FMI_TRY(run_attn(v, AttnW{v->attn_gn, v->aq, v->ak, v->av, v->ao}, B, H, W, s));
+  FMI_HIP_TRY(hipMemcpyAsync(out_bf16_nhwc, v->bx, bytes, hipMemcpyDeviceToDevice, s));
+  return FMI_OK;
+}
+
 extern "C" int fmi_groupnorm_nhwc(const void* x_bf16, const float* weight, const float* bias, void* out_bf16, int B, int HW, int C, int groups, float eps,
                                   int fuse_silu, void* stream) {
   if (!x_bf16 || !weight || !bias || !out_bf16) return fail(FMI_ERR_INVALID, "groupnorm_nhwc: null pointer");

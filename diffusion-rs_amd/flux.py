@@ -311,6 +311,14 @@ class AutoEncoderKl:
     def shift_factor(self) -> float:
         return self.lib.fmi_vae_shift_factor(self.h)
 
+    def mid_attention(self, x_nhwc):
+        """AttnBlock::forward (vae.rs:95-111) of the decoder's mid block alone: (B,H,W,C) bf16 NHWC -> same shape."""
+        x = x_nhwc.contiguous()
+        assert x.dtype == torch.bfloat16 and x.dim() == 4
+        out = torch.empty_like(x)
+        L.check(self.lib.fmi_vae_mid_attention(self.h, _ptr(x), x.shape[0], x.shape[1], x.shape[2], _ptr(out), _stream()))
+        return out
+
     def decode(self, z):
         """== VAEModel::decode (vaes/mod.rs:15-28): z (B,16,h,w) f32 -> (B,3,8h,8w) f32."""
         z = z.to(torch.float32).contiguous()

@@ -285,6 +285,10 @@ int fmi_vae_decode(fmi_vae*, const float* z, int B, int h, int w, float* image_o
  * moments_out (B,2*latent_channels,H/8,W/8) f32 optional.  decode needs only the `decoder.*`
  * tensors, encode only `encoder.*` (+ `quant_conv.*`). */
 int fmi_vae_encode(fmi_vae*, const float* image, int B, int H, int W, const float* noise, float* z_out, float* moments_out, void* stream);
+/* AttnBlock::forward (vaes/vae.rs:95-111) of the decoder's mid block as one op: x and out (B,H,W,C) bf16 NHWC device
+ * buffers, C = block_out_channels.last, H*W a multiple of 64; out = x + to_out(sdpa(q,k,v)(group_norm(x))).  Needs the
+ * `decoder.*` tensors.  Used by the parity tests to check the block alone at production size. */
+int fmi_vae_mid_attention(fmi_vae*, const void* x_bf16_nhwc, int B, int H, int W, void* out_bf16_nhwc, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Text encoders — they run once per image in front of the denoise loop and

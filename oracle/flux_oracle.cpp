@@ -624,17 +624,66 @@ struct orc_flux {
   int axes[3], theta;
   int D, M;
   std::map<std::string, std::vector<float>> t;
+  // Full-size checks (C1 at D = 3072, 19 + 38 blocks: 12e9 weights) hold the checkpoint as bf16 bits (24 GB instead of 48) and
+  // widen a tensor to f32 on first use; evict_pages() drops the widened copies at the end of each block.  bf16 -> f32 is exact,
+  // so the arithmetic is the same as with orc_flux_set_tensor on the same values.
+  std::map<std::string, std::vector<uint16_t>> t16;
+  struct Page {
+    float* p;
+    size_t n;
+  };
+  mutable std::map<std::string, Page> page;
+  mutable std::multimap<size_t, float*> pool;  // widened buffers are recycled by size: no zero-fill, no fresh page faults per block
+  void evict_pages() const {
+    for (auto& kv : page) pool.emplace(kv.second.n, kv.second.p);
+    page.clear();
+  }
+  ~orc_flux() {
+    evict_pages();
+    for (auto& kv : pool) free(kv.second);
+  }
   const float* get(const std::string& name, int64_t numel) const {
+    const float* f = nullptr;
+    size_t fn = 0;
     auto it = t.find(name);
-    if (it == t.end()) {
+    if (it != t.end()) {
+      f = it->second.data(), fn = it->second.size();
+    } else {
+      auto ip = page.find(name);
+      if (ip != page.end()) {
+        f = ip->second.p, fn = ip->second.n;
+      } else {
+        auto i16 = t16.find(name);
+        if (i16 != t16.end()) {
+          const std::vector<uint16_t>& h = i16->second;
+          const int64_t n = (int64_t)h.size();
+          float* w;
+          auto pp = pool.find((size_t)n);
+          if (pp != pool.end()) {
+            w = pp->second;
+            pool.erase(pp);
+          } else {
+            w = (float*)malloc(sizeof(float) * (size_t)std::max<int64_t>(n, 1));
+          }
+#pragma omp parallel for
+          for (int64_t i = 0; i < n; ++i) {
+            uint32_t u = (uint32_t)h[i] << 16;
+            memcpy(&w[i], &u, 4);
+          }
+          page[name] = Page{w, (size_t)n};
+          f = w, fn = (size_t)n;
+        }
+      }
+    }
+    if (!f) {
       fprintf(stderr, "[oracle] missing tensor %s\n", name.c_str());
       return nullptr;
     }
-    if ((int64_t)it->second.size() != numel) {
-      fprintf(stderr, "[oracle] tensor %s has %zu elements, expected %lld\n", name.c_str(), it->second.size(), (long long)numel);
+    if ((int64_t)fn != numel) {
+      fprintf(stderr, "[oracle] tensor %s has %zu elements, expected %lld\n", name.c_str(), fn, (long long)numel);
       return nullptr;
     }
-    return it->second.data();
+    return f;
   }
 };
 
@@ -660,6 +709,16 @@ extern "C" void orc_flux_set_fp8(orc_flux* m, int on) { m->fp8 = on; }
 extern "C" void orc_flux_set_fp8_attention(orc_flux* m, int on) { m->fp8_attn = on; }
 extern "C" int orc_flux_set_tensor(orc_flux* m, const char* name, const float* data, int64_t numel) {
   m->t[name] = std::vector<float>(data, data + numel);
+  m->t16.erase(name);
+  m->fp8_w.clear();
+  return 0;
+}
+// The same tensor handed over as bf16 bits (see orc_flux::t16).  Not available together with the fp8 recipe, which caches
+// per-weight codes keyed by the f32 pointer.
+extern "C" int orc_flux_set_tensor_bf16(orc_flux* m, const char* name, const uint16_t* data, int64_t numel) {
+  m->t16[name] = std::vector<uint16_t>(data, data + numel);
+  m->t.erase(name);
+  m->evict_pages();
   m->fp8_w.clear();
   return 0;
 }
@@ -875,12 +934,14 @@ extern "C" int orc_flux_double_block(orc_flux* m, int idx, float* img, float* tx
   const int D = m->D, L = S + T, d = D / m->heads;
   for (int b = 0; b < B; ++b)
     if (double_block_one(m, idx, img + (int64_t)b * S * D, txt + (int64_t)b * T * D, vec + (int64_t)b * D, pe + (int64_t)b * L * (d / 2) * 4, S, T)) return -1;
+  m->evict_pages();
   return 0;
 }
 extern "C" int orc_flux_single_block(orc_flux* m, int idx, float* x, const float* vec, const float* pe, int B, int L) {
   const int D = m->D, d = D / m->heads;
   for (int b = 0; b < B; ++b)
     if (single_block_one(m, idx, x + (int64_t)b * L * D, vec + (int64_t)b * D, pe + (int64_t)b * L * (d / 2) * 4, L)) return -1;
+  m->evict_pages();
   return 0;
 }
 
@@ -945,6 +1006,7 @@ extern "C" int orc_flux_forward(orc_flux* m, const float* img, const float* img_
     ln_mod(xs.data() + ((size_t)b * L + T) * D, shift, scale, S, D, xn.data());
     lin_fwd(proj, xn.data(), S, pred + (size_t)b * S * C);
   }
+  m->evict_pages();
   return 0;
 }
 
@@ -1057,6 +1119,15 @@ bool v_attn(const orc_vae* v, const std::string& p, F& x, int B, int C, int H, i
   return true;
 }
 }  // namespace
+
+// AttnBlock::forward (vae.rs:95-111) of the decoder's mid block alone, in place on x (B,C,H,W), C = block_out_channels.last.
+extern "C" int orc_vae_mid_attention(orc_vae* v, float* x, int B, int H, int W) {
+  const int C = v->boc[v->boc.size() - 1];
+  F xv(x, x + (size_t)B * C * H * W);
+  if (!v_attn(v, "decoder.mid_block.attentions.0", xv, B, C, H, W)) return -1;
+  memcpy(x, xv.data(), xv.size() * sizeof(float));
+  return 0;
+}
 
 // Decoder::forward, vae.rs:436-456 (+ AutoEncoderKl::decode, autoencoder_kl.rs:112-119).
 extern "C" int orc_vae_decode(orc_vae* v, const float* z, int B, int h, int w, float* out) {

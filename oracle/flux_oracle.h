@@ -57,6 +57,7 @@ typedef struct orc_flux orc_flux;
 orc_flux* orc_flux_create(int in_channels, int pooled_projection_dim, int joint_attention_dim, int num_attention_heads, int num_layers, int num_single_layers, int guidance_embeds, const int* axes_dim, int theta);
 void orc_flux_destroy(orc_flux*);
 int orc_flux_set_tensor(orc_flux*, const char* name, const float* data, int64_t numel);
+int orc_flux_set_tensor_bf16(orc_flux*, const char* name, const uint16_t* data, int64_t numel);  /* same values as bf16 bits, widened per block */
 /* fp8 recipe (BASELINE configs[4]; no reference counterpart — parity unpinned, see flux_oracle.cpp) */
 void orc_flux_set_fp8(orc_flux*, int on);
 void orc_flux_set_fp8_attention(orc_flux*, int on); /* with set_fp8: q, k of the attention on e4m3 with static scales */
@@ -76,6 +77,7 @@ orc_vae* orc_vae_create(const int* block_out_channels, int n_blocks, int layers_
 void orc_vae_destroy(orc_vae*);
 int orc_vae_set_tensor(orc_vae*, const char* name, const float* data, int64_t numel);
 int orc_vae_decode(orc_vae*, const float* z, int B, int h, int w, float* out);
+int orc_vae_mid_attention(orc_vae*, float* x_nchw_inout, int B, int H, int W);  /* AttnBlock of the decoder mid block alone */
 /* image (B,in_channels,H,W) -> moments (B,2*latent,H/8,W/8) [optional] and z = mean + exp(0.5 logvar) * noise (noise NULL: z = mean) */
 int orc_vae_encode(orc_vae*, const float* img, int B, int in_channels, int H, int W, int use_quant_conv, const float* noise, float* moments_out, float* z_out);
 

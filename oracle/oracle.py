@@ -388,6 +388,11 @@ class Flux:
         for k, v in tensors.items():
             self.set_tensor(k, v)
 
+    def set_tensor_bf16(self, name, bits):
+        """The tensor as bf16 bits (uint16): held at 2 bytes per weight and widened per block (full-size checks)."""
+        a = np.ascontiguousarray(bits, np.uint16)
+        lib().orc_flux_set_tensor_bf16(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), C.c_int64(a.size))
+
     def set_fp8(self, on=True, attention=False):
         """Block linears on the fp8 recipe (flux_oracle.cpp: parity unpinned, no reference counterpart); attention=True
         also puts q and k of the attention on e4m3 with the static scales (what the library does when both streams of a
@@ -495,6 +500,14 @@ class Vae:
         if rc:
             raise RuntimeError("oracle vae_decode failed rc=%d" % rc)
         return out
+
+    def mid_attention(self, x):
+        """AttnBlock::forward (vae.rs:95-111) of the decoder's mid block alone: x (B,C,H,W) f32 -> same shape."""
+        x = np.array(x, dtype=np.float32, order="C", copy=True)
+        B, _, H, W = x.shape
+        if lib().orc_vae_mid_attention(self.h, x.ctypes.data_as(f32p), B, H, W):
+            raise RuntimeError("oracle vae_mid_attention failed")
+        return x
 
 
 T5_ACT = {"relu": 0, "gated-gelu": 1, "gated-silu": 2}

@@ -1,0 +1,151 @@
+"""Parity at the PRODUCTION shapes of the two models (VERDICT r2 "missing" 2 and 3).
+
+* `Decoder::forward` (vaes/vae.rs:436-456) at the real FLUX AutoencoderKL config — block_out_channels
+  [128, 256, 512, 512], 3 resnets per up level, 32 groups, mid attention — for a 64x64 latent (512^2 image: the Cin = 512
+  convolutions with K = 4608, a 4096-token AttnBlock) and for the 128x128 latent of BASELINE configs[1] (1024^2: the 16384-token
+  AttnBlock, GroupNorm over 4 M elements per group), against the f32 CPU oracle.  Tolerances as in tests/test_gpu_vae.py:
+  rel-L2 <= 2e-2 on the decoded image, |delta u8| <= 2 on >= 99 % of the pixels.
+* one Cin = 512 3x3 convolution (ResnetBlock2D conv1/conv2 of the 512-channel levels, vae.rs:157-172) and one AttnBlock
+  (vae.rs:95-111) on 4096 tokens, as single ops.
+* BASELINE configs[0] (C1: FLUX.1-schnell 256x256, 4 steps, batch 1 — the reference's own CPU-runnable case) IN FULL:
+  D = 3072, 19 double + 38 single blocks (`Flux::forward`, model.rs:790-833), S = T = 256, the 4-step Euler loop
+  (sampling.rs:25-48), every block with its own weights.  12e9 weights: generated on the GPU, handed to the oracle as bf16 bits
+  (24 GB on the host, widened per block — exact).  Tolerance: latents after the loop rel-L2 <= 3e-2.
+"""
+import time
+
+import numpy as np
+import pytest
+
+from tests.util import bf16_round, dev, host, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _u8_agreement(d, orc, got, ref):
+    import torch
+    u_ref = orc.postprocess_u8(ref)
+    u_got = d.postprocess_u8(torch.from_numpy(got).cuda()).cpu().numpy()
+    diff = np.abs(u_ref.astype(np.int32) - u_got.astype(np.int32))
+    return int(diff.max()), float((diff <= 2).mean())
+
+
+@pytest.mark.parametrize("h", [64, 128])
+def test_vae_decode_flux_config_matches_oracle(h):
+    import diffusion_rs_amd as d
+    from oracle import oracle as orc
+    sd = d.synth.vae_state_dict_numpy(d.VAE_FLUX, seed=4)
+    gv = d.AutoEncoderKl(d.VAE_FLUX)
+    gv.load_state_dict(sd)
+    ov = orc.Vae(d.VAE_FLUX)
+    ov.load(sd)
+    z = np.random.default_rng(h).standard_normal((1, 16, h, h)).astype(np.float32)
+    t0 = time.time()
+    ref = ov.decode(z)
+    t_or = time.time() - t0
+    got = host(gv.decode(dev(z)))
+    assert got.shape == ref.shape == (1, 3, 8 * h, 8 * h)
+    assert np.isfinite(got).all()
+    err = rel_l2(got, ref)
+    mx, frac = _u8_agreement(d, orc, got, ref)
+    print(f"VAE decode at the FLUX config, latent {h}x{h} -> {8 * h}^2: rel-L2 {err:.3e}, u8 max |d| {mx}, frac<=2 {frac:.5f} "
+          f"(oracle {t_or:.1f} s, ref range [{ref.min():.2f},{ref.max():.2f}])")
+    assert err <= 2e-2
+    assert frac >= 0.99
+    gv.close()
+
+
+def test_conv2d_cin512_matches_oracle():
+    """3x3, Cin = Cout = 512 on a 64x64 map: the K = 4608 implicit GEMM of the 512-channel ResnetBlocks (vae.rs:157-172), plain
+    and with the 2x nearest upsample folded into the gather (Upsample2D, vae.rs:225-236)."""
+    import ctypes as C
+    import torch
+    from diffusion_rs_amd import _lib as L
+    from oracle import oracle as orc
+    lib = L.load()
+    L.check(lib.fmi_init(0))
+    rng = np.random.default_rng(7)
+    Cin, Cout = 512, 512
+    w = bf16_round((rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32))
+    b = bf16_round((0.1 * rng.standard_normal(Cout)).astype(np.float32))
+    wd = dev(w.transpose(0, 2, 3, 1).copy(), torch.bfloat16)
+    bd = dev(b, torch.bfloat16)
+    for (H, W, up) in ((64, 64, 0), (32, 32, 1)):
+        x = bf16_round(rng.standard_normal((1, Cin, H, W)).astype(np.float32))
+        xin = orc.upsample_nearest2d(x, 2 * H, 2 * W) if up else x
+        ref = orc.conv2d(xin, w, b, pad=1)
+        xd = dev(x.transpose(0, 2, 3, 1).copy(), torch.bfloat16)
+        out = torch.full((1, ref.shape[2], ref.shape[3], Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(lib.fmi_conv2d_nhwc(p(xd), p(wd), p(bd), None, p(out), 1, H, W, Cin, Cout, 3, up, None))
+        torch.cuda.synchronize()
+        got = host(out).transpose(0, 3, 1, 2)
+        err = rel_l2(got, ref)
+        print(f"conv2d 3x3 512->512, input {H}x{W}, upsample {up}: rel-L2 {err:.3e}")
+        assert np.isfinite(got).all() and err <= 4e-3
+
+
+def test_vae_attn_block_4096_tokens_matches_oracle():
+    """AttnBlock::forward (vae.rs:95-111) alone on a 64x64 map of 512 channels: GroupNorm(32), q/k/v 1x1, the 4096x4096 softmax,
+    to_out + residual (fmi_vae_mid_attention vs the oracle's v_attn), with the weights of the FLUX-config decoder."""
+    import torch
+    import diffusion_rs_amd as d
+    from oracle import oracle as orc
+    sd = d.synth.vae_state_dict_numpy(d.VAE_FLUX, seed=5)
+    gv = d.AutoEncoderKl(d.VAE_FLUX)
+    gv.load_state_dict(sd)
+    ov = orc.Vae(d.VAE_FLUX)
+    ov.load(sd)
+    x = bf16_round((1.5 * np.random.default_rng(8).standard_normal((1, 512, 64, 64))).astype(np.float32))
+    ref = ov.mid_attention(x)
+    got = host(gv.mid_attention(dev(x.transpose(0, 2, 3, 1).copy(), torch.bfloat16))).transpose(0, 3, 1, 2)
+    err, delta = rel_l2(got, ref), rel_l2(got - x, ref - x)
+    print(f"VAE AttnBlock, 4096 tokens x 512 channels: rel-L2 {err:.3e}; of the attention branch alone (out - x) {delta:.3e}")
+    assert np.isfinite(got).all() and err <= 4e-3 and delta <= 2e-2
+    gv.close()
+
+
+def test_c1_schnell_full_width_full_depth_matches_oracle():
+    import torch
+    import diffusion_rs_amd as d
+    from oracle import oracle as orc
+    cfg = dict(d.FLUX_SCHNELL)
+    gm = d.FluxModel(cfg)
+    om = orc.Flux(cfg)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    n_w = 0
+    t0 = time.time()
+    for name, shape in d.synth.flux_tensor_shapes(cfg).items():
+        if "norm_q.weight" in name or "norm_k.weight" in name or "norm_added" in name:
+            t = (1.0 + 0.1 * torch.randn(shape, generator=g, device="cuda")).to(torch.bfloat16)
+        elif name.endswith(".bias"):
+            t = (0.02 * torch.randn(shape, generator=g, device="cuda")).to(torch.bfloat16)
+        else:
+            t = torch.randn(shape, generator=g, device="cuda", dtype=torch.bfloat16)
+            t.mul_(d.synth._std_for(name, 0.02, 0.01))
+        gm.set_tensor(name, t)
+        om.set_tensor_bf16(name, t.view(torch.int16).cpu().numpy().view(np.uint16))
+        n_w += t.numel()
+        del t
+    gm.assert_complete()
+    t_load = time.time() - t0
+    assert not gm.is_guidance()
+    B, T = 1, 256
+    rng = np.random.default_rng(78)
+    lat = rng.standard_normal((B, 16, 32, 32)).astype(np.float32)  # 256x256 image -> 32x32 latent -> S = 256
+    t5 = bf16_round(rng.standard_normal((B, T, cfg["joint_attention_dim"])).astype(np.float32))
+    clip = rng.standard_normal((B, cfg["pooled_projection_dim"])).astype(np.float32)
+    img, ids = orc.pack_latents(lat)
+    txt_ids = np.zeros((B, T, 3), np.float32)
+    ts = orc.get_timesteps(4, False, 0.0, 1.0)  # schnell: no dynamic shifting, shift = 1.0 (scheduler.rs:22-51)
+    got = host(gm.denoise(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(clip), None, ts))
+    gm.close()
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    ref = om.denoise(img, ids, t5, txt_ids, clip, None, ts)
+    t_or = time.time() - t0
+    err, moved = rel_l2(got, ref), rel_l2(ref, img)
+    print(f"C1 in full (FLUX.1-schnell, D=3072, 19+38 blocks, {n_w / 1e9:.2f}e9 weights, S=T=256, 4 steps): latents rel-L2 {err:.3e} "
+          f"(the loop moved them by {moved:.3f}; weights {t_load:.0f} s, oracle {t_or:.0f} s)")
+    assert np.isfinite(got).all() and err <= 3e-2
