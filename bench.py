@@ -80,6 +80,35 @@ def vae_flops(h8, w8):
     return f
 
 
+def self_launch_command(n_gpus, argv, port):
+    """The command `bench.py --gpus N` re-executes itself under when it was started plainly (no WORLD_SIZE in the environment):
+    one rank per GPU on this node, rendezvous on 127.0.0.1 — the same launch line the driver uses."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher: spawn the N ranks ourselves.  Fails loudly if the node has fewer
+    than N devices (unless FMI_BENCH_BACKEND=gloo, the debugging mode in which ranks share devices)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()
+    if os.environ.get("FMI_BENCH_BACKEND", "nccl") == "nccl" and n_dev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible on this node — one rank per GPU is required "
+                         "(FMI_BENCH_BACKEND=gloo lets ranks share a device for debugging)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = self_launch_command(args.gpus, argv, port)
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +129,7 @@ def main():
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--cpu-baseline-tokens", type=int, default=0, help="override L of the CPU sample (debug)")
     args = ap.parse_args()
+    maybe_self_launch(args, sys.argv[1:])
 
     import numpy as np
     import torch
@@ -108,14 +138,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}; they must agree (n_gpus in the JSON line is the number of ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # debugging aid for boxes with fewer GPUs than ranks: FMI_BENCH_BACKEND=gloo lets several ranks share device 0
     backend = os.environ.get("FMI_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible): one rank per GPU is required")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -158,8 +190,13 @@ def main():
     t_load = time.time()
     flux = d.FluxModel(d.FLUX_DEV, local_rank)
     vae = d.AutoEncoderKl(d.VAE_FLUX, local_rank)
-    if rank == 0:
-        fill_flux(flux, "nf4" if args.quant == "nf4" else "none")
+    gen_err = None
+    try:
+        if rank == 0:
+            fill_flux(flux, "nf4" if args.quant == "nf4" else "none")
+    except Exception as e:  # the other ranks must hear about it instead of waiting in the broadcast
+        gen_err = e
+    fdist.agree_or_raise(gen_err, "weight generation on rank 0")
     torch.cuda.synchronize()
     gen_s = time.time() - t_load
     bcast = fdist.broadcast_state(flux, dev) if world > 1 else None
@@ -270,10 +307,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     e_end = energy_uj() if rank == 0 else None
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in allt]
+        elapsed = max(float(t.item()) for t in allt)  # the job is as slow as its slowest rank
     finite = bool(torch.isfinite(u8.float()).all().item()) and int(u8.max()) > int(u8.min())
 
     # gather the decoded images to rank 0 (outside the timed region; 3 MB/sample over xGMI)
@@ -468,6 +508,8 @@ def main():
         }
         if world > 1:
             out["rccl_ranks"] = world
+            out["backend"] = backend
+            out["ms_per_step_per_rank"] = [round(x, 1) for x in per_rank_ms]
             out["broadcast_s"] = round(bcast["seconds"], 2)
             out["broadcast_gib"] = round(bcast["bytes"] / 2**30, 2)
             out["broadcast_messages"] = bcast["messages"]

@@ -102,6 +102,16 @@ def load():
     lib.fmi_flux_set_quant_dense_cache.argtypes = [C.c_void_p, C.c_int]
     lib.fmi_flux_set_split_k.argtypes = [C.c_void_p, C.c_int]
     lib.fmi_flux_set_sequence_parallel.argtypes = [C.c_void_p, C.c_int, C.c_int, ALL_TO_ALL_FN, C.c_void_p]
+    lib.fmi_comm_unique_id.argtypes = [C.c_void_p]
+    lib.fmi_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.fmi_comm_destroy.argtypes = [C.c_void_p]
+    lib.fmi_comm_destroy.restype = None
+    lib.fmi_comm_rank.argtypes = [C.c_void_p]
+    lib.fmi_comm_world_size.argtypes = [C.c_void_p]
+    lib.fmi_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.fmi_comm_all_to_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.fmi_comm_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    lib.fmi_comm_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     lib.fmi_flux_set_attention_rescale_threshold.argtypes = [C.c_void_p, C.c_int]
     lib.fmi_flux_forward.argtypes = [C.c_void_p, C.POINTER(FluxInputs), C.c_void_p, C.c_void_p]
     for enc in ("t5", "clip"):
@@ -170,6 +180,8 @@ EXPORTED = [
     "fmi_clip_missing_count", "fmi_clip_missing_name", "fmi_clip_size_in_bytes", "fmi_clip_forward", "fmi_pack_latents", "fmi_unpack_latents", "fmi_postprocess_u8",
     "fmi_randn", "fmi_philox_u32", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_linear_int8_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_set_attention_kernel", "fmi_layernorm_mod",
     "fmi_groupnorm_nhwc", "fmi_conv2d_nhwc",
+    "fmi_comm_unique_id", "fmi_comm_create", "fmi_comm_destroy", "fmi_comm_rank", "fmi_comm_world_size", "fmi_comm_stats", "fmi_comm_all_to_all",
+    "fmi_comm_broadcast", "fmi_comm_gather",
     "dequantize_blockwise_f32_int8", "dequantize_blockwise_f32_fp4", "dequantize_blockwise_f32_nf4", "dequantize_blockwise_f16_int8",
     "dequantize_blockwise_f16_fp4", "dequantize_blockwise_f16_nf4", "dequantize_blockwise_bf16_int8", "dequantize_blockwise_bf16_fp4",
     "dequantize_blockwise_bf16_nf4", "dequantize_8bit_kernel_f32", "dequantize_8bit_kernel_f16", "dequantize_8bit_kernel_bf16",

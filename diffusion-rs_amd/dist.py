@@ -48,45 +48,153 @@ def broadcast_tensors(shapes: Dict[str, tuple], make: Callable[[str, tuple], tor
 STATE_CHUNK = 1 << 30  # bytes per broadcast message of the weight arenas
 
 
-def broadcast_state(model, device, src: int = 0, chunk_bytes: int = STATE_CHUNK) -> dict:
-    """Replicate `model`'s weights from rank `src` to every rank: the layout blob first (state_export /
-    state_adopt), then every weight arena in messages of `chunk_bytes` through one reusable staging tensor
-    (arena -> staging on the source, broadcast, staging -> arena on the receivers; the extra device-to-device
-    copy runs at HBM speed and keeps the C-ABI free of torch types).  `model` needs state_export(), state_adopt(blob),
-    state_buffers() -> [(ptr, bytes)] and copy_state_chunk(index, offset, staging, nbytes, to_staging).
-    Returns {"bytes", "messages", "seconds"}."""
+class StateExportUnsupported(RuntimeError):
+    """The source rank's checkpoint cannot travel as flat arenas (LLM.int8 matrices): every rank loads it itself."""
+
+
+def agree_or_raise(error: Optional[BaseException], what: str = "load") -> None:
+    """Collective error check: every rank reports whether its `what` step failed; if any did, ALL ranks raise (instead of the
+    healthy ones blocking in the next collective until the RCCL timeout).  No-op without torch.distributed."""
+    rank, ws = world()
+    if ws == 1:
+        if error is not None:
+            raise error
+        return
+    msgs = [None] * ws
+    dist.all_gather_object(msgs, None if error is None else f"{type(error).__name__}: {error}")
+    bad = [(r, m) for r, m in enumerate(msgs) if m is not None]
+    if bad:
+        if error is not None:
+            raise error
+        raise RuntimeError(f"{what} failed on rank {bad[0][0]}: {bad[0][1]}")
+
+
+def broadcast_state(model, device, src: int = 0, chunk_bytes: int = STATE_CHUNK, comm: "Optional[RcclComm]" = None) -> dict:
+    """Replicate `model`'s weights from rank `src` to every rank: the layout blob first (state_export / state_adopt), then every
+    weight arena IN PLACE — the arenas are wrapped as torch views of their device pointers (no staging copy) and go out in
+    messages of `chunk_bytes`, enqueued back to back on the current stream with one synchronisation at the end.  With `comm`
+    (an RcclComm) the messages are fmi_comm_broadcast calls instead of torch.distributed ones.  `model` needs state_export(),
+    state_adopt(blob), state_buffers() -> [(ptr, bytes)] and state_views(device).  An export failure on `src` (StateExportUnsupported for LLM.int8
+    checkpoints, or any load error recorded by the caller) is announced to every rank before the first data collective, so
+    nobody blocks.  Returns {"bytes", "messages", "seconds"}."""
+    # (`model.state_views(device)` -> one flat uint8 tensor per arena aliasing its memory; FluxModel builds them from
+    # state_buffers() through __cuda_array_interface__)
     import time
     rank, ws = world()
     t0 = time.perf_counter()
     if ws == 1:
         return {"bytes": 0, "messages": 0, "seconds": 0.0}
-    blob = [model.state_export() if rank == src else None]
-    dist.broadcast_object_list(blob, src=src)
+    head = [None]
+    if rank == src:
+        try:
+            head = [("ok", model.state_export())]
+        except Exception as e:  # e.g. FMI_ERR_UNSUPPORTED: LLM.int8 matrices are not part of the flat state
+            head = [("unsupported", f"{type(e).__name__}: {e}")]
+    dist.broadcast_object_list(head, src=src)
+    kind, blob = head[0]
+    if kind != "ok":
+        raise StateExportUnsupported(blob)
     if rank != src:
-        model.state_adopt(blob[0])
-    sizes = [n for _, n in model.state_buffers()]
-    staging = torch.empty(min(chunk_bytes, max(sizes + [1])), dtype=torch.uint8, device=device)
+        model.state_adopt(blob)
     total = msgs = 0
-    for i, n in enumerate(sizes):
+    dev = torch.device(device)
+    views = model.state_views(dev)
+    for (ptr, n), view in zip(model.state_buffers(), views):
+        if not n:
+            continue
         off = 0
         while off < n:
             k = min(chunk_bytes, n - off)
-            if rank == src:
-                model.copy_state_chunk(i, off, staging, k, True)
-                _sync(device)
-            dist.broadcast(staging[:k], src=src)
-            if rank != src:
-                model.copy_state_chunk(i, off, staging, k, False)
-                _sync(device)
+            if comm is not None:
+                comm.broadcast(ptr + off, k, src)
+            else:
+                dist.broadcast(view[off:off + k], src=src)
             off += k
             total += k
             msgs += 1
+    _sync(device)
     return {"bytes": total, "messages": msgs, "seconds": time.perf_counter() - t0}
 
 
 def _sync(device):
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
+
+
+class RcclComm:
+    """fmi_comm (csrc/rccl_comm.hip): this process's RCCL communicator behind the C-ABI, created collectively — rank 0 draws the
+    128-byte id, torch.distributed (whatever its backend) carries it to the others, every rank calls fmi_comm_create on its
+    current device.  Operations are enqueued on the current torch stream unless a stream pointer is given."""
+
+    def __init__(self, device, group=None):
+        import ctypes as C
+        from . import _lib as L
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("RcclComm needs an initialised torch.distributed process group (it carries the communicator id)")
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
+        ident, err = [None], None
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            try:
+                L.check(self.lib.fmi_comm_unique_id(buf))
+                ident = [bytes(buf)]
+            except Exception as e:
+                err = e
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(ident, src=src, group=group)
+        h = C.c_void_p()
+        if ident[0] is None:
+            err = err or RuntimeError("rank 0 could not create an RCCL id")
+        else:
+            try:
+                with torch.cuda.device(self.device):
+                    L.check(self.lib.fmi_comm_create((C.c_uint8 * 128).from_buffer_copy(ident[0]), self.rank, self.world_size, C.byref(h)))
+            except Exception as e:
+                err = e
+        agree_or_raise(err, "RCCL communicator creation")
+        self.h = h
+
+    def _stream(self, stream=None):
+        import ctypes as C
+        return C.c_void_p(int(stream) if stream else torch.cuda.current_stream(self.device).cuda_stream)
+
+    def broadcast(self, ptr: int, nbytes: int, root: int = 0, stream=None):
+        import ctypes as C
+        from . import _lib as L
+        L.check(self.lib.fmi_comm_broadcast(self.h, C.c_void_p(ptr), nbytes, root, self._stream(stream)))
+
+    def gather(self, send: torch.Tensor, recv: Optional[torch.Tensor], root: int = 0, stream=None):
+        import ctypes as C
+        from . import _lib as L
+        n = send.numel() * send.element_size()
+        L.check(self.lib.fmi_comm_gather(self.h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()) if recv is not None else None, n, root,
+                                         self._stream(stream)))
+
+    def all_to_all(self, send: torch.Tensor, recv: torch.Tensor, stream=None):
+        import ctypes as C
+        from . import _lib as L
+        n = send.numel() * send.element_size()
+        assert n % self.world_size == 0 and recv.numel() * recv.element_size() == n
+        L.check(self.lib.fmi_comm_all_to_all(self.h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), n // self.world_size, self._stream(stream)))
+
+    def stats(self) -> Tuple[int, int]:
+        import ctypes as C
+        calls, sent = C.c_ulonglong(), C.c_ulonglong()
+        self.lib.fmi_comm_stats(self.h, C.byref(calls), C.byref(sent))
+        return calls.value, sent.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fmi_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def gather_to_rank0(local: torch.Tensor, n_total: int) -> Optional[torch.Tensor]:
@@ -210,8 +318,22 @@ class SequenceParallel:
         self.device = torch.device(device)
         self.backend = dist.get_backend(group)
         self._views = {}
-        self.exchanges = 0
-        self.bytes_sent = 0
+        self._exchanges = 0
+        self._bytes_sent = 0
+        # RCCL: the library's own communicator does the exchange from C (fmi_comm_all_to_all); FMI_SP_TORCH_A2A=1 keeps the
+        # round-2 path (a Python callback per exchange that calls torch.distributed.all_to_all_single) for A/B runs
+        import os
+        self.comm = None
+        if self.backend == "nccl" and os.environ.get("FMI_SP_TORCH_A2A", "0") != "1":
+            self.comm = RcclComm(self.device, group)
+
+    @property
+    def exchanges(self) -> int:
+        return self.comm.stats()[0] if self.comm is not None else self._exchanges
+
+    @property
+    def bytes_sent(self) -> int:
+        return self.comm.stats()[1] if self.comm is not None else self._bytes_sent
 
     def _view(self, ptr: int, nbytes: int) -> torch.Tensor:
         key = (ptr, nbytes)
@@ -232,11 +354,14 @@ class SequenceParallel:
                 hr = torch.empty_like(hs)
                 dist.all_to_all_single(hr, hs, group=self.group)
                 rt.copy_(hr)
-        self.exchanges += 1
-        self.bytes_sent += n - bytes_per_peer
+        self._exchanges += 1
+        self._bytes_sent += n - bytes_per_peer
 
     def attach(self, flux_model) -> None:
-        flux_model.set_sequence_parallel(self.rank, self.world_size, self.all_to_all)
+        if self.comm is not None:
+            flux_model.set_sequence_parallel_native(self.rank, self.world_size, self.comm)
+        else:
+            flux_model.set_sequence_parallel(self.rank, self.world_size, self.all_to_all)
 
     def detach(self, flux_model) -> None:
         flux_model.set_sequence_parallel(0, 1, None)

@@ -179,6 +179,14 @@ class FluxModel:
         self._sp_cb = L.ALL_TO_ALL_FN(_cb) if world_size > 1 else L.ALL_TO_ALL_FN()  # keep the thunk alive with the model
         L.check(self.lib.fmi_flux_set_sequence_parallel(self.h, int(rank), int(world_size), self._sp_cb, None))
 
+    def set_sequence_parallel_native(self, rank: int, world_size: int, comm):
+        """The same with the exchange done by the library's own RCCL communicator (dist.RcclComm / fmi_comm): the callback is the C
+        function fmi_comm_all_to_all itself, so an exchange is one ncclAllToAll enqueued from C on the launch stream — no Python
+        between two kernels of a block."""
+        fn = C.cast(self.lib.fmi_comm_all_to_all, L.ALL_TO_ALL_FN)
+        self._sp_cb, self._sp_comm = fn, comm  # keep both alive with the model
+        L.check(self.lib.fmi_flux_set_sequence_parallel(self.h, int(rank), int(world_size), fn, comm.h))
+
     # ---- the weights as flat device buffers (multi-GPU broadcast, dist.broadcast_state)
     def state_export(self) -> bytes:
         n = C.c_size_t()
@@ -200,12 +208,12 @@ class FluxModel:
             out.append((p.value or 0, n.value))
         return out
 
-    def copy_state_chunk(self, index: int, offset: int, staging: torch.Tensor, nbytes: int, to_staging: bool):
-        """Device-to-device copy between weight buffer `index` (+offset) and a torch staging tensor."""
-        ptr, total = self.state_buffers()[index]
-        assert ptr and offset + nbytes <= total and staging.numel() * staging.element_size() >= nbytes
-        a, b = C.c_void_p(ptr + offset), C.c_void_p(staging.data_ptr())
-        L.check(self.lib.fmi_memcpy(b, a, nbytes, _stream()) if to_staging else self.lib.fmi_memcpy(a, b, nbytes, _stream()))
+    def state_views(self, device=None):
+        """One flat uint8 torch tensor per weight arena, aliasing its device memory (None for an arena not in use): what
+        dist.broadcast_state hands to the collective — the weights travel in place, without a staging copy."""
+        from .dist import _DeviceBytes
+        dev = torch.device(device) if device is not None else self.device
+        return [torch.as_tensor(_DeviceBytes(p, n), device=dev) if n else None for p, n in self.state_buffers()]
 
     def _inputs(self, img, img_ids, txt, txt_ids, timesteps, y, guidance):
         B, S = int(img_ids.shape[0]), int(img_ids.shape[1])

@@ -144,28 +144,47 @@ class Pipeline:
         # multi-GPU: the DiT (98 % of the bytes) is materialised on rank 0 and broadcast as flat arenas; the VAE and
         # the text encoders are loaded / generated by every rank itself (same files, same seeds)
         self.load_stats = {}
-        if source.kind == "synthetic":
-            fcfg = source.flux_cfg or (F.FLUX_DEV if source.variant == "dev" else F.FLUX_SCHNELL)
-            vcfg = source.vae_cfg or F.VAE_FLUX
-            self.flux = F.FluxModel(fcfg, device)
-            if rank == 0:
-                synth.fill_flux_random_device(self.flux, seed=source.seed, device=self.device)
-            self.vae = F.AutoEncoderKl(vcfg, device)
-            synth.fill_vae_random_device(self.vae, seed=source.seed + 1, device=self.device)
-            if source.variant != "dev":
-                self.scheduler = F.SchedulerConfig(shift=1.0, use_dynamic_shifting=False)
-            if getattr(source, "text_encoders", False):
-                from . import text
-                self.t5 = text.T5EncoderModel(source.t5_cfg, device)
-                synth.fill_text_random_device(self.t5, seed=source.seed + 2, device=self.device)
-                self.clip = text.ClipTextTransformer(source.clip_cfg, device)
-                synth.fill_text_random_device(self.clip, seed=source.seed + 3, device=self.device)
-        elif source.kind == "model_id":
-            self._load_checkpoint(source.model_id, getattr(source, "transformer_model_id", None), load_dit=(rank == 0))
-        else:
-            self._load_checkpoint(source.file, None, load_dit=(rank == 0))
+        self._dit_loader = None  # loads the DiT into self.flux on this rank (used by rank 0, and by every rank when the flat state cannot travel)
+        err = None
+        try:
+            if source.kind == "synthetic":
+                fcfg = source.flux_cfg or (F.FLUX_DEV if source.variant == "dev" else F.FLUX_SCHNELL)
+                vcfg = source.vae_cfg or F.VAE_FLUX
+                self.flux = F.FluxModel(fcfg, device)
+                self._dit_loader = lambda: synth.fill_flux_random_device(self.flux, seed=source.seed, device=self.device)
+                if rank == 0:
+                    self._dit_loader()
+                self.vae = F.AutoEncoderKl(vcfg, device)
+                synth.fill_vae_random_device(self.vae, seed=source.seed + 1, device=self.device)
+                if source.variant != "dev":
+                    self.scheduler = F.SchedulerConfig(shift=1.0, use_dynamic_shifting=False)
+                if getattr(source, "text_encoders", False):
+                    from . import text
+                    self.t5 = text.T5EncoderModel(source.t5_cfg, device)
+                    synth.fill_text_random_device(self.t5, seed=source.seed + 2, device=self.device)
+                    self.clip = text.ClipTextTransformer(source.clip_cfg, device)
+                    synth.fill_text_random_device(self.clip, seed=source.seed + 3, device=self.device)
+            elif source.kind == "model_id":
+                self._load_checkpoint(source.model_id, getattr(source, "transformer_model_id", None), load_dit=(rank == 0))
+            else:
+                self._load_checkpoint(source.file, None, load_dit=(rank == 0))
+        except Exception as e:  # a rank that fails here must not leave the others blocked in the broadcast below
+            if world == 1:
+                raise
+            err = e
         if world > 1:
-            self.load_stats["broadcast"] = D.broadcast_state(self.flux, self.device)
+            D.agree_or_raise(err, "Pipeline load")
+            try:
+                self.load_stats["broadcast"] = D.broadcast_state(self.flux, self.device)
+            except D.StateExportUnsupported as e:  # raised on EVERY rank (e.g. LLM.int8 matrices are not part of the flat state)
+                err = None
+                try:
+                    if rank != 0:
+                        self._dit_loader()
+                except Exception as e2:
+                    err = e2
+                D.agree_or_raise(err, "per-rank DiT load")
+                self.load_stats["broadcast"] = {"bytes": 0, "messages": 0, "seconds": 0.0, "fallback": f"every rank loaded the DiT itself ({e})"}
         if dtype == ModelDType.F8E4M3:
             self.flux.quantize_fp8()
 
@@ -185,8 +204,9 @@ class Pipeline:
         fcfg = dict(F.FLUX_DEV, **{k: tc[k] for k in ("in_channels", "pooled_projection_dim", "joint_attention_dim", "num_attention_heads", "num_layers",
                                                      "num_single_layers", "guidance_embeds") if k in tc})
         self.flux = F.FluxModel(fcfg, self.device_index)
+        self._dit_loader = lambda: self.load_stats.update(loader.load_flux(self.flux, tl.tensors("transformer")))
         if load_dit:  # (multi-GPU: the other ranks receive the weight arenas, dist.broadcast_state)
-            self.load_stats.update(loader.load_flux(self.flux, tl.tensors("transformer")))
+            self._dit_loader()
         vc = fl.read_json("vae/config.json")
         vcfg = dict(F.VAE_FLUX, **{k: vc[k] for k in F.VAE_FLUX if k in vc})
         self.vae = F.AutoEncoderKl(vcfg, self.device_index)

@@ -34,7 +34,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
 #pragma GCC visibility push(default)
 
-#define FMI_ABI_VERSION 2
+#define FMI_ABI_VERSION 3
 
 typedef enum fmi_status {
   FMI_OK = 0,
@@ -153,6 +153,29 @@ int fmi_flux_set_quant_dense_cache(fmi_flux*, int mode);
 int fmi_flux_set_split_k(fmi_flux*, int enable);
 typedef int (*fmi_all_to_all_fn)(void* user, const void* send, void* recv, size_t bytes_per_peer, void* stream);
 int fmi_flux_set_sequence_parallel(fmi_flux*, int rank, int world_size, fmi_all_to_all_fn a2a, void* user);
+
+/* ------------------------------------------------------------------------------------
+ * RCCL communicator (rccl_comm.hip): the collectives of the multi-GPU path behind plain C — the counterpart a host
+ * without torch.distributed needs (the reference itself is single-device, pipelines/mod.rs:214-217).  librccl.so.1 is
+ * opened with dlopen on first use (FMI_ERR_UNSUPPORTED if absent).  One fmi_comm per process / GPU; rank 0 calls
+ * fmi_comm_unique_id and ships the FMI_COMM_ID_BYTES bytes to the other ranks by any host channel; fmi_comm_create is
+ * collective (ncclCommInitRank) and binds the comm to the CURRENT device.  All operations are enqueued on `stream`
+ * (hipStream_t) like a kernel launch; none synchronises the host.
+ *   fmi_comm_all_to_all  has the fmi_all_to_all_fn signature: pass (fmi_comm_all_to_all, comm) to
+ *                        fmi_flux_set_sequence_parallel and the two exchanges per block are one ncclAllToAll each.
+ *   fmi_comm_broadcast   in place, e.g. on every fmi_flux_state_buffer (weights from rank 0).
+ *   fmi_comm_gather      rank r's `bytes` land at recv + r*bytes on root (decoded u8 images to rank 0). */
+#define FMI_COMM_ID_BYTES 128
+typedef struct fmi_comm fmi_comm;
+int fmi_comm_unique_id(void* id_out /* FMI_COMM_ID_BYTES */);
+int fmi_comm_create(const void* id, int rank, int world_size, fmi_comm** out);
+void fmi_comm_destroy(fmi_comm*);
+int fmi_comm_rank(const fmi_comm*);
+int fmi_comm_world_size(const fmi_comm*);
+int fmi_comm_stats(const fmi_comm*, unsigned long long* calls, unsigned long long* bytes_sent);
+int fmi_comm_all_to_all(void* comm, const void* send, void* recv, size_t bytes_per_peer, void* stream);
+int fmi_comm_broadcast(fmi_comm*, void* buf, size_t bytes, int root, void* stream);
+int fmi_comm_gather(fmi_comm*, const void* send, void* recv, size_t bytes, int root, void* stream);
 /* Process-wide: rows from which 4-bit GEMMs use the one-wave-per-SIMD fused kernel (default 256). */
 int fmi_set_bnb4_onewave_min_rows(int rows);
 /* Test hook of the attention kernel's deferred-rescale branch: 0 = rescale on every key tile, else the

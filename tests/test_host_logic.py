@@ -27,7 +27,7 @@ def test_library_exports_every_header_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert set(L.EXPORTED) == declared
-    assert lib.fmi_abi_version() == 2
+    assert lib.fmi_abi_version() == 3
 
 
 def test_no_cpu_fallback():
@@ -140,3 +140,34 @@ def test_bnb_quantise_dequantise_consistency():
         assert np.abs(dq - w).max() <= 0.2 * np.abs(w).max()
         # bf16 / f16 outputs are the f32 outputs rounded once
         np.testing.assert_array_equal(orc.dequantize_blockwise(None, packed, absmax, 64, w.size, qt, "bf16"), orc.round_bf16(dq))
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` (N > 1) without a launcher re-executes itself under torch.distributed.run with one rank per
+    GPU and a 127.0.0.1 rendezvous; under a launcher (WORLD_SIZE set) or with N = 1 it does nothing."""
+    import argparse
+    import os
+    import sys
+    import bench
+    cmd = bench.self_launch_command(4, ["--gpus", "4", "--steps", "3"], 29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    assert cmd[-5] == os.path.abspath(bench.__file__) and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    bench.maybe_self_launch(argparse.Namespace(gpus=1), [])  # N = 1: returns
+    old = os.environ.get("WORLD_SIZE")
+    os.environ["WORLD_SIZE"] = "4"
+    try:
+        bench.maybe_self_launch(argparse.Namespace(gpus=4), [])  # already under a launcher: returns
+    finally:
+        if old is None:
+            del os.environ["WORLD_SIZE"]
+        else:
+            os.environ["WORLD_SIZE"] = old
+    # no launcher and too few GPUs: refuses loudly instead of silently measuring one device (here: 0 GPUs visible)
+    import pytest
+    import torch
+    if torch.cuda.device_count() < 4 and "WORLD_SIZE" not in os.environ:
+        with pytest.raises(SystemExit) as e:
+            bench.maybe_self_launch(argparse.Namespace(gpus=4), ["--gpus", "4"])
+        assert "GPU(s) visible" in str(e.value)
