@@ -25,6 +25,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace fmi {
@@ -547,13 +549,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
 #include "attention_w4.h"
 namespace fmi {
 
-static bool g_att_pingpong = true;
+static std::atomic<bool> g_att_pingpong{true};  // process-wide test hooks, like the GEMM switches (gemm_bf16.hip)
 void set_attention_pingpong(bool on) { g_att_pingpong = on; }
 // bf16 operands: the one-wave-per-SIMD kernel (attention_w4.h); FMI_ATT_W4=0 / set_attention_w4(false) -> the 8-wave ping-pong kernel
-static bool g_att_w4 = [] {
+static std::atomic<bool> g_att_w4{[] {
   const char* e = getenv("FMI_ATT_W4");
   return e ? atoi(e) != 0 : true;
-}();
+}()};
 void set_attention_w4(bool on) { g_att_w4 = on; }
 
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,

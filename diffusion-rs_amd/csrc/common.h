@@ -181,10 +181,11 @@ struct GemmProblem {
   const float* w_scale;
 };
 int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream);
-void set_gemm_w4(bool on);        // dense N>128 launches without the fused relayout: the 4-wave 128x128-per-wave kernel
-void set_gemm_pingpong(bool on);
-void set_gemm_w4q_min_rows(int rows);
-void set_gemm_w4_qkv_min_n(int n);  // fused-relayout launches at least this wide run on the 4-wave kernel  // 4-bit weights: M from which the one-wave-per-SIMD fused dequant-GEMM runs (default 256)  // dense N>128 launches: ping-pong kernel (default) or the double-buffered one
+// Process-wide kernel-selection hooks (tests, ablations; the alternatives are bit-identical):
+void set_gemm_w4(bool on);             // residual-update launches (N > 128, no fused relayout) on the 4-wave 128x128-per-wave kernel (default off)
+void set_gemm_pingpong(bool on);       // dense N > 128 launches: the ping-pong kernel (default) or the double-buffered one
+void set_gemm_w4q_min_rows(int rows);  // 4-bit weights: M from which the one-wave-per-SIMD fused dequant-GEMM runs (default 256)
+void set_gemm_w4_qkv_min_n(int n);     // dense fused-relayout launches at least this wide run on the 4-wave kernel (default: never)
 
 // attention output routing: query rows [0,rows0) -> p0, the rest -> p1 (token-major, head h at
 // column h*128); or head-major (B,H,Lq,128) in p1.

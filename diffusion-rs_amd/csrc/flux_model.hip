@@ -139,7 +139,7 @@ struct fmi_flux {
   void* sp_user = nullptr;
   char* sp_base = nullptr;  // [send | recv | Qf | Kf | Vtf | O (+ SP_SPLITS partial outputs) | lse]
   size_t sp_bytes = 0;
-  int sp_Tl = 0, sp_Sl = 0;
+  int sp_Tl = 0, sp_Sl = 0, sp_Nw = 0;  // the (txt, img, world) shard shape the exchange buffers were laid out for
   void *sp_send = nullptr, *sp_recv = nullptr;
   bf16_t *sp_Qf = nullptr, *sp_Kf = nullptr, *sp_Vtf = nullptr, *sp_O = nullptr;
   float* sp_lse = nullptr;
@@ -521,16 +521,22 @@ int densify(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s)
   for (int i = 0; i < n && i < 2; ++i)
     if (dn[i] && p[i].q_type && m->quant_mode == 0)
       scratch = scratch || p[i].M > (p[i].q_type == 3 ? INT8_FUSED_MAX_ROWS : Q4_FUSED_MAX_ROWS);
+  // A matrix of 2^31 or more weights (the fused modulation matrix of FLUX.1: 344 D x D = 3.2e9) never goes through the scratch —
+  // the stand-alone dequant launchers count elements in 32 bits and the scratch is sized for the block matrices — it stays on
+  // the fused dequant-GEMM kernels at any row count (8 prompts x 50 steps = 400 rows of the modulation precompute).
+  for (int i = 0; i < n && i < 2; ++i)
+    if (dn[i] && p[i].q_type && (size_t)p[i].N * p[i].K >= (1ull << 31)) scratch = false;
   for (int i = 0; i < n && i < 2; ++i) {
     Dense* d = dn[i];
     if (!d || !p[i].q_type) continue;
     if (!m->dense_cache && !scratch) continue;  // fused paths (launch_gemm picks the kernel)
     const size_t elems = (size_t)p[i].N * p[i].K;
-    if (elems >= (1ull << 31)) return fail(FMI_ERR_UNSUPPORTED, "densify: weight too large");
     if (m->dense_cache) {
       FMI_TRY(ensure_arena(m, d->ar));
       if (!m->dense_ready.count(d)) {
-        FMI_TRY(dequant_rows(*d, 0, d->N, d->q_type, d->q_blocksize, s));
+        // expanded once, in row chunks below 2^31 elements (chunk starts stay multiples of the quantisation block: K % 64 == 0)
+        const int chunk = std::max(64, (int)std::min<int64_t>(d->N, (((1ll << 31) - 1) / d->K) / 64 * 64));
+        for (int r0 = 0; r0 < d->N; r0 += chunk) FMI_TRY(dequant_rows(*d, r0, std::min(chunk, d->N - r0), d->q_type, d->q_blocksize, s));
         m->dense_ready.insert(d);
       }
       p[i].W = d->w;
@@ -631,7 +637,7 @@ int gemm1(fmi_flux* m, GemmProblem& p, Dense& d, hipStream_t s) {
 // Sequence-parallel joint attention: the local (H, Ll) q|k|v go out, (H/N heads, all L tokens) come in, attention runs on
 // this rank's heads, and the output rows travel back to their owners.  `out` = where the local rows of the result go.
 int ensure_sp_buffers(fmi_flux* m, int Tl, int Sl) {
-  if (m->sp_base && m->sp_Tl == Tl && m->sp_Sl == Sl) return FMI_OK;
+  if (m->sp_base && m->sp_Tl == Tl && m->sp_Sl == Sl && m->sp_Nw == m->sp_world) return FMI_OK;  // sizes and offsets depend on all three
   const int N = m->sp_world, Hr = m->H / N, Ll = Tl + Sl, L = N * Ll, Lp = (L + 63) / 64 * 64;
   const size_t xb = align_up((size_t)N * std::max(sp_qkv_bytes_per_peer(Hr, Ll), sp_o_bytes_per_peer(Hr, Ll)), 256);
   const size_t qb = align_up((size_t)Hr * L * 128 * 2, 256), vb = align_up((size_t)Hr * 128 * Lp * 2, 256);
@@ -649,7 +655,7 @@ int ensure_sp_buffers(fmi_flux* m, int Tl, int Sl) {
   m->sp_Vtf = reinterpret_cast<bf16_t*>(c), c += vb;
   m->sp_O = reinterpret_cast<bf16_t*>(c), c += (1 + fmi_flux::SP_SPLITS) * qb;
   m->sp_lse = reinterpret_cast<float*>(c);
-  m->sp_bytes = total, m->sp_Tl = Tl, m->sp_Sl = Sl;
+  m->sp_bytes = total, m->sp_Tl = Tl, m->sp_Sl = Sl, m->sp_Nw = m->sp_world;
   return FMI_OK;
 }
 int attention_sp(fmi_flux* m, const AttnOut& out, int Tl, int Sl, float scale, hipStream_t s) {

@@ -32,6 +32,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace fmi {
@@ -1256,18 +1258,21 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
 #include "gemm_w4q.h"
 namespace fmi {
 
-static bool g_pingpong = true;
+// Kernel-selection switches: PROCESS-WIDE test / ablation hooks (documented as such in include/flux_mi355x.h), shared by every
+// handle and thread.  They select between kernels that produce identical bits, so a concurrent change can move time, not results;
+// they are atomics so that a setter racing a launch is at least well-defined.
+static std::atomic<bool> g_pingpong{true};
 // Default OFF since both kernels moved to v_mfma_f32_16x16x32_bf16 (round 2): with twice the MFMA instructions per K tile the
 // one-wave-per-SIMD stream no longer beats two waves per SIMD (tools/gemm_bench, f32 residual epilogue: 4608x3072x15360 1280 vs
 // 1385 TF, 4096x3072x12288 1259 vs 1353 TF; it was +5-8 % with 32x32x16).  Bit-identical to the ping-pong kernel;
 // FMI_GEMM_W4=1 in the environment (or set_gemm_w4(true)) sends the launches `w4_pays` selects below (the residual-update
 // GEMMs: proj, mlp2, linear2) to it.
-static bool g_w4 = [] {
+static std::atomic<bool> g_w4{[] {
   const char* e = getenv("FMI_GEMM_W4");
   return e ? atoi(e) != 0 : false;
-}();
-static int g_w4q_min_rows = 256;
-static int g_w4_qkv_min_n = 1 << 30;  // never for dense weights (measured: slower, see launch_gemm); the packed 4-bit kernel always fuses
+}()};
+static std::atomic<int> g_w4q_min_rows{256};
+static std::atomic<int> g_w4_qkv_min_n{1 << 30};  // never for dense weights (measured: slower, see launch_gemm); the packed 4-bit kernel always fuses
 void set_gemm_w4_qkv_min_n(int n) { g_w4_qkv_min_n = n; }
 void set_gemm_w4q_min_rows(int rows) { g_w4q_min_rows = rows; }
 void set_gemm_w4(bool on) { g_w4 = on; }

@@ -176,10 +176,15 @@ int fmi_comm_stats(const fmi_comm*, unsigned long long* calls, unsigned long lon
 int fmi_comm_all_to_all(void* comm, const void* send, void* recv, size_t bytes_per_peer, void* stream);
 int fmi_comm_broadcast(fmi_comm*, void* buf, size_t bytes, int root, void* stream);
 int fmi_comm_gather(fmi_comm*, const void* send, void* recv, size_t bytes, int root, void* stream);
-/* Process-wide: rows from which 4-bit GEMMs use the one-wave-per-SIMD fused kernel (default 256). */
+/* PROCESS-WIDE test / ablation hooks — fmi_set_bnb4_onewave_min_rows, fmi_set_attention_kernel (below) and the environment
+ * variables FMI_GEMM_W4 / FMI_ATT_W4 read once at load — are shared by every handle and thread of the process: they pick between
+ * kernels that produce identical bits, so they move time, never results.  Set them before starting work on other threads.
+ * Everything that changes results (fp8 mode, split-K latency mode, the quantised-weight policy, sequence parallelism) is per handle.
+ * Rows from which 4-bit GEMMs use the one-wave-per-SIMD fused kernel (default 256): */
 int fmi_set_bnb4_onewave_min_rows(int rows);
-/* Test hook of the attention kernel's deferred-rescale branch: 0 = rescale on every key tile, else the
- * threshold in sixteenths of a log2 unit (default 96 = 6.0). */
+/* Test hook of the attention kernel's deferred-rescale branch, a BOOLEAN: 0 = rescale the accumulator on every key tile,
+ * any other value = the default (rescale only when the running maximum grew by more than 6.0 in log2 units; the kernels are
+ * instantiated for these two settings only). */
 int fmi_flux_set_attention_rescale_threshold(fmi_flux*, int thr_x16);
 /* The weights as flat device buffers — the unit of the multi-GPU broadcast (north star: "RCCL broadcast of
  * weights").  Rank 0 loads a checkpoint, fmi_flux_state_export() fills a small host blob saying which

@@ -171,3 +171,50 @@ def test_nf4_model_at_c3_tokens_fused_equals_dense_cache_and_holds_no_bf16_copy(
     print(f"nf4 D=3072 1+1 blocks at S=4096,T=512: fused == per-call expansion == dense cache bit for bit; resident {fused_bytes / 2**20:.0f} MiB fused, "
           f"{packed_bytes / 2**20:.0f} MiB with the scratch, {gm.size_in_bytes() / 2**20:.0f} MiB with the expanded cache")
     gm.close()
+
+
+def test_nf4_full_model_modulation_matrix_above_2e31_elements_with_400_rows(env):
+    """FLUX.1-dev in full (19 + 38 blocks) as an nf4 checkpoint — the fused modulation matrix is
+    344 D x D = 3.25e9 weights, more than 2^31 — with 8 prompts x 50 steps = 400 rows in the modulation precompute of
+    fmi_flux_denoise (Pipeline.MAX_BATCH = 8 makes this reachable).  The launch must stay on the fused dequant-GEMM (the
+    per-call scratch and the 32-bit dequant launchers cannot hold that matrix): the 8-sample denoise equals the same samples
+    run 4 + 4 (200 rows, always fused) bit for bit, and the expanded-cache mode (row-chunked one-time expansion) gives the same
+    bits.  Few tokens, so the 50 steps stay cheap."""
+    torch, d, L, lib, orc = env
+    cfg = dict(d.FLUX_DEV)
+    gm = d.FluxModel(cfg)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    for name, shape in d.synth.flux_tensor_shapes(cfg).items():
+        if "norm_q" in name or "norm_k" in name or "norm_added" in name:
+            t = torch.ones(shape, dtype=torch.bfloat16, device="cuda")
+        elif name.endswith(".bias"):
+            t = (torch.randn(shape, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+        else:
+            t = torch.randn(shape, generator=g, device="cuda", dtype=torch.bfloat16)
+            t.mul_(d.synth._std_for(name, 0.02, 0.01))
+        if name.endswith(".weight") and (d.synth.is_block_linear(name) or "norm" in name and "linear" in name):
+            packed, absmax = d.synth.quantize_nf4_device(t, 64)
+            gm.set_linear_bnb4(name[:-len(".weight")], packed, absmax, 64, "nf4", shape[0], shape[1])
+            del packed, absmax
+        else:
+            gm.set_tensor(name, t)
+        del t
+    gm.assert_complete()
+    B, T, hw, steps = 8, 32, (4, 8), 50
+    from tests.util import flux_inputs
+    img, ids, txt, txt_ids, y = flux_inputs(cfg, B, hw, T, seed=6)
+    gd = np.full((B,), 3.5, np.float32)
+    sched = d.SchedulerConfig()
+    ts = sched.get_timesteps(steps, sched.calculate_shift(hw[0] * hw[1]))
+    run = lambda sl: host(gm.denoise(dev(img[sl]), dev(ids[sl]), dev(txt[sl], torch.bfloat16), dev(txt_ids[sl]), dev(y[sl]), dev(gd[sl]), ts))
+    full = run(slice(0, 8))  # 400 modulation rows
+    halves = np.concatenate([run(slice(0, 4)), run(slice(4, 8))], 0)  # 200 + 200
+    assert np.isfinite(full).all() and np.array_equal(full, halves)
+    bufs = gm.state_buffers()
+    assert bufs[1][1] == 0 and bufs[2][1] == 0  # still no bf16 arena
+    gm.set_quant_dense_cache(1)  # one-time expansion of every matrix, the 3.25e9-weight one in row chunks
+    cached = run(slice(0, 8))
+    assert np.array_equal(full, cached)
+    print(f"nf4 FLUX.1-dev, 8 x 50 = 400 modulation rows over a 3.25e9-weight matrix: fused == 4+4 == expanded cache bit for bit "
+          f"({gm.size_in_bytes() / 2**30:.1f} GiB with the cache)")
+    gm.close()
