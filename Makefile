@@ -15,7 +15,7 @@ lib: $(LIB)
 oracle:
 	$(MAKE) -C oracle -s
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h $(CSRC)/attention_w4_loop.inc include/flux_mi355x.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h $(CSRC)/attention_w4_loop.inc $(CSRC)/attention_w16.h $(CSRC)/attention_w16_loop.inc $(CSRC)/attention_w32.h $(CSRC)/attention_w32_loop.inc include/flux_mi355x.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -25,6 +25,9 @@ $(LIB): $(OBJS)
 # the KV loop of attention_w4_kernel is generated assembly (committed; regenerate after editing the generator)
 $(CSRC)/attention_w4_loop.inc: tools/gen_attention_w4_loop.py
 	python3 tools/gen_attention_w4_loop.py > /dev/null
+
+$(CSRC)/attention_w16_loop.inc: tools/gen_attention_w16.py
+	python3 tools/gen_attention_w16.py
 
 clean:
 	rm -rf build $(LIB)

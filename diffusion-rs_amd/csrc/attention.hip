@@ -547,6 +547,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
 
 }  // namespace fmi
 #include "attention_w4.h"
+#include "attention_w16.h"
+#include "attention_w32.h"
 namespace fmi {
 
 static std::atomic<bool> g_att_pingpong{true};  // process-wide test hooks, like the GEMM switches (gemm_bf16.hip)
@@ -557,6 +559,19 @@ static std::atomic<bool> g_att_w4{[] {
   return e ? atoi(e) != 0 : true;
 }()};
 void set_attention_w4(bool on) { g_att_w4 = on; }
+// bf16 operands, round 3: the 16x16x32-MFMA one-wave kernel (attention_w16.h) in front of all of them; FMI_ATT_W16=0 /
+// set_attention_w16(false) falls back to the selection above.  Not bit-identical to the others (Q pre-scaled, row sums of the rounded P).
+static std::atomic<bool> g_att_w16{[] {
+  const char* e = getenv("FMI_ATT_W16");
+  return e ? atoi(e) != 0 : true;
+}()};
+void set_attention_w16(bool on) { g_att_w16 = on; }
+// the same design on the 32x32x16 MFMA (attention_w32.h): FMI_ATT_W32=0 / set_attention_w32(false) -> the selection above
+static std::atomic<bool> g_att_w32{[] {
+  const char* e = getenv("FMI_ATT_W32");
+  return e ? atoi(e) != 0 : true;
+}()};
+void set_attention_w32(bool on) { g_att_w32 = on; }
 
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
                         int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8, float* lse, int k_hstride) {  // (k_hstride: see the lse branch)
@@ -581,7 +596,17 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
       hipLaunchKernelGGL((attention_pp_kernel<0, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
     else
       hipLaunchKernelGGL((attention_pp_kernel<96, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
-  } else if (g_att_w4 && Lk > ATT_KV) {  // (a single KV tile has no steady state to pipeline: the 8-wave kernel serves it)
+  } else if (g_att_w32 && Lk > ATT_KV) {  // (a single KV tile has no steady state to pipeline: the 8-wave kernel serves it)
+    if (rescale_thr_x16 == 0)
+      hipLaunchKernelGGL((attention_w32_kernel<0>), grid, dim3(AW32_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+    else
+      hipLaunchKernelGGL((attention_w32_kernel<96>), grid, dim3(AW32_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+  } else if (g_att_w16 && Lk > ATT_KV) {
+    if (rescale_thr_x16 == 0)
+      hipLaunchKernelGGL((attention_w16_kernel<0>), grid, dim3(AW16_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+    else
+      hipLaunchKernelGGL((attention_w16_kernel<96>), grid, dim3(AW16_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+  } else if (g_att_w4 && Lk > ATT_KV) {
     if (rescale_thr_x16 == 0)
       hipLaunchKernelGGL((attention_w4_kernel<0>), grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, 0, nullptr, 1);
     else

@@ -230,8 +230,10 @@ extern "C" int fmi_sdpa_fp8qk(const void* q, const void* k, const void* v, void*
 // Process-wide kernel selection for bf16 attention (test / benchmark hook; all three give bit-identical results):
 // 2 (default) = one wave per SIMD (attention_w4.h), 1 = 8-wave ping-pong, 0 = 8-wave single barrier.
 extern "C" int fmi_set_attention_kernel(int kind) {
-  if (kind < 0 || kind > 2) return fail(FMI_ERR_INVALID, "set_attention_kernel: kind must be 0, 1 or 2");
-  set_attention_w4(kind == 2);
+  if (kind < 0 || kind > 4) return fail(FMI_ERR_INVALID, "set_attention_kernel: kind must be 0 .. 4");
+  set_attention_w32(kind == 4);
+  set_attention_w16(kind >= 3);
+  set_attention_w4(kind >= 2);
   set_attention_pingpong(kind >= 1);
   return FMI_OK;
 }

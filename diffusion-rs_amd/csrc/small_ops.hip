@@ -62,13 +62,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict x, co
 int launch_gemv(const float* x, const bf16_t* W, const bf16_t* bias, float* y, int M, int N, int K, int silu_in, int accumulate,
                 hipStream_t stream) {
   if (M <= 0 || N <= 0) return FMI_OK;
-  if (M > GEMV_MAXM) return fail(FMI_ERR_UNSUPPORTED, "gemv: batch > 8 not supported by the vector path");
   if (K % 8) return fail(FMI_ERR_INVALID, "gemv: K must be a multiple of 8");
-  const size_t lds = (size_t)M * K * sizeof(float);
-  if (lds > 64 * 1024) return fail(FMI_ERR_UNSUPPORTED, "gemv: M*K too large for LDS staging");
+  if ((size_t)K * sizeof(float) > 64 * 1024) return fail(FMI_ERR_UNSUPPORTED, "gemv: K too large for LDS staging");
+  // The x rows of a pass are staged in LDS as f32 (<= 64 KiB) and a wave keeps GEMV_MAXM accumulators: more rows (8 samples at
+  // D = 3072 are 96 KiB) run as several passes over W — each output row depends on its own x row only, so the split changes nothing.
+  const int rows_per_pass = std::max(1, std::min<int>(GEMV_MAXM, (int)((64 * 1024) / ((size_t)K * sizeof(float)))));
   const int rows_per_block = 4 * GEMV_ROWS_PER_WAVE;
-  hipLaunchKernelGGL(gemv_kernel, dim3(cdiv(N, rows_per_block)), dim3(256), lds, stream, x, W, bias, y, M, N, K, silu_in, accumulate);
-  FMI_LAUNCH_CHECK();
+  for (int m0 = 0; m0 < M; m0 += rows_per_pass) {
+    const int mm = std::min(rows_per_pass, M - m0);
+    hipLaunchKernelGGL(gemv_kernel, dim3(cdiv(N, rows_per_block)), dim3(256), (size_t)mm * K * sizeof(float), stream, x + (size_t)m0 * K, W, bias,
+                       y + (size_t)m0 * N, mm, N, K, silu_in, accumulate);
+    FMI_LAUNCH_CHECK();
+  }
   return FMI_OK;
 }
 

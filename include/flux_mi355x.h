@@ -178,7 +178,8 @@ int fmi_comm_broadcast(fmi_comm*, void* buf, size_t bytes, int root, void* strea
 int fmi_comm_gather(fmi_comm*, const void* send, void* recv, size_t bytes, int root, void* stream);
 /* PROCESS-WIDE test / ablation hooks — fmi_set_bnb4_onewave_min_rows, fmi_set_attention_kernel (below) and the environment
  * variables FMI_GEMM_W4 / FMI_ATT_W4 read once at load — are shared by every handle and thread of the process: they pick between
- * kernels that produce identical bits, so they move time, never results.  Set them before starting work on other threads.
+ * kernels that produce identical bits (the attention kernels: identical within a family, equal to rounding across, see
+ * fmi_set_attention_kernel), so they move time, not results.  Set them before starting work on other threads.
  * Everything that changes results (fp8 mode, split-K latency mode, the quantised-weight policy, sequence parallelism) is per handle.
  * Rows from which 4-bit GEMMs use the one-wave-per-SIMD fused kernel (default 256): */
 int fmi_set_bnb4_onewave_min_rows(int rows);
@@ -449,8 +450,12 @@ int fmi_linear_fp8(const void* x, const uint8_t* wq, const float* w_scale, const
  * == backend::ops::sdpa fallback (ops.rs:247-262) without materialising the scores. */
 int fmi_sdpa_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
                   int Lk, int d, float scale, int out_token_major, void* stream);
-/* Process-wide choice of the bf16 attention kernel (test / benchmark hook; the three are bit-identical):
- * 2 (default) one wave per SIMD (attention_w4.h), 1 the 8-wave ping-pong kernel, 0 the 8-wave single-barrier kernel. */
+/* Process-wide choice of the bf16 attention kernel (test / benchmark hook):
+ *   3 (default) one wave per SIMD on v_mfma_f32_16x16x32_bf16, the whole KV stream generated assembly (attention_w16.h);
+ *   4 the same design on v_mfma_f32_32x32x16_bf16 (attention_w32.h) — 3 and 4 are bit-identical to each other;
+ *   2 round 2's one-wave kernel (attention_w4.h), 1 the 8-wave ping-pong kernel, 0 the 8-wave single-barrier kernel — these
+ *   three are bit-identical to each other, and equal to 3 / 4 to rounding (3 / 4 round q * scale * log2(e) to bf16 once and
+ *   normalise by the sum of the bf16-rounded probabilities: rel-L2 ~3e-3 between the families, both within the oracle tolerance). */
 int fmi_set_attention_kernel(int kind);
 /* Same with q and k as OCP e4m3 bytes (B,H,L,128): QK^T on the fp8 MFMA, softmax / P / V in f32 / bf16 as above.
  * `scale` must include 1 / (q scale * k scale).  The fp8-mode attention of fmi_flux_* (fmi_flux_set_fp8_attention). */

@@ -109,11 +109,14 @@ def test_sdpa_random_shapes(env):
     print(f"20 random attentions: worst rel-L2 {worst:.2e}")
 
 
-def test_attention_kernels_agree_bitwise_on_random_shapes(env):
-    """The one-wave kernel (its KV loop is generated assembly, attention_w4_loop.inc), the 8-wave ping-pong kernel and the
-    single-barrier kernel implement one arithmetic: their outputs must be identical bit for bit on every shape — ragged, exact
-    multiples of 64 / 256, long KV (many loop iterations), batch > 1 — and from run to run (a hazard in a hand-scheduled
-    loop shows up as a rare, shape- or timing-dependent difference)."""
+def test_attention_kernels_agree_on_random_shapes(env):
+    """Five kernels, two arithmetic families.  The round-2 one-wave kernel (attention_w4_loop.inc), the 8-wave ping-pong kernel and
+    the single-barrier kernel implement ONE arithmetic: identical bit for bit.  Round 3's kernels (attention_w16 / attention_w32:
+    the whole KV stream generated assembly, Q pre-multiplied by scale * log2(e) and rounded to bf16 once, row sums of the
+    bf16-rounded probabilities from a ones-row MFMA) implement another: identical to EACH OTHER bit for bit (two MFMA shapes, two
+    schedules, one arithmetic — a hazard in either hand-scheduled stream shows up as a difference), equal to the first family to
+    rounding (rel-L2 <= 6e-3, the oracle tolerance of a single attention), and every kernel reproduces itself from run to run.
+    Shapes: ragged, exact multiples of 64 / 256, long KV (many loop iterations), batch > 1."""
     torch, L, lib = env
     rng = np.random.default_rng(2024)
     g = torch.Generator(device="cuda").manual_seed(11)
@@ -121,22 +124,29 @@ def test_attention_kernels_agree_bitwise_on_random_shapes(env):
     for _ in range(10):
         Lq = int(rng.integers(65, 1500))
         shapes.append((int(rng.integers(1, 3)), int(rng.integers(1, 4)), Lq, Lq if rng.integers(0, 2) else int(rng.integers(65, 3000))))
+    worst = 0.0
     try:
         for (B, H, Lq, Lk) in shapes:
             q = torch.randn(B, H, Lq, 128, device="cuda", generator=g).to(torch.bfloat16)
             k = torch.randn(B, H, Lk, 128, device="cuda", generator=g).to(torch.bfloat16)
             v = torch.randn(B, H, Lk, 128, device="cuda", generator=g).to(torch.bfloat16)
             outs = []
-            for kind in (2, 1, 0, 2):  # one-wave (default), ping-pong, single-barrier, one-wave again
+            kinds = (3, 4, 3, 4, 2, 1, 0, 2)  # 16x16x32 one-wave (default), 32x32x16 one-wave, both again, then the round-2 family
+            for kind in kinds:
                 L.check(lib.fmi_set_attention_kernel(kind))
                 o = torch.full((B, Lq, H * 128), float("nan"), device="cuda", dtype=torch.bfloat16)
                 L.check(lib.fmi_sdpa_bf16(_p(q), _p(k), _p(v), _p(o), B, H, Lq, Lk, 128, 1.0 / 128 ** 0.5, 1, None))
                 torch.cuda.synchronize()
-                outs.append(o.view(torch.int16).cpu().numpy())
-            assert np.isfinite(o.float().cpu().numpy()).all(), (B, H, Lq, Lk)
-            for i in (1, 2, 3):
-                nbad = int((outs[0] != outs[i]).sum())
-                assert nbad == 0, (B, H, Lq, Lk, ["", "ping-pong", "single-barrier", "one-wave rerun"][i], nbad)
+                outs.append(o)
+                assert torch.isfinite(o.float()).all(), (B, H, Lq, Lk, kind)
+            bits = [o.view(torch.int16).cpu().numpy() for o in outs]
+            for i, what in ((1, "w32 vs w16"), (2, "w16 rerun"), (3, "w32 rerun"), (5, "ping-pong vs w4"), (6, "single-barrier vs w4"), (7, "w4 rerun")):
+                ref = bits[0] if i <= 3 else bits[4]
+                nbad = int((ref != bits[i]).sum())
+                assert nbad == 0, (B, H, Lq, Lk, what, nbad)
+            err = float((outs[0].float() - outs[4].float()).norm() / outs[4].float().norm())
+            worst = max(worst, err)
+            assert err <= 6e-3, (B, H, Lq, Lk, err)
     finally:
-        L.check(lib.fmi_set_attention_kernel(2))
-    print(f"{len(shapes)} shapes x 3 kernels: bit-identical")
+        L.check(lib.fmi_set_attention_kernel(3))
+    print(f"{len(shapes)} shapes x 5 kernels: two bit-identical families, worst rel-L2 between them {worst:.2e}")

@@ -45,11 +45,19 @@ int main(int argc, char** argv) {
     hipMalloc((void**)&o2, n * 2);
     bf16_t* o3;
     hipMalloc((void**)&o3, n * 2);
-    double tf[3];
-    for (int pp = 0; pp < 3; ++pp) {  // single-barrier kernel, the ping-pong kernel, the one-wave-per-SIMD kernel
+    bf16_t* o4;
+    hipMalloc((void**)&o4, n * 2);
+    hipMemset(o4, 0xff, n * 2);
+    bf16_t* o5;
+    hipMalloc((void**)&o5, n * 2);
+    hipMemset(o5, 0xff, n * 2);
+    double tf[5];
+    for (int pp = 0; pp < 5; ++pp) {  // single-barrier kernel, the ping-pong kernel, the one-wave-per-SIMD kernel, the 16x16x32 one-wave kernel
       set_attention_pingpong(pp != 0);
       set_attention_w4(pp == 2);
-      bf16_t* dst = pp == 0 ? o : pp == 1 ? o2 : o3;
+      set_attention_w16(pp == 3);
+      set_attention_w32(pp == 4);
+      bf16_t* dst = pp == 0 ? o : pp == 1 ? o2 : pp == 2 ? o3 : pp == 3 ? o4 : o5;
       for (int i = 0; i < 3; ++i) launch_attention(q, k, vt, dst, s.B, s.H, s.L, s.L, Lpad, scale, 1, nullptr);
       hipDeviceSynchronize();
       hipEventRecord(e0, nullptr);
@@ -61,7 +69,9 @@ int main(int argc, char** argv) {
       ms /= iters;
       tf[pp] = 4.0 * s.B * s.H * (double)s.L * s.L * 128 / (ms * 1e-3) / 1e12;
     }
-    std::vector<uint16_t> ha(n), hb(n), hc(n);
+    std::vector<uint16_t> ha(n), hb(n), hc(n), hd(n), he(n);
+    hipMemcpy(hd.data(), o4, n * 2, hipMemcpyDeviceToHost);
+    hipMemcpy(he.data(), o5, n * 2, hipMemcpyDeviceToHost);
     hipMemcpy(ha.data(), o, n * 2, hipMemcpyDeviceToHost);
     hipMemcpy(hb.data(), o2, n * 2, hipMemcpyDeviceToHost);
     hipMemcpy(hc.data(), o3, n * 2, hipMemcpyDeviceToHost);
@@ -92,11 +102,26 @@ int main(int argc, char** argv) {
       printf("   one-wave vs pp: max |diff| %.4g, first at token %zu head %zu d %zu (pp %.5g, one-wave %.5g); %zu of %zu token rows differ, last %zu\n", maxd, row,
              col / 128, col % 128, tof(hb[first]), tof(hc[first]), rows_bad, (size_t)s.B * s.L, last_row);
     }
+    for (int which = 0; which < 2; ++which) {  // the round-3 kernels equal the others to rounding (Q pre-scaled, row sums of the rounded P), not bit for bit
+      const std::vector<uint16_t>& hx = which ? he : hd;
+      double num = 0, den = 0, mx = 0;
+      size_t nan = 0;
+      for (size_t i = 0; i < n; ++i) {
+        const double a = tof(hx[i]), b = tof(hb[i]);
+        if (!(a == a)) ++nan;
+        num += (a - b) * (a - b), den += b * b;
+        mx = std::max(mx, std::fabs(a - b));
+      }
+      printf("   %s vs pp: rel-L2 %.3e, max |diff| %.4g, NaN %zu     %s %7.1f TF (%6.1f us)\n", which ? "w32" : "w16", std::sqrt(num / std::max(den, 1e-30)), mx, nan,
+             which ? "w32" : "w16", tf[3 + which], 4.0 * s.B * s.H * (double)s.L * s.L * 128 / tf[3 + which] * 1e-6);
+    }
     const double fl = 4.0 * s.B * s.H * (double)s.L * s.L * 128;
     printf("B=%d H=%d L=%d  single-barrier %7.1f TF   ping-pong %7.1f TF (%6.1f us)   one-wave %7.1f TF (%6.1f us)   mismatching elements: pp vs sb %zu, one-wave vs pp %zu%s\n", s.B,
            s.H, s.L, tf[0], tf[1], fl / tf[1] * 1e-6, tf[2], fl / tf[2] * 1e-6, mis, mis3, hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
     hipFree(o2);
     hipFree(o3);
+    hipFree(o4);
+    hipFree(o5);
     hipFree(q); hipFree(k); hipFree(vt); hipFree(o);
   }
   return 0;
