@@ -123,6 +123,8 @@ def load():
         getattr(lib, f"fmi_{enc}_size_in_bytes").argtypes = [C.c_void_p]
         getattr(lib, f"fmi_{enc}_destroy").argtypes = [C.c_void_p]
         getattr(lib, f"fmi_{enc}_destroy").restype = None
+    lib.fmi_t5_set_linear_bnb4.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.fmi_t5_set_linear_int8.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.fmi_t5_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.fmi_clip_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.fmi_flux_denoise.argtypes = [C.c_void_p, C.POINTER(FluxInputs), C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_void_p]
@@ -175,7 +177,7 @@ EXPORTED = [
     "fmi_flux_forward", "fmi_flux_denoise", "fmi_flux_set_profiling", "fmi_flux_set_fused_qkv_relayout", "fmi_flux_phase_count", "fmi_flux_phase_name", "fmi_flux_phase_ms",
     "fmi_vae_default_config", "fmi_vae_create", "fmi_vae_destroy", "fmi_vae_set_tensor", "fmi_vae_missing_count", "fmi_vae_missing_name",
     "fmi_vae_scale_factor", "fmi_vae_shift_factor", "fmi_vae_decode", "fmi_vae_encode", "fmi_vae_mid_attention",
-    "fmi_t5_default_config", "fmi_t5_create", "fmi_t5_destroy", "fmi_t5_set_tensor", "fmi_t5_missing_count", "fmi_t5_missing_name",
+    "fmi_t5_default_config", "fmi_t5_create", "fmi_t5_destroy", "fmi_t5_set_tensor", "fmi_t5_set_linear_bnb4", "fmi_t5_set_linear_int8", "fmi_t5_missing_count", "fmi_t5_missing_name",
     "fmi_t5_size_in_bytes", "fmi_t5_forward", "fmi_clip_default_config", "fmi_clip_create", "fmi_clip_destroy", "fmi_clip_set_tensor",
     "fmi_clip_missing_count", "fmi_clip_missing_name", "fmi_clip_size_in_bytes", "fmi_clip_forward", "fmi_pack_latents", "fmi_unpack_latents", "fmi_postprocess_u8",
     "fmi_randn", "fmi_philox_u32", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_linear_int8_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_set_attention_kernel", "fmi_layernorm_mod",

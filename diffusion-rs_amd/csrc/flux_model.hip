@@ -534,8 +534,8 @@ int densify(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s)
     if (m->dense_cache) {
       FMI_TRY(ensure_arena(m, d->ar));
       if (!m->dense_ready.count(d)) {
-        // expanded once, in row chunks below 2^31 elements (chunk starts stay multiples of the quantisation block: K % 64 == 0)
-        const int chunk = std::max(64, (int)std::min<int64_t>(d->N, (((1ll << 31) - 1) / d->K) / 64 * 64));
+        // expanded once, in row chunks of at most 2^28 elements (chunk starts stay multiples of the quantisation block: K % 64 == 0)
+        const int chunk = std::max(64, (int)std::min<int64_t>(d->N, ((1ll << 28) / d->K) / 64 * 64));  // (the dequant kernels index in 32 bits: stay well below 2^31)
         for (int r0 = 0; r0 < d->N; r0 += chunk) FMI_TRY(dequant_rows(*d, r0, std::min(chunk, d->N - r0), d->q_type, d->q_blocksize, s));
         m->dense_ready.insert(d);
       }

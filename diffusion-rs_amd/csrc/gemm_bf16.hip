@@ -820,11 +820,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int ra = (a_chunk0 + i) * 8 + (lane >> 3), rw = (w_chunk0 + i) * 8 + (lane >> 3);
-    a_off[i] = (uint32_t)((int64_t)min(m0 + ra, P.M - 1) * P.lda * ES + (((lane & 7) ^ ((ra >> 1) & 7)) << 4));
-    w_off[i] = (uint32_t)((int64_t)min(n0 + rw, P.N - 1) * P.ldw * ES + (((lane & 7) ^ ((rw >> 1) & 7)) << 4));
+    // relative to the tile's first row (the uniform base below carries m0 / n0 in 64 bits): an operand may exceed 4 GiB — the fused
+    // modulation matrix of FLUX.1 is 6.5 GB — but a tile's 256 rows never do
+    a_off[i] = (uint32_t)((int64_t)(min(m0 + ra, P.M - 1) - m0) * P.lda * ES + (((lane & 7) ^ ((ra >> 1) & 7)) << 4));
+    w_off[i] = (uint32_t)((int64_t)(min(n0 + rw, P.N - 1) - n0) * P.ldw * ES + (((lane & 7) ^ ((rw >> 1) & 7)) << 4));
   }
-  const char* const a_base = reinterpret_cast<const char*>(P.A);
-  const char* const w_base = reinterpret_cast<const char*>(P.W);
+  const char* const a_base = reinterpret_cast<const char*>(P.A) + (int64_t)m0 * P.lda * ES;
+  const char* const w_base = reinterpret_cast<const char*>(P.W) + (int64_t)n0 * P.ldw * ES;
   auto dma_a = [&](int kt, int i) {
     const char* base = a_base + (int64_t)kt * (BK * 2);  // uniform
     __builtin_amdgcn_global_load_lds((glb_void*)(base + a_off[i]), (lds_void*)(smem + A_RING + (kt & 1) * TILE + (a_chunk0 + i) * 1024), 16, 0, 0);
@@ -1123,11 +1125,11 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int r = (wave * 8 + i) * 8 + (lane >> 3);
-    a_off[i] = (uint32_t)((int64_t)min(m0 + r, P.M - 1) * P.lda * ES + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
-    w_off[i] = (uint32_t)((int64_t)min(n0 + r, P.N - 1) * P.ldw * ES + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+    a_off[i] = (uint32_t)((int64_t)(min(m0 + r, P.M - 1) - m0) * P.lda * ES + (((lane & 7) ^ ((r >> 1) & 7)) << 4));  // tile-relative, see gemm_pp_kernel
+    w_off[i] = (uint32_t)((int64_t)(min(n0 + r, P.N - 1) - n0) * P.ldw * ES + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
   }
-  const char* const a_base = reinterpret_cast<const char*>(P.A);
-  const char* const w_base = reinterpret_cast<const char*>(P.W);
+  const char* const a_base = reinterpret_cast<const char*>(P.A) + (int64_t)m0 * P.lda * ES;
+  const char* const w_base = reinterpret_cast<const char*>(P.W) + (int64_t)n0 * P.ldw * ES;
   // LDS-DMA in the scalar-base form (SGPR pair + 32-bit lane offset), written as asm: from the builtin hipcc forms a 64-bit
   // per-lane address with a v_lshl_add_u64 in front of every piece inside this loop (+1-2 % on the K loop, tools/gemm_bench).
   // m0 = LDS destination of the 1-KiB piece; one wait state between the m0 write and the load.

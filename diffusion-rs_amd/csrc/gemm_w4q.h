@@ -84,9 +84,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const GemmBatch
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int r = (wave * 8 + i) * 8 + (lane >> 3);
-    a_off[i] = (uint32_t)((int64_t)min(m0 + r, P.M - 1) * P.lda * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+    a_off[i] = (uint32_t)((int64_t)(min(m0 + r, P.M - 1) - m0) * P.lda * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4));  // tile-relative
   }
-  const char* const a_base = reinterpret_cast<const char*>(P.A);
+  const char* const a_base = reinterpret_cast<const char*>(P.A) + (int64_t)m0 * P.lda * 2;
   auto dma_a = [&](int kt, int slot, int i) {
     const char* base = a_base + (int64_t)kt * (BK * 2);
     __builtin_amdgcn_global_load_lds((glb_void*)(base + a_off[i]), (lds_void*)(smem + A_RING + slot * TILE + (wave * 8 + i) * 1024), 16, 0, 0);

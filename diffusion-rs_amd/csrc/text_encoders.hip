@@ -388,6 +388,76 @@ extern "C" int fmi_t5_set_tensor(fmi_t5* m, const char* name, const void* data, 
   if (!m) return fail(FMI_ERR_INVALID, "t5_set_tensor: null model");
   return m->r.set("t5_set_tensor", name, data, dtype, shape, rank);
 }
+// Quantised T5 Linears.  The reference builds every T5 Linear through `linear_no_bias(.., &cfg.quantization_config, ..)`
+// (t5/mod.rs:132-133,164-173,258-261) -> BnbLinear (bitsandbytes/mod.rs:111-239), whose forward is "dequantise W, then matmul"
+// (:293-312).  The encoder runs ONCE per image (25 ms of 3.2 s), so the codes are expanded once, here, into the linear's slot of
+// the bf16 arena with the library's own dequant kernels (kDequantizeBlockwise / dequantize_8bit semantics: bit-exact with the
+// stand-alone entry points) and the forward is the dense one: the same numbers BnbLinear::forward produces, no per-call expansion.
+namespace {
+int t5_linear_dest(fmi_t5* m, const char* who, const char* prefix, int out_features, int in_features, Dest* out, std::string* wname) {
+  *wname = std::string(prefix) + ".weight";
+  auto it = m->r.names.find(*wname);
+  if (it == m->r.names.end() || !it->second.cols) return fail(FMI_ERR_INVALID, std::string(who) + ": unknown linear '" + prefix + "'");
+  if (wname->find("SelfAttention.") == std::string::npos && wname->find("DenseReluDense.") == std::string::npos)
+    return fail(FMI_ERR_INVALID, std::string(who) + ": '" + prefix + "' is not a Linear of the encoder blocks");
+  if (it->second.rows != out_features || it->second.cols != in_features) return fail(FMI_ERR_INVALID, std::string(who) + ": shape mismatch for " + *wname);
+  *out = it->second;
+  return FMI_OK;
+}
+}  // namespace
+extern "C" int fmi_t5_set_linear_bnb4(fmi_t5* m, const char* prefix, const uint8_t* packed, const float* absmax, int blocksize, int quant_type,
+                                      int out_features, int in_features) {
+  if (m) FMI_TRY(use_device_ordinal(m->device));
+  if (!m || !prefix || !packed || !absmax) return fail(FMI_ERR_INVALID, "t5_set_linear_bnb4: null argument");
+  if (quant_type != 1 && quant_type != 2) return fail(FMI_ERR_INVALID, "t5_set_linear_bnb4: quant_type must be 1 (fp4) or 2 (nf4)");
+  const int64_t n = (int64_t)out_features * in_features;
+  if (blocksize <= 0 || (blocksize & (blocksize - 1)) || n % blocksize || n % 2) return fail(FMI_ERR_UNSUPPORTED, "t5_set_linear_bnb4: blocksize must be a power of two dividing the weight");
+  if (n >= (1ll << 31)) return fail(FMI_ERR_UNSUPPORTED, "t5_set_linear_bnb4: linear too large");
+  Dest d;
+  std::string wname;
+  FMI_TRY(t5_linear_dest(m, "t5_set_linear_bnb4", prefix, out_features, in_features, &d, &wname));
+  uint8_t* dq = nullptr;
+  float* da = nullptr;
+  FMI_HIP_TRY(hipMalloc((void**)&dq, (size_t)n / 2));
+  hipError_t e = hipMalloc((void**)&da, (size_t)(n / blocksize) * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(dq, packed, (size_t)n / 2, hipMemcpyDefault);
+  if (e == hipSuccess) e = hipMemcpy(da, absmax, (size_t)(n / blocksize) * sizeof(float), hipMemcpyDefault);
+  if (e == hipSuccess) {
+    if (quant_type == 2) dequantize_blockwise_bf16_nf4(nullptr, dq, da, d.ptr, blocksize, (int)n, nullptr);
+    else dequantize_blockwise_bf16_fp4(nullptr, dq, da, d.ptr, blocksize, (int)n, nullptr);
+    e = hipDeviceSynchronize();
+  }
+  (void)hipFree(dq);
+  if (da) (void)hipFree(da);
+  if (e != hipSuccess) return fail(FMI_ERR_HIP, std::string("t5_set_linear_bnb4: ") + hipGetErrorString(e));
+  m->r.missing.erase(wname);
+  return FMI_OK;
+}
+extern "C" int fmi_t5_set_linear_int8(fmi_t5* m, const char* prefix, const int8_t* weight, const float* scb, int out_features, int in_features) {
+  if (m) FMI_TRY(use_device_ordinal(m->device));
+  if (!m || !prefix || !weight || !scb) return fail(FMI_ERR_INVALID, "t5_set_linear_int8: null argument");
+  const int64_t n = (int64_t)out_features * in_features;
+  Dest d;
+  std::string wname;
+  FMI_TRY(t5_linear_dest(m, "t5_set_linear_int8", prefix, out_features, in_features, &d, &wname));
+  int8_t* dw = nullptr;
+  float* ds = nullptr;
+  FMI_HIP_TRY(hipMalloc((void**)&dw, (size_t)n));
+  hipError_t e = hipMalloc((void**)&ds, (size_t)out_features * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(dw, weight, (size_t)n, hipMemcpyDefault);
+  if (e == hipSuccess) e = hipMemcpy(ds, scb, (size_t)out_features * sizeof(float), hipMemcpyDefault);
+  int rc = FMI_OK;
+  if (e == hipSuccess) {
+    rc = launch_dequant_int8_scb_bf16(dw, ds, d.ptr, in_features, n, nullptr);
+    e = hipDeviceSynchronize();
+  }
+  (void)hipFree(dw);
+  if (ds) (void)hipFree(ds);
+  if (e != hipSuccess) return fail(FMI_ERR_HIP, std::string("t5_set_linear_int8: ") + hipGetErrorString(e));
+  if (rc) return rc;
+  m->r.missing.erase(wname);
+  return FMI_OK;
+}
 extern "C" int fmi_t5_missing_count(const fmi_t5* m) { return m ? (int)m->r.missing.size() : 0; }
 extern "C" const char* fmi_t5_missing_name(fmi_t5* m, int i) {
   if (!m) return nullptr;

@@ -123,15 +123,17 @@ def _resolve_absmax(lib, group: Dict[str, torch.Tensor], state: dict, device) ->
     return out + float(state["nested_offset"])
 
 
-def load_flux(flux, tensors: Iterator[Tuple[str, torch.Tensor]]) -> dict:
-    """Feed a FluxModel from (name, tensor) pairs; returns {"dense": n, "bnb4": n, "skipped": [...]}."""
+def _feed_linears(model, tensors: Iterator[Tuple[str, torch.Tensor]], want: dict, on_extra=None) -> dict:
+    """Shared by load_flux and load_text_encoder: feed `model` (set_tensor / set_linear_bnb4 / set_linear_int8, .device) from
+    (name, tensor) pairs.  bitsandbytes layers arrive as groups of tensors — "<prefix>.weight" (packed u8 or int8) with
+    "<prefix>.weight.absmax", ".weight.quant_map", ".weight.quant_state.bitsandbytes__nf4|fp4" (+ the nested_* tensors of double
+    quantisation), or "<prefix>.SCB" for LLM.int8 — the naming BnbLinear::linear_b reads (bitsandbytes/mod.rs:111-239).
+    `on_extra(name, tensor) -> bool` may claim a name the model does not list.  Returns {"dense", "bnb4", "int8", "skipped"}."""
     from . import _lib as L
     lib = L.load()
-    want = synth.flux_tensor_shapes(flux.cfg)
-    stats = {"dense": 0, "bnb4": 0, "skipped": []}
+    stats = {"dense": 0, "bnb4": 0, "int8": 0, "skipped": []}
     pending: Dict[str, Dict[str, torch.Tensor]] = {}
     for name, t in tensors:
-        # bnb side tensors: "<prefix>.weight.absmax", ".weight.quant_map", ".weight.quant_state.bitsandbytes__nf4", ...
         if ".weight." in name:
             prefix, rest = name.split(".weight.", 1)
             pending.setdefault(prefix, {})["weight." + rest] = t
@@ -145,19 +147,23 @@ def load_flux(flux, tensors: Iterator[Tuple[str, torch.Tensor]]) -> dict:
             pending.setdefault(name[:-len(".weight")], {})["weight"] = t
             continue
         if name in want:
-            flux.set_tensor(name, t)
+            model.set_tensor(name, t)
+            stats["dense"] += 1
+        elif on_extra is not None and on_extra(name, t):
             stats["dense"] += 1
         else:
             stats["skipped"].append(name)
-    stats["int8"] = 0
     for prefix, group in pending.items():
+        if prefix + ".weight" not in want:
+            stats["skipped"].append(prefix + ".weight")
+            continue
+        out_f, in_f = want[prefix + ".weight"]
         if "SCB" in group:  # BnbLinear::Int8
             if "weight" not in group or group["weight"].dtype != torch.int8:
                 raise ValueError(f"`BnbLinear` int8 layer {prefix} needs an int8 `weight` next to `SCB`")
-            out_f, in_f = want[prefix + ".weight"]
             if tuple(group["weight"].shape) != (out_f, in_f) or group["SCB"].numel() != out_f:
                 raise ValueError(f"{prefix}: int8 weight {tuple(group['weight'].shape)} / SCB {tuple(group['SCB'].shape)} != expected {(out_f, in_f)}")
-            flux.set_linear_int8(prefix, group["weight"], group["SCB"], out_f, in_f)
+            model.set_linear_int8(prefix, group["weight"], group["SCB"], out_f, in_f)
             stats["int8"] += 1
             continue
         qkey = next((k for k in group if k.startswith("weight.quant_state.bitsandbytes__")), None)
@@ -165,12 +171,17 @@ def load_flux(flux, tensors: Iterator[Tuple[str, torch.Tensor]]) -> dict:
             raise ValueError(f"`BnbLinear` expects fp4/nf4 layers: incomplete tensors for {prefix}: {sorted(group)}")  # bitsandbytes/mod.rs:120
         qt = qkey.rsplit("__", 1)[1]
         state = json.loads(bytes(group[qkey].numpy().tobytes()))
-        out_f, in_f = want[prefix + ".weight"]
         if list(state["shape"]) != [out_f, in_f]:
             raise ValueError(f"{prefix}: quant_state shape {state['shape']} != expected {(out_f, in_f)}")
-        absmax = _resolve_absmax(lib, group, state, flux.device)
-        flux.set_linear_bnb4(prefix, group["weight"].reshape(-1), absmax, int(state["blocksize"]), qt, out_f, in_f)
+        absmax = _resolve_absmax(lib, group, state, model.device)
+        model.set_linear_bnb4(prefix, group["weight"].reshape(-1), absmax, int(state["blocksize"]), qt, out_f, in_f)
         stats["bnb4"] += 1
+    return stats
+
+
+def load_flux(flux, tensors: Iterator[Tuple[str, torch.Tensor]]) -> dict:
+    """Feed a FluxModel from (name, tensor) pairs; returns {"dense": n, "bnb4": n, "int8": n, "skipped": [...]}."""
+    stats = _feed_linears(flux, tensors, synth.flux_tensor_shapes(flux.cfg))
     flux.assert_complete()
     return stats
 
@@ -186,18 +197,21 @@ def load_vae(vae, tensors: Iterator[Tuple[str, torch.Tensor]]) -> int:
 
 
 def load_text_encoder(model, tensors: Iterator[Tuple[str, torch.Tensor]]) -> int:
-    """Feed a T5EncoderModel / ClipTextTransformer from (name, tensor) pairs; names the model does not
-    read (decoder-tied embeddings, position_ids buffers, CLIP's unused text_projection) are skipped."""
+    """Feed a T5EncoderModel / ClipTextTransformer from (name, tensor) pairs; names the model does not read (decoder-tied
+    embeddings, position_ids buffers, CLIP's unused text_projection) are skipped.  A bitsandbytes-quantised T5 (the reference
+    builds every T5 Linear through `linear_no_bias(.., &cfg.quantization_config, ..)`, t5/mod.rs:132-173,258-261 — the
+    FLUX.1-dev-Q4-bnb.dduf layout of README.md:37-41) is fed through the same group logic as the DiT."""
     want = model.tensor_names()
-    n = 0
-    for name, t in tensors:
-        if name in want:
-            model.set_tensor(name, t)
-            n += 1
-        elif name == "encoder.embed_tokens.weight" and "shared.weight" in model.missing():
+
+    def extra(name, t):
+        if name == "encoder.embed_tokens.weight" and "shared.weight" in model.missing():
             model.set_tensor("shared.weight", t)  # T5EncoderModel::new falls back to it (t5/mod.rs:615-621)
-            n += 1
+            return True
+        return False
+
+    stats = _feed_linears(model, tensors, want, on_extra=extra)
     m = model.missing()
     if m:
         raise ValueError(f"{len(m)} text-encoder tensors missing, e.g. {m[0]}")
-    return n
+    model.load_stats = stats
+    return stats["dense"] + stats["bnb4"] + stats["int8"]

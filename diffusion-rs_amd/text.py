@@ -78,8 +78,8 @@ class T5EncoderModel(_Encoder):
         L.check(self.lib.fmi_init(device))
         self.device = torch.device("cuda", device)
         cfg = dict(T5_XXL if cfg is None else cfg)
-        if cfg.get("quantization_config"):
-            raise L.FmiError("quantised (bitsandbytes) T5 checkpoints are not supported; use the bf16 text_encoder_2")
+        # `quantization_config` (bitsandbytes nf4 / fp4 / LLM.int8, t5/mod.rs:85-90): the quantised Linears arrive through
+        # set_linear_bnb4 / set_linear_int8 (loader.load_text_encoder); nothing to configure up front
         self.cfg = cfg
         c = L.T5Config(cfg["vocab_size"], cfg["d_model"], cfg["d_kv"], cfg["d_ff"], cfg["num_layers"], cfg["num_heads"], cfg["relative_attention_num_buckets"],
                        cfg.get("relative_attention_max_distance", 128), cfg["layer_norm_epsilon"], _T5_ACT[cfg.get("feed_forward_proj", "relu")])
@@ -90,6 +90,21 @@ class T5EncoderModel(_Encoder):
     def tensor_names(self):
         from . import synth
         return synth.t5_tensor_shapes(self.cfg)
+
+    def set_linear_bnb4(self, prefix: str, packed, absmax, blocksize: int, quant_type: str, out_features: int, in_features: int):
+        """A bitsandbytes 4-bit Linear of the encoder (BnbLinear::linear_b, bitsandbytes/mod.rs:137-239; used by every T5 Linear
+        when text_encoder_2/config.json carries a quantization_config, t5/mod.rs:132-173,258-261): packed codes (u8, n/2) +
+        f32 absmax (n/blocksize), quant_type "nf4" | "fp4"."""
+        pk = packed.to(device=self.device, dtype=torch.uint8).contiguous()
+        am = absmax.to(device=self.device, dtype=torch.float32).contiguous()
+        L.check(self.lib.fmi_t5_set_linear_bnb4(self.h, prefix.encode(), _ptr(pk), _ptr(am), int(blocksize), {"fp4": 1, "nf4": 2}[quant_type], int(out_features),
+                                                int(in_features)))
+
+    def set_linear_int8(self, prefix: str, weight, scb, out_features: int, in_features: int):
+        """An LLM.int8 Linear (BnbLinear::Int8, bitsandbytes/mod.rs:104-134): int8 weight (out, in) + f32 SCB (out)."""
+        w = weight.to(device=self.device, dtype=torch.int8).contiguous()
+        sc = scb.to(device=self.device, dtype=torch.float32).contiguous()
+        L.check(self.lib.fmi_t5_set_linear_int8(self.h, prefix.encode(), _ptr(w), _ptr(sc), int(out_features), int(in_features)))
 
     def forward(self, input_ids, dtype=torch.bfloat16):
         """== T5EncoderModel::forward: ids (B,T) -> hidden states (B,T,d_model) in the model dtype."""

@@ -345,6 +345,14 @@ void fmi_t5_destroy(fmi_t5*);
  * encoder.block.N.layer.1.{layer_norm.weight, DenseReluDense.{wi_0,wi_1,wo}.weight},
  * encoder.final_layer_norm.weight */
 int fmi_t5_set_tensor(fmi_t5*, const char* name, const void* data, fmi_dtype dtype, const int64_t* shape, int rank);
+/* bitsandbytes-quantised Linears of the encoder blocks (`<prefix>` = "encoder.block.N.layer.0.SelfAttention.q" ...): the
+ * reference builds every T5 Linear as a QuantMethod from text_encoder_2's quantization_config (t5/mod.rs:132-173,258-261 ->
+ * BnbLinear, bitsandbytes/mod.rs:111-239).  Arguments as fmi_flux_set_linear_bnb4 / _int8 (host or device pointers).  The
+ * codes are expanded once at load into the encoder's bf16 weights (BnbLinear::forward = dequantise + matmul, mod.rs:293-312;
+ * the encoder runs once per image), bit-exact with dequantize_blockwise_bf16_* / dequantize_8bit_kernel_bf16. */
+int fmi_t5_set_linear_bnb4(fmi_t5*, const char* prefix, const uint8_t* packed, const float* absmax, int blocksize, int quant_type,
+                           int out_features, int in_features);
+int fmi_t5_set_linear_int8(fmi_t5*, const char* prefix, const int8_t* weight, const float* scb, int out_features, int in_features);
 int fmi_t5_missing_count(const fmi_t5*);
 const char* fmi_t5_missing_name(fmi_t5*, int i);
 size_t fmi_t5_size_in_bytes(const fmi_t5*);

@@ -179,3 +179,33 @@ def test_vae_full_resolution_is_finite_and_deterministic():
     assert torch.equal(a, b)
     assert float(a.std()) > 1e-3
     vae.close()
+
+
+@pytest.mark.parametrize("M", [50, 400])
+def test_linear_with_a_weight_matrix_above_4_gib(lib_env, M):
+    """The fused modulation matrix of FLUX.1 is (344 * 3072) x 3072 bf16 = 6.5 GB, and fmi_flux_denoise multiplies it in ONE GEMM
+    (all steps' rows).  Regression test of round 3's finding: the dense kernels carried per-lane 32-bit byte offsets from the
+    operand's base, so weight rows beyond 4 GiB (the single blocks' and the final layer's modulation) were read from the wrapped
+    address — silently, the output stayed finite.  Offsets are tile-relative now.  Here: a 4.5 GB weight, the output columns on
+    both sides of the 4 GiB line against a plain matmul of those rows."""
+    torch, L, lib = lib_env
+    K, N = 3072, 736 * 1024  # 4.63e9 bytes
+    assert N * K * 2 > (1 << 32) + (1 << 28)
+    g = torch.Generator(device="cuda").manual_seed(M)
+    w = torch.empty((N, K), dtype=torch.bfloat16, device="cuda")
+    for r0 in range(0, N, 65536):  # filled in pieces: randn of the whole matrix in f32 would need 9 GB more
+        w[r0:r0 + 65536] = (torch.randn((min(65536, N - r0), K), generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    x = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+    y = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    bias = torch.zeros((N,), dtype=torch.bfloat16, device="cuda")
+    y16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.fmi_linear_bf16(_p(x), _p(w), _p(bias), _p(y16), M, N, K, 0, None))
+    torch.cuda.synchronize()
+    line = (1 << 32) // (K * 2)  # first row whose bytes lie beyond 4 GiB
+    for (a, b) in ((0, 512), (line - 512, line + 512), (N - 700, N)):
+        ref = x.float() @ w[a:b].float().T
+        got = y16[:, a:b].float()
+        err = float((got - ref).norm() / ref.norm())
+        assert err <= 4e-3, (M, a, b, err)
+    del w, y, y16
+    torch.cuda.empty_cache()

@@ -307,3 +307,118 @@ def test_pipeline_more_prompts_than_max_batch(tmp_path):
     rest = pipe.generate_tensor(prompts[8:], params, embeddings=(t5[8:], clip[8:]), seed=7, sample_ids=[8, 9, 10]).cpu().numpy()
     np.testing.assert_array_equal(whole, np.concatenate([first, rest], 0))
     assert len({whole[i].tobytes() for i in range(B)}) == B  # every sample drew its own noise
+
+
+def _nf4_group(orc, d, name, w, nested):
+    """the tensors HF-bitsandbytes stores for one nf4 Linear (bitsandbytes/mod.rs:137-239), and the dense weight they stand for"""
+    import torch
+    prefix = name[:-len(".weight")]
+    packed, absmax = orc.quantize_blockwise_4bit(w.ravel(), 64, "nf4")
+    state = {"blocksize": 64, "shape": list(w.shape), "dtype": "bfloat16", "quant_type": "nf4"}
+    out = {name: torch.from_numpy(packed.reshape(-1, 1)), prefix + ".weight.quant_map": torch.from_numpy(np.array(d.synth.NF4_CODE, np.float32))}
+    eff = absmax
+    if nested:
+        code256 = np.linspace(-1.0, 1.0, 256).astype(np.float32)
+        off = float(absmax.mean())
+        a = absmax - np.float32(off)
+        nb = (a.size + 255) // 256
+        nabs = np.array([np.abs(a[i * 256:(i + 1) * 256]).max() for i in range(nb)], np.float32)
+        idx = np.array([np.abs(code256 - (a[i] / max(nabs[i // 256], 1e-30))).argmin() for i in range(a.size)], np.uint8)
+        eff = (code256[idx] * nabs[np.arange(a.size) // 256]).astype(np.float32) + np.float32(off)
+        state.update({"nested_blocksize": 256, "nested_offset": off, "nested_dtype": "float32"})
+        out[prefix + ".weight.absmax"] = torch.from_numpy(idx)
+        out[prefix + ".weight.nested_absmax"] = torch.from_numpy(nabs)
+        out[prefix + ".weight.nested_quant_map"] = torch.from_numpy(code256.copy())
+    else:
+        out[prefix + ".weight.absmax"] = torch.from_numpy(absmax)
+    out[prefix + ".weight.quant_state.bitsandbytes__nf4"] = torch.from_numpy(np.frombuffer(json.dumps(state).encode(), np.uint8).copy())
+    dense = orc.dequantize_blockwise(None, packed, eff, 64, w.size, "nf4", "bf16").reshape(w.shape)
+    return out, dense
+
+
+def test_q4_bnb_dduf_with_quantised_t5_prompt_to_image(tmp_path):
+    """§8(f) rank 2 completed: the layout of the reference's own example checkpoint, FLUX.1-dev-Q4-bnb.dduf
+    (README.md:37-41) — ONE DDUF whose transformer AND text_encoder_2 (T5) are bitsandbytes nf4 (text_encoder_2/config.json carries
+    a quantization_config; the reference builds every T5 Linear through it, t5/mod.rs:132-173,258-261), bf16 CLIP, both
+    tokenizers — goes prompt -> u8 through the front door, against the oracle chain on the dequantised weights."""
+    import zipfile
+    import torch
+    from safetensors.torch import save
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    import diffusion_rs_amd as d
+    from oracle import oracle as orc
+    t5_cfg = dict(vocab_size=64, d_model=SMALL_FLUX["joint_attention_dim"], d_kv=64, d_ff=256, num_layers=2, num_heads=2, relative_attention_num_buckets=32,
+                  relative_attention_max_distance=128, layer_norm_epsilon=1e-6, feed_forward_proj="gated-gelu")
+    clip_cfg = dict(vocab_size=40, projection_dim=SMALL_FLUX["pooled_projection_dim"], intermediate_size=128, max_position_embeddings=77, num_hidden_layers=2,
+                    num_attention_heads=1)
+    sd = d.synth.flux_state_dict_numpy(SMALL_FLUX, seed=12)
+    vsd = d.synth.vae_state_dict_numpy(SMALL_VAE, seed=12)
+    tsd = d.synth.text_state_dict_numpy(d.synth.t5_tensor_shapes(t5_cfg), seed=13)
+    csd = d.synth.text_state_dict_numpy(d.synth.clip_tensor_shapes(clip_cfg), seed=14)
+    ft, fdense, nq = {}, {}, 0
+    for name, w in sd.items():
+        if d.synth.is_block_linear(name):
+            grp, dense = _nf4_group(orc, d, name, w, nested=True)
+            ft.update(grp)
+            fdense[name] = dense
+            nq += 1
+        else:
+            ft[name] = torch.from_numpy(w).to(torch.bfloat16)
+            fdense[name] = w
+    tt, tdense, nqt = {}, {}, 0
+    for name, w in tsd.items():
+        if w.ndim == 2 and ("SelfAttention." in name or "DenseReluDense." in name) and "relative_attention_bias" not in name:
+            grp, dense = _nf4_group(orc, d, name, w, nested=(nqt % 2 == 0))  # plain and double-quantised absmax alternate
+            tt.update(grp)
+            tdense[name] = dense
+            nqt += 1
+        else:
+            tt[name] = torch.from_numpy(w).to(torch.bfloat16)
+            tdense[name] = w
+    assert nqt == 2 * 7  # q, k, v, o, wi_0, wi_1, wo per block
+    letters = "abcdefghijklmnopqrstuvwxyz "
+    vocab = {ch: i for i, ch in enumerate(letters)}
+    merges = [("t", "h"), ("th", "e"), ("a", "t"), ("c", "at")]
+    for a, b in merges:
+        vocab[a + b] = len(vocab)
+    words = ["<pad>", "</s>", "<unk>", "the", "cat", "sat", "on", "a", "mat", "dog", "ran"]
+    tk = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tk.post_processor = processors.TemplateProcessing(single="$A </s>", special_tokens=[("</s>", 1)])
+    qcfg = {"quant_method": "bitsandbytes", "load_in_4bit": True, "bnb_4bit_quant_type": "nf4", "bnb_4bit_use_double_quant": True}
+    path = str(tmp_path / "tiny-FLUX.1-dev-Q4-bnb.dduf")
+    with zipfile.ZipFile(path, "w", compression=zipfile.ZIP_STORED) as z:
+        z.writestr("model_index.json", json.dumps({"_class_name": "FluxPipeline"}))
+        z.writestr("scheduler/scheduler_config.json", json.dumps({"_class_name": "FlowMatchEulerDiscreteScheduler", "base_image_seq_len": 256,
+                   "base_shift": 0.5, "max_image_seq_len": 4096, "max_shift": 1.15, "shift": 3.0, "use_dynamic_shifting": True}))
+        z.writestr("transformer/config.json", json.dumps(dict({k: SMALL_FLUX[k] for k in ("in_channels", "pooled_projection_dim", "joint_attention_dim",
+                   "num_attention_heads", "num_layers", "num_single_layers", "guidance_embeds")}, quantization_config=qcfg)))
+        z.writestr("transformer/diffusion_pytorch_model.safetensors", save(ft))
+        z.writestr("vae/config.json", json.dumps(dict(SMALL_VAE)))
+        z.writestr("vae/diffusion_pytorch_model.safetensors", save({k: torch.from_numpy(v) for k, v in vsd.items()}))
+        z.writestr("text_encoder/config.json", json.dumps(dict(clip_cfg, hidden_size=clip_cfg["projection_dim"], hidden_act="quick_gelu")))
+        z.writestr("text_encoder/model.safetensors", save({k: torch.from_numpy(v).to(torch.bfloat16) for k, v in csd.items()}))
+        z.writestr("text_encoder_2/config.json", json.dumps(dict(t5_cfg, is_encoder_decoder=True, quantization_config=qcfg)))
+        z.writestr("text_encoder_2/model.safetensors", save(tt))
+        z.writestr("tokenizer/vocab.json", json.dumps(vocab))
+        z.writestr("tokenizer/merges.txt", "#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n")
+        z.writestr("tokenizer_2/tokenizer.json", tk.to_str())
+    pipe = d.Pipeline(d.ModelSource.DdufFile(path))
+    assert pipe.load_stats["bnb4"] == nq and pipe.t5 is not None and pipe.t5.load_stats["bnb4"] == nqt
+    prompts = ["the cat sat on a mat", "a dog ran"]
+    params = d.DiffusionGenerationParams(height=128, width=128, num_steps=3, guidance_scale=3.5)
+    lat = np.random.default_rng(9).standard_normal((2, 16, 16, 16)).astype(np.float32)
+    u8 = pipe.forward(prompts, params, latents=dev(lat), output="tensor")
+    t5_ids = np.array(d.tokenize_and_pad(prompts, pipe.t5_tokenizer), np.int32)
+    clip_ids = np.array(d.tokenize_and_pad(prompts, pipe.clip_tokenizer), np.int32)
+    ot, oc = orc.T5(t5_cfg), orc.Clip(clip_cfg)
+    ot.load(tdense)
+    oc.load(csd)
+    t5_emb, clip_emb = ot.forward(t5_ids), oc.forward(clip_ids)
+    g_t5, _ = pipe.encode_prompts(prompts)
+    e_t5 = rel_l2(host(g_t5.float()), t5_emb)
+    ref_u8, _ = _oracle_pipeline_cfg(fdense, vsd, lat, t5_emb, clip_emb, 3, 3.5, pipe.scheduler)
+    diff = np.abs(u8.cpu().numpy().astype(np.int32) - ref_u8.astype(np.int32))
+    print(f"Q4-bnb DDUF, nf4 transformer ({nq} linears) + nf4 T5 ({nqt} linears): T5 embeddings rel-L2 {e_t5:.3e}; prompt -> u8 max |d| {diff.max()}, "
+          f"frac<=2 {float((diff <= 2).mean()):.4f}")
+    assert e_t5 <= 1.2e-2 and float((diff <= 2).mean()) >= 0.99

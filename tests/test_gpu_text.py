@@ -124,3 +124,49 @@ def test_full_size_encoders_run_and_feed_flux_shapes():
     p = clip.forward(cid)
     torch.cuda.synchronize()
     assert p.shape == (2, 768) and p.dtype == torch.float32 and torch.isfinite(p).all()
+
+
+def test_t5_quantised_linears_match_oracle_on_dequantised_weights():
+    """A bitsandbytes-quantised T5 (the reference builds every T5 Linear as a QuantMethod, t5/mod.rs:132-173,258-261): nf4, fp4
+    and LLM.int8 Linears fed through fmi_t5_set_linear_bnb4 / _int8 give the encoder output of the oracle run on the dequantised
+    weights (BnbLinear::forward = dequantise + matmul, bitsandbytes/mod.rs:293-312), and exactly the output of the same encoder
+    loaded with those dequantised weights as bf16 (the expansion is the library's bit-exact dequant)."""
+    import torch
+    import diffusion_rs_amd as d
+    from diffusion_rs_amd import text
+    from oracle import oracle as orc
+    cfg = dict(vocab_size=96, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2, relative_attention_num_buckets=32,
+               relative_attention_max_distance=128, layer_norm_epsilon=1e-6, feed_forward_proj="gated-gelu")
+    sd = d.synth.text_state_dict_numpy(d.synth.t5_tensor_shapes(cfg), seed=21)
+    ids = np.random.default_rng(3).integers(0, 96, (2, 40)).astype(np.int32)
+    for kind in ("nf4", "fp4", "int8"):
+        gq, gd = text.T5EncoderModel(dict(cfg, quantization_config={"quant_method": "bitsandbytes"})), text.T5EncoderModel(cfg)
+        dense = {}
+        for name, w in sd.items():
+            lin = w.ndim == 2 and ("SelfAttention." in name or "DenseReluDense." in name) and "relative_attention_bias" not in name
+            if not lin:
+                gq.set_tensor(name, w)
+                dense[name] = w
+                continue
+            prefix = name[:-len(".weight")]
+            if kind == "int8":
+                scb = np.abs(w).max(1).astype(np.float32)
+                q = np.clip(np.rint(w / scb[:, None] * 127.0), -127, 127).astype(np.int8)
+                gq.set_linear_int8(prefix, torch.from_numpy(q), torch.from_numpy(scb), w.shape[0], w.shape[1])
+                dense[name] = orc.dequantize_8bit(q, scb, w.shape[0], w.shape[1], "bf16").reshape(w.shape)
+            else:
+                packed, absmax = orc.quantize_blockwise_4bit(w.ravel(), 64, kind)
+                gq.set_linear_bnb4(prefix, torch.from_numpy(packed), torch.from_numpy(absmax), 64, kind, w.shape[0], w.shape[1])
+                dense[name] = orc.dequantize_blockwise(None, packed, absmax, 64, w.size, kind, "bf16").reshape(w.shape)
+        assert gq.missing() == []
+        gd.load_state_dict(dense)
+        om = orc.T5(cfg)
+        om.load(dense)
+        a, b = host(gq.forward(ids, dtype=torch.float32)), host(gd.forward(ids, dtype=torch.float32))
+        err = rel_l2(a, om.forward(ids))
+        print(f"T5 with {kind} Linears: rel-L2 vs oracle on the dequantised weights {err:.3e}; identical to the bf16 load of them: {np.array_equal(a, b)}")
+        assert np.array_equal(a, b) and err <= 1e-2
+        with pytest.raises(d.FmiError):
+            gq.set_linear_bnb4("encoder.final_layer_norm", torch.zeros(64, dtype=torch.uint8), torch.zeros(2), 64, "nf4", 128, 1)
+        gq.close()
+        gd.close()
