@@ -566,10 +566,11 @@ static std::atomic<bool> g_att_w16{[] {
   return e ? atoi(e) != 0 : true;
 }()};
 void set_attention_w16(bool on) { g_att_w16 = on; }
-// the same design on the 32x32x16 MFMA (attention_w32.h): FMI_ATT_W32=0 / set_attention_w32(false) -> the selection above
+// the same design on the 32x32x16 MFMA (attention_w32.h), bit-identical to attention_w16: off by default (in the denoise loop the
+// 16x16x32 form measured 13.17 vs 13.32 ms of attention per step, profiles/r03_attention_ab.txt); FMI_ATT_W32=1 / set_attention_w32(true)
 static std::atomic<bool> g_att_w32{[] {
   const char* e = getenv("FMI_ATT_W32");
-  return e ? atoi(e) != 0 : true;
+  return e ? atoi(e) != 0 : false;
 }()};
 void set_attention_w32(bool on) { g_att_w32 = on; }
 

@@ -21,6 +21,8 @@
 #include <cstring>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "common.h"
 
 using namespace fmi;
@@ -692,11 +694,36 @@ int attention_sp(fmi_flux* m, const AttnOut& out, int Tl, int Sl, float scale, h
   return launch_sp_unpack_o(m->sp_recv, out, H, Ll, N, s);
 }
 
+// roctx ranges around the phases (rocprofv3 --marker-trace groups the kernel trace by them): FMI_ROCTX=1 in the environment.
+// The marker library is opened at run time (librocprofiler-sdk-roctx.so.1, else libroctx64.so.4): no link-time dependency, and
+// nothing happens — not even the dlopen — unless the variable is set.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = getenv("FMI_ROCTX");
+    if (!e || !atoi(e)) return;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"}) {
+      if (void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+        push = nullptr, pop = nullptr;
+      }
+    }
+  }
+};
+const Roctx& roctx() {
+  static const Roctx r;
+  return r;
+}
+
 struct PhaseTimer {
   fmi_flux* m;
   hipStream_t s;
   int ph;
   PhaseTimer(fmi_flux* m_, hipStream_t s_, int ph_) : m(m_), s(s_), ph(ph_) {
+    if (roctx().push) roctx().push(kPhaseNames[ph]);
     if (m->profiling) hipEventRecord(m->ev0, s);
   }
   ~PhaseTimer() {
@@ -707,6 +734,7 @@ struct PhaseTimer {
       hipEventElapsedTime(&ms, m->ev0, m->ev1);
       m->phase_ms[ph] += ms;
     }
+    if (roctx().pop) roctx().pop();
   }
 };
 

@@ -257,7 +257,9 @@ int fmi_flux_denoise(fmi_flux*, const fmi_flux_inputs* in, float* img_inout,
                      const double* timesteps_host, int n_steps, void* stream);
 
 /* Per-phase device time of the last forward in ms (hipEvents; enabled by
- * fmi_flux_set_profiling(1), which also serialises phases).  Phases: see fmi_flux_phase_name. */
+ * fmi_flux_set_profiling(1), which also serialises phases).  Phases: see fmi_flux_phase_name.
+ * With FMI_ROCTX=1 in the environment every phase is also a roctx range (roctxRangePushA / Pop from
+ * librocprofiler-sdk-roctx, opened at run time), so `rocprofv3 --marker-trace --kernel-trace` groups the trace by phase. */
 int fmi_flux_set_profiling(fmi_flux*, int enable);
 /* Tuning / verification knob (default 1): QkNorm (model.rs:433-452) + apply_rope (:77-101) + the
  * head-major q,k and transposed v relayout run in the epilogue of the [q|k|v] projection GEMM

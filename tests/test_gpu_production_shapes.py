@@ -140,6 +140,20 @@ def test_c1_schnell_full_width_full_depth_matches_oracle():
     txt_ids = np.zeros((B, T, 3), np.float32)
     ts = orc.get_timesteps(4, False, 0.0, 1.0)  # schnell: no dynamic shifting, shift = 1.0 (scheduler.rs:22-51)
     got = host(gm.denoise(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(clip), None, ts))
+    # With 4 steps the modulation precompute takes the f32 GEMV passes (<= 4 rows).  The path the 50-step runs take — ONE GEMM
+    # over the 6.5 GB (344 D x D) modulation matrix for all steps' rows — is checked against those passes here at the full
+    # model (12 steps): same weights, bf16 vs f32 silu(vec) input, so rounding-level agreement; round 3 found the GEMM reading
+    # the rows beyond 4 GiB (single blocks, final layer) from a wrapped offset — an O(1) difference this comparison catches.
+    from diffusion_rs_amd import _lib as L
+    ts12 = orc.get_timesteps(12, False, 0.0, 1.0)
+    args12 = (dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(clip), None, ts12)
+    L.check(gm.lib.fmi_flux_set_modulation_gemm(gm.h, 0))
+    a12 = host(gm.denoise(*args12))
+    L.check(gm.lib.fmi_flux_set_modulation_gemm(gm.h, 1))
+    b12 = host(gm.denoise(*args12))
+    e12 = rel_l2(b12, a12)
+    print(f"12-step denoise at full size, modulation as one GEMM vs f32 GEMV passes: rel-L2 {e12:.3e}")
+    assert e12 <= 5e-3
     gm.close()
     torch.cuda.empty_cache()
     t0 = time.time()
