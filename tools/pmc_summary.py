@@ -2,7 +2,10 @@
 """Builds profiles/pmc_summary_latest.json (read by bench.py for roofline.traffic) from the two
 per-counter summaries tools/profile_round.sh writes.
 
-    tools/pmc_summary.py <tag> <fetch_size.txt> <write_size.txt> <denoise steps of the pmc pass> [kernel regex]
+    tools/pmc_summary.py <tag> <fetch_size.txt> <write_size.txt> <denoise steps of the pmc pass> [kernel regex] [mode]
+
+mode (default "latest" = the bf16 headline run) names the output: profiles/pmc_summary_<mode>.json; bench.py's secondary legs
+read pmc_summary_nf4.json / pmc_summary_fp8.json the same way.
 
 Traffic per launch = FETCH_SIZE x 2 + WRITE_SIZE (KiB as reported -> bytes), averaged over the
 block-linear GEMM kernels weighted by dispatch count.  The x2 on FETCH_SIZE is the gfx950
@@ -29,7 +32,8 @@ def rows(path, rx):
 
 def main():
     tag, fpath, wpath, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-    rx = re.compile(sys.argv[5] if len(sys.argv) > 5 else r"fmi::gemm_(pp|w4|w4q)_kernel<(false|0|1|2|3)")
+    rx = re.compile(sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] else r"fmi::gemm_(pp|w4|w4q)_kernel<(false|true|0|1|2|3)")
+    mode = sys.argv[6] if len(sys.argv) > 6 else "latest"
     f, w = rows(fpath, rx), rows(wpath, rx)
     nf, nw = sum(c for _, c, _ in f), sum(c for _, c, _ in w)
     fa = sum(c * a for _, c, a in f) / max(nf, 1)
@@ -47,7 +51,8 @@ def main():
         "traffic_bytes_per_launch": int((2 * fa + wa) * 1024),
         "note": "L2-miss side traffic (Infinity-Cache hits included); the QKV launches also write the head-major q/k and transposed v buffers from their epilogue",
     }
-    path = os.path.join(ROOT, "profiles", "pmc_summary_latest.json")
+    out["mode"] = mode
+    path = os.path.join(ROOT, "profiles", f"pmc_summary_{mode}.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
         fh.write("\n")

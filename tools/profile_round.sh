@@ -3,7 +3,7 @@
 #   tools/profile_round.sh <tag>        e.g. r01c      (BENCH_ARGS="--quant fp8" adds bench flags to every pass)
 # 1. kernel trace + stats of the default bench command (whole 50-step image, no CPU baseline)
 # 2./3. FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (PMC_STEPS denoise steps, default 10), never combined with traces
-# 4. without BENCH_ARGS (the headline bf16 run): profiles/pmc_summary_latest.json rebuilt from 2./3. (tools/pmc_summary.py)
+# 4. profiles/pmc_summary_<mode>.json rebuilt from 2./3. (tools/pmc_summary.py; mode = latest for the bf16 headline run, nf4, fp8)
 set -e
 TAG=${1:-r02x}
 PMC_STEPS=${PMC_STEPS:-10}
@@ -22,7 +22,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   DB=$(find "$OUT/pmc_$C" -name "*.db" | head -1)
   python profiles/summarize_rocpd.py pmc "$DB" $C > "$OUT/${TAG}_pmc_$(echo $C | tr A-Z a-z).txt"
 done
-[ -n "$BENCH_ARGS" ] || { python tools/pmc_summary.py "$TAG" "$OUT/${TAG}_pmc_fetch_size.txt" "$OUT/${TAG}_pmc_write_size.txt" "$PMC_STEPS" > /dev/null; cp profiles/pmc_summary_latest.json "$OUT/pmc_summary_latest.json"; }
+# traffic per block-linear launch of this mode -> profiles/pmc_summary_<mode>.json (bench.py reads it: roofline.traffic of the line / of the leg)
+MODE=latest
+case "$BENCH_ARGS" in *"--quant nf4"*) MODE=nf4 ;; *"--quant fp8"*) MODE=fp8 ;; esac
+python tools/pmc_summary.py "$TAG" "$OUT/${TAG}_pmc_fetch_size.txt" "$OUT/${TAG}_pmc_write_size.txt" "$PMC_STEPS" "" $MODE > /dev/null; cp profiles/pmc_summary_$MODE.json "$OUT/pmc_summary_$MODE.json"
 tail -1 "$OUT/bench_under_rocprof.json" > "$OUT/${TAG}_bench_under_rocprof.json"
 head -12 "$OUT/${TAG}_kernel_stats.txt"
 head -6 "$OUT/${TAG}_pmc_fetch_size.txt"
