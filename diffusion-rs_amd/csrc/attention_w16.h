@@ -24,12 +24,20 @@
 #define FMI_AW16_LOOP_INC "attention_w16_loop.inc"
 #endif
 #include FMI_AW16_LOOP_INC
+#ifndef FMI_AW16F8_LOOP_INC  // the fp8-QK^T stream (AW16_MODE=fp8qk of the same generator)
+#define FMI_AW16F8_LOOP_INC "attention_w16f8_loop.inc"
+#endif
+#include FMI_AW16F8_LOOP_INC
 
 namespace fmi {
 
 constexpr int AW16_THREADS = 256;
 
-template <int THR_X16>
+// QK8 = true (the model's fp8 mode): Q and K point to OCP e4m3 bytes, rows of 128 B, with their static scales folded
+// into scale_log2e, which the launcher guarantees to be an exact power of two 2^-n (the host picks the q scale accordingly): the
+// score product is one v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile whose E8M0 block scale carries 2^-n.  P, V^T and the
+// second product are the bf16 ones.
+template <int THR_X16, bool QK8 = false>
 __global__ __launch_bounds__(AW16_THREADS, 1) void attention_w16_kernel(const bf16_t* __restrict Q, const bf16_t* __restrict K, const bf16_t* __restrict Vt,
                                                                         AttnOut out, int H, int Lq, int Lk, int Lkpad, float scale_log2e) {
   constexpr int TILE = 16384, VT_RING = 4 * TILE;
@@ -43,7 +51,8 @@ __global__ __launch_bounds__(AW16_THREADS, 1) void attention_w16_kernel(const bf
   const int b_ = bh / H, h = bh % H;
   const int q0 = (lid % nqb) * ATT_QBLK + wave * 64;
   const int g = lane >> 4, n16 = lane & 15;
-  const bf16_t* Kb = K + (int64_t)bh * Lk * HD;
+  constexpr int KROW = QK8 ? 128 : 256, TILE_K = 64 * KROW;  // bytes of a K row / of a K tile (HBM and LDS)
+  const char* Kb = reinterpret_cast<const char*>(K) + (int64_t)bh * Lk * KROW;
   const bf16_t* Vb = Vt + (int64_t)bh * HD * Lkpad;
   const int ntiles = (Lk + ATT_KV - 1) / ATT_KV;  // >= 2 (the launcher sends single-tile problems to the 8-wave kernel)
 
@@ -53,22 +62,33 @@ __global__ __launch_bounds__(AW16_THREADS, 1) void attention_w16_kernel(const bf
   typedef int i32x16 __attribute__((ext_vector_type(16)));
   typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-  // ---- Q fragments (MFMA B operand, rows = d): QF[b][c][s] = bf16(Q[q0 + 32 b + 16 c + n][32 s + 8 g .. + 7] * scale * log2(e))
+  // ---- Q fragments (MFMA B operand, rows = d): QF[b][c][s] = bf16(Q[q0 + 32 b + 16 c + n][32 s + 8 g .. + 7] * scale * log2(e));
+  // fp8: QF8[b][c] = the 32 bytes Q8[q][32 g .. + 31] as they are (the scale rides in the MFMA's block scale)
   i32x32 QA[2];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) QA[1][r] = 0;
 #pragma unroll
   for (int b = 0; b < 2; ++b)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int qr = min(q0 + 32 * b + 16 * c + n16, Lq - 1);
-      const bf16_t* qp = Q + ((int64_t)bh * Lq + qr) * HD + 8 * g;
+      if constexpr (QK8) {
+        const char* qp = reinterpret_cast<const char*>(Q) + ((int64_t)bh * Lq + qr) * 128 + 32 * g;
+        const uint4 lo = *reinterpret_cast<const uint4*>(qp), hi = *reinterpret_cast<const uint4*>(qp + 16);
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(qp + 32 * s);
-        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+        for (int e = 0; e < 8; ++e) QA[0][(2 * b + c) * 8 + e] = (int)w[e];
+      } else {
+        const bf16_t* qp = Q + ((int64_t)bh * Lq + qr) * HD + 8 * g;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float lo = __uint_as_float(w[e] << 16) * scale_log2e, hi = __uint_as_float(w[e] & 0xffff0000u) * scale_log2e;
-          QA[b][(c * 4 + s) * 4 + e] = (int)pack_bf16x2(lo, hi);
+        for (int s = 0; s < 4; ++s) {
+          const uint4 raw = *reinterpret_cast<const uint4*>(qp + 32 * s);
+          const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(w[e] << 16) * scale_log2e, hi = __uint_as_float(w[e] & 0xffff0000u) * scale_log2e;
+            QA[b][(c * 4 + s) * 4 + e] = (int)pack_bf16x2(lo, hi);
+          }
         }
       }
     }
@@ -80,19 +100,27 @@ __global__ __launch_bounds__(AW16_THREADS, 1) void attention_w16_kernel(const bf
   frag_t R3;  // the ones fragment: A operand whose row 0 is bf16 1.0 (V^T extended by a row of ones -> the row sums)
   const int k_last_rows = Lk - (ntiles - 1) * ATT_KV;  // keys in the last tile (1..64): rows beyond are fetched from the last key
   uint32_t k_voff[4], v_voff[4], k_voffc[4];
+  constexpr int KP = QK8 ? 2 : 4;  // 1-KiB DMA pieces of a K tile per wave
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int chunk = wave * 4 + i;
-    const int kr = chunk * 4 + (lane >> 4), vr = chunk * 8 + (lane >> 3);
-    const int fk = (kr & 7) | (((kr >> 4) & 1) << 3);
-    k_voff[i] = (uint32_t)(kr * 256 + (((lane & 15) ^ fk) << 4));
-    k_voffc[i] = kr >= k_last_rows ? (uint32_t)((k_last_rows - 1) * 256 + (((lane & 15) ^ fk) << 4)) : k_voff[i];
+    const int vr = (wave * 4 + i) * 8 + (lane >> 3);
     v_voff[i] = (uint32_t)(vr * Lkpad * 2 + (((lane & 7) ^ ((vr >> 1) & 7)) << 4));
+    if constexpr (QK8) {  // piece = 8 rows of 128 B; slot p of row r holds global slot p ^ f8(r)
+      const int kr = (wave * 2 + (i & 1)) * 8 + (lane >> 3);
+      const int fk = ((kr & 7) >> 1) | (((kr >> 4) & 1) << 2);
+      k_voff[i] = (uint32_t)(kr * 128 + (((lane & 7) ^ fk) << 4));
+      k_voffc[i] = kr >= k_last_rows ? (uint32_t)((k_last_rows - 1) * 128 + (((lane & 7) ^ fk) << 4)) : k_voff[i];
+    } else {      // piece = 4 rows of 256 B; slot p of row r holds global slot p ^ f(r)
+      const int kr = (wave * 4 + i) * 4 + (lane >> 4);
+      const int fk = (kr & 7) | (((kr >> 4) & 1) << 3);
+      k_voff[i] = (uint32_t)(kr * 256 + (((lane & 15) ^ fk) << 4));
+      k_voffc[i] = kr >= k_last_rows ? (uint32_t)((k_last_rows - 1) * 256 + (((lane & 15) ^ fk) << 4)) : k_voff[i];
+    }
   }
   auto stage_k = [&](int tile, int i) __attribute__((always_inline)) {
-    const char* base = reinterpret_cast<const char*>(Kb) + (int64_t)tile * (ATT_KV * 256);
+    const char* base = Kb + (int64_t)tile * TILE_K;
     const uint32_t off = (tile == ntiles - 1) ? k_voffc[i] : k_voff[i];
-    __builtin_amdgcn_global_load_lds((glb_void*)(base + off), (lds_void*)(smem + (tile & 3) * TILE + (wave * 4 + i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + off), (lds_void*)(smem + (tile & 3) * TILE_K + (wave * KP + i) * 1024), 16, 0, 0);
   };
   auto stage_v = [&](int tile, int i) __attribute__((always_inline)) {
     const char* base = reinterpret_cast<const char*>(Vb) + (int64_t)tile * (ATT_KV * 2);
@@ -105,8 +133,15 @@ __global__ __launch_bounds__(AW16_THREADS, 1) void attention_w16_kernel(const bf
   // immediate offset.  V^T fragment (d block dt, k-step kk): row 16 dt + m, slot 4 kk + g, at VAD[kk] + 2048 dt.
   {
     const int m = n16, krow = (m & 7) + 16 * (m >> 3);
+    if constexpr (QK8) {  // fp8 K fragment (key block a): the row's bytes 32 g .. + 31 = global slots 2 g, 2 g + 1; f8(row) = ((m & 7) >> 1) | (m >> 3) << 2
+      const int f8 = ((m & 7) >> 1) | ((m >> 3) << 2);
+      R0[0] = krow * 128 + (((2 * g) ^ f8) << 4);
+      R0[1] = R0[0] ^ 16;
+      R0[2] = R0[3] = 0;
+    } else {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) R0[s] = krow * 256 + (((4 * s + g) ^ m) << 4);
+      for (int s = 0; s < 4; ++s) R0[s] = krow * 256 + (((4 * s + g) ^ m) << 4);
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) R0[4 + kk] = VT_RING + m * 128 + (((4 * kk + g) ^ ((m >> 1) & 7)) << 4);
 #pragma unroll
@@ -128,7 +163,7 @@ __global__ __launch_bounds__(AW16_THREADS, 1) void attention_w16_kernel(const bf
   for (int t = 0; t < 3; ++t)
     if (t < ntiles) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) stage_k(t, i);
+      for (int i = 0; i < KP; ++i) stage_k(t, i);
     }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -151,6 +186,9 @@ __global__ __launch_bounds__(AW16_THREADS, 1) void attention_w16_kernel(const bf
     FP[r] = 0;
   }
   i32x32 FB = FP;
+  frag_t R4;  // fp8: E8M0 block scales of the score product (byte = biased exponent): 2^-n on the K side, 1 on the Q side
+  R4[0] = (int)(((__float_as_uint(scale_log2e) >> 23) & 0xffu) * 0x01010101u), R4[1] = 0x7f7f7f7f, R4[2] = R4[3] = 0;
+  i32x32 KF = FP;  // fp8 mode: the four 32-byte K fragment buffers (a[208:239]); named here so that the registers belong to the kernel
   f32x16 OL;  // ones-row accumulators: OL[(2 b + c) * 4] in lanes 0..15 = the row sum of query 32 b + 16 c + n
 #pragma unroll
   for (int r = 0; r < 16; ++r) OL[r] = 0.f;
@@ -159,14 +197,18 @@ __global__ __launch_bounds__(AW16_THREADS, 1) void attention_w16_kernel(const bf
     const uint32_t kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)kb64), kb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(kb64 >> 32));
     const uint32_t vb_lo = __builtin_amdgcn_readfirstlane((uint32_t)vb64), vb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(vb64 >> 32));
     const float thr = (float)THR_X16 * 0.0625f;
-    asm volatile(FMI_AW16_LOOP_ASM
-                 : "+{a[0:31]}"(O[0]), "+{a[32:63]}"(O[1]), "+{a[64:95]}"(O[2]), "+{a[96:127]}"(O[3]), "+{v[0:31]}"(SP0), "+{v[32:63]}"(SP1),
-                   "+{v[64:95]}"(FP), "+{v[96:127]}"(FB), "+{v[128:143]}"(R0), "+{v[144:159]}"(R1), "+{v[160:167]}"(R2), "+{v[168:171]}"(R3), "+{a[192:207]}"(OL)
-                 : "{a[128:159]}"(QA[0]), "{a[160:191]}"(QA[1]), [kb_lo] "s"(kb_lo), [kb_hi] "s"(kb_hi), [vb_lo] "s"(vb_lo), [vb_hi] "s"(vb_hi),
-                   [ntm1] "s"(ntiles - 1), [thr] "s"(thr), [woff] "s"(wave * 4096), [rag] "s"(k_last_rows)
-                 : "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201",
-                   "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "s80", "s81",
-                   "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "vcc", "scc", "memory");
+#define FMI_AW16_OPERANDS                                                                                                                      \
+    : "+{a[0:31]}"(O[0]), "+{a[32:63]}"(O[1]), "+{a[64:95]}"(O[2]), "+{a[96:127]}"(O[3]), "+{v[0:31]}"(SP0), "+{v[32:63]}"(SP1), "+{v[64:95]}"(FP), \
+      "+{v[96:127]}"(FB), "+{v[128:143]}"(R0), "+{v[144:159]}"(R1), "+{v[160:167]}"(R2), "+{v[168:171]}"(R3), "+{v[172:175]}"(R4),               \
+      "+{a[192:207]}"(OL), "+{a[208:239]}"(KF)                                                                                                       \
+    : "{a[128:159]}"(QA[0]), "{a[160:191]}"(QA[1]), [kb_lo] "s"(kb_lo), [kb_hi] "s"(kb_hi), [vb_lo] "s"(vb_lo), [vb_hi] "s"(vb_hi),                \
+      [ntm1] "s"(ntiles - 1), [thr] "s"(thr), [woffk] "s"(wave * KP * 1024), [woffv] "s"(VT_RING + wave * 4096), [rag] "s"(k_last_rows)             \
+    : "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201",  \
+      "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "s80", "s81", "s82", "s83", "s84", "s85",      \
+      "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "vcc", "scc", "memory"
+    if constexpr (QK8) asm volatile(FMI_AW16F8_LOOP_ASM FMI_AW16_OPERANDS);
+    else asm volatile(FMI_AW16_LOOP_ASM FMI_AW16_OPERANDS);
+#undef FMI_AW16_OPERANDS
   }
 
   // ---- epilogue.  Lane (g, n) holds O^T[d = 16 dt + 4 g + i][query 32 b + 16 c + n] in O[..][((8 b + dt) * 2 + c) * 4 + i] and its

@@ -1454,6 +1454,15 @@ extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) {
       return FMI_OK;
     };
     auto scale_of = [](float mx) { return 448.0f / (11.3137085f * std::max(mx, 1e-20f)); };  // sqrt(128)
+    // The q scale is then lowered (by less than a factor 2: e4m3 keeps its relative precision) to the value that makes the
+    // attention's score factor softmax_scale * log2(e) / (sq * sk) an exact power of two 2^-n: the one-wave fp8 attention
+    // (attention_w16.h, QK8) folds it into the E8M0 block scale of its score MFMA.  The oracle applies the same rule
+    // (flux_oracle.cpp: fp8_q_scale_pow2).
+    auto q_scale_pow2 = [](float q8, float k8) {
+      const float c0 = (1.0f / sqrtf(128.0f)) * 1.4426950408889634f;
+      const int n = (int)floorf(log2f(q8 * k8 / c0));
+      return c0 * ldexpf(1.0f, n) / k8;
+    };
     m->q8_dbl.assign(m->dbl.size(), 0.f), m->k8_dbl.assign(m->dbl.size(), 0.f);
     m->q8_sgl.assign(m->sgl.size(), 0.f), m->k8_sgl.assign(m->sgl.size(), 0.f);
     for (size_t i = 0; i < m->dbl.size(); ++i) {
@@ -1462,14 +1471,15 @@ extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) {
       FMI_TRY(wmax(m->dbl[i].nq[1], &b));
       FMI_TRY(wmax(m->dbl[i].nk[0], &c));
       FMI_TRY(wmax(m->dbl[i].nk[1], &d));
-      m->q8_dbl[i] = scale_of(std::max(a, b));  // both streams feed one attention call: one scale
-      m->k8_dbl[i] = scale_of(std::max(c, d));
+      m->k8_dbl[i] = scale_of(std::max(c, d));  // both streams feed one attention call: one scale
+      m->q8_dbl[i] = q_scale_pow2(scale_of(std::max(a, b)), m->k8_dbl[i]);
     }
     for (size_t i = 0; i < m->sgl.size(); ++i) {
       float a, c;
       FMI_TRY(wmax(m->sgl[i].nq, &a));
       FMI_TRY(wmax(m->sgl[i].nk, &c));
-      m->q8_sgl[i] = scale_of(a), m->k8_sgl[i] = scale_of(c);
+      m->k8_sgl[i] = scale_of(c);
+      m->q8_sgl[i] = q_scale_pow2(scale_of(a), m->k8_sgl[i]);
     }
   }
   if (m->ws.base) {  // the fp8 workspace has two more buffers: rebuild on the next call

@@ -836,6 +836,14 @@ void add_gated(float* x, const float* gate, const float* y, int rows, int D) {
 }
 }  // namespace
 
+// The q scale of the fp8 attention is lowered (by less than a factor 2) to the value that makes the score factor
+// softmax_scale * log2(e) / (sq * sk) an exact power of two — the library folds that factor into the block scale of its fp8 score
+// MFMA (attention_w16.h).  Our recipe (no reference counterpart); the same float arithmetic as flux_model.hip: q_scale_pow2.
+static float fp8_q_scale_pow2(float q8, float k8, int d) {
+  const float c0 = (1.0f / sqrtf((float)d)) * 1.4426950408889634f;
+  const int n = (int)floorf(log2f(q8 * k8 / c0));
+  return c0 * ldexpf(1.0f, n) / k8;
+}
 static float fp8_attn_scale(const orc_flux* m, const std::string& a, const std::string& b, int d) {
   float mx = 0.f;
   for (const std::string& n : {a, b}) {
@@ -865,8 +873,8 @@ static int double_block_one(orc_flux* m, int idx, float* img, float* txt, const 
   std::vector<float> attn((size_t)L * D);
   float q8 = 0.f, k8 = 0.f;
   if (m->fp8 && m->fp8_attn) {
-    q8 = fp8_attn_scale(m, p + "attn.norm_q", p + "attn.norm_added_q", d);
     k8 = fp8_attn_scale(m, p + "attn.norm_k", p + "attn.norm_added_k", d);
+    q8 = fp8_q_scale_pow2(fp8_attn_scale(m, p + "attn.norm_q", p + "attn.norm_added_q", d), k8, d);
   }
   attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8);
   const float* txt_attn = attn.data();
@@ -914,8 +922,8 @@ static int single_block_one(orc_flux* m, int idx, float* x, const float* vec, co
   lin_blk(m, pm, xm.data(), L, mlp.data());
   float q8 = 0.f, k8 = 0.f;
   if (m->fp8 && m->fp8_attn) {
-    q8 = fp8_attn_scale(m, p + "attn.norm_q", "", d);
     k8 = fp8_attn_scale(m, p + "attn.norm_k", "", d);
+    q8 = fp8_q_scale_pow2(fp8_attn_scale(m, p + "attn.norm_q", "", d), k8, d);
   }
   attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8);
   orc_gelu(mlp.data(), (int64_t)L * M, mlp.data());

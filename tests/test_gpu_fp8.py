@@ -292,23 +292,34 @@ def test_fp8_attention_toggle(env, models):
     assert not np.array_equal(on, off)
 
 
-@pytest.mark.parametrize("B,H,L", [(1, 2, 64), (2, 3, 200), (1, 2, 333), (1, 24, 4608), (2, 24, 4112)])
-def test_sdpa_fp8qk_equals_bf16_sdpa_on_the_same_codes(env, B, H, L):
+@pytest.mark.parametrize("pow2", [False, True])
+@pytest.mark.parametrize("B,H,L", [(1, 2, 64), (2, 3, 200), (1, 2, 96), (1, 2, 333), (1, 24, 4608), (2, 24, 4112)])
+def test_sdpa_fp8qk_equals_bf16_sdpa_on_the_same_codes(env, B, H, L, pow2):
     """QK^T on the fp8 MFMA vs the bf16 attention kernel fed the dequantised codes (e4m3 values are exact in bf16, the
-    products exact in both): only the accumulation order of the 128-long dot products differs, far below the softmax's
-    sensitivity.  The last two shapes are BASELINE's C2 and C5 attention shapes.  The bf16 kernel itself is pinned to
-    the oracle in tests/test_gpu_ops.py."""
+    products exact in both): the accumulation order of the 128-long dot products differs, and the bf16 kernel rounds
+    q * scale * log2(e) to bf16 once — both far below the softmax's sensitivity.  pow2 = True takes the one-wave generated
+    stream (attention_w16 QK8: the score factor is a power of two and rides in the MFMA's block scale — what the model's fp8
+    mode runs), pow2 = False the 8-wave kernel (any factor).  The last two shapes are BASELINE's C2 and C5 attention shapes.
+    The bf16 kernel itself is pinned to the oracle in tests/test_gpu_ops.py."""
     torch, L_, lib = env["torch"], env["L"], env["lib"]
     g = torch.Generator(device="cuda").manual_seed(B * 1000 + L)
     q = torch.randn(B, H, L, 128, device="cuda", generator=g)
     k = torch.randn(B, H, L, 128, device="cuda", generator=g)
     v = torch.randn(B, H, L, 128, device="cuda", generator=g).to(torch.bfloat16)
-    QS = KS = 448.0 / (128 ** 0.5 * 1.5)
+    KS = 448.0 / (128 ** 0.5 * 1.5)
+    QS = KS
+    if pow2:  # the q scale the model's fp8 mode picks: softmax_scale * log2(e) / (QS * KS) an exact power of two -> the one-wave stream
+        c0 = np.float32(1.0 / 128 ** 0.5) * np.float32(1.4426950408889634)
+        n = int(np.floor(np.log2(np.float32(QS * KS) / c0)))
+        QS = float(c0 * np.float32(2.0 ** n) / np.float32(KS))
     q8 = (q * QS).clamp(-448, 448).to(torch.float8_e4m3fn)
     k8 = (k * KS).clamp(-448, 448).to(torch.float8_e4m3fn)
     qd, kd = q8.to(torch.bfloat16), k8.to(torch.bfloat16)
     assert torch.equal(qd.float(), q8.float())
     scale = (1.0 / 128 ** 0.5) / (QS * KS)
+    if pow2:
+        sl = np.float32(scale) * np.float32(1.4426950408889634)
+        assert abs(float(sl) / 2.0 ** round(np.log2(float(sl))) - 1.0) < 2e-7  # the launcher's test for the one-wave stream
     o8 = torch.empty(B, L, H * 128, device="cuda", dtype=torch.bfloat16)
     ob = torch.empty_like(o8)
     L_.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o8), B, H, L, L, 128, scale, 1, None))
@@ -317,7 +328,7 @@ def test_sdpa_fp8qk_equals_bf16_sdpa_on_the_same_codes(env, B, H, L):
     assert torch.isfinite(o8.float()).all()
     diff = (o8.float() - ob.float()).abs()
     rel = float((o8.float() - ob.float()).norm() / ob.float().norm())
-    print(f"sdpa fp8-QK vs bf16 on the same codes B={B} H={H} L={L}: rel-L2 {rel:.2e}, max |d| {float(diff.max()):.3e}")
+    print(f"sdpa fp8-QK ({'one-wave' if pow2 and L > 64 else '8-wave'}) vs bf16 on the same codes B={B} H={H} L={L}: rel-L2 {rel:.2e}, max |d| {float(diff.max()):.3e}")
     assert rel <= 3e-3 and float(diff.max()) <= 0.05
     # run-to-run determinism (hand-placed waitcnts)
     o8b = torch.empty_like(o8)

@@ -128,6 +128,12 @@ def test_attention_and_gemm_reproduce_their_idle_results_while_another_process_u
         L.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o), 1, H, Lq, Lq, 128, 1e-5, 1, None))
         return o
     cases.append(("sdpa fp8 QK", run_fp8_attn))
+
+    def run_fp8_attn_onewave(q8=q8, k8=k8, v=v, H=H, Lq=Lq):  # a power-of-two score factor: the one-wave generated stream (attention_w16 QK8)
+        o = torch.full((1, Lq, H * 128), float("nan"), dtype=torch.bfloat16, device="cuda")
+        L.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o), 1, H, Lq, Lq, 128, 2.0 ** -17 / 1.4426950408889634, 1, None))
+        return o
+    cases.append(("sdpa fp8 QK one-wave", run_fp8_attn_onewave))
     try:
         idle = []
         for name, run in cases:

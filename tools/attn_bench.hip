@@ -26,8 +26,69 @@ __global__ void fill_kernel(bf16_t* p, size_t n, uint32_t seed) {
   }
 }
 
+__global__ void fill_e4m3_kernel(uint8_t* p, size_t n, uint32_t seed) {  // random e4m3 codes of moderate magnitude (|x| <= 4), no NaN codes
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t x = (uint32_t)i * 2654435761u ^ seed;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+    p[i] = (uint8_t)((x & 0x80u) | (x >> 8) % 0x48u);
+  }
+}
+
+// fp8-QK^T attention (the model's fp8 mode): the one-wave stream (attention_w16 QK8) against the 8-wave fp8 kernel
+static void fp8_section(int iters) {
+  struct Shape { int B, H, L; };
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (Shape s : {Shape{1, 24, 4608}, Shape{2, 24, 4112}, Shape{1, 4, 1000}, Shape{1, 2, 129}, Shape{1, 3, 200}, Shape{1, 2, 96}, Shape{1, 2, 128}, Shape{2, 2, 176}}) {
+    const int Lpad = (s.L + 63) / 64 * 64;
+    const size_t n = (size_t)s.B * s.H * s.L * 128, nv = (size_t)s.B * s.H * 128 * Lpad;
+    uint8_t *q, *k;
+    bf16_t *vt, *oa, *ob;
+    hipMalloc((void**)&q, n); hipMalloc((void**)&k, n); hipMalloc((void**)&vt, nv * 2); hipMalloc((void**)&oa, n * 2); hipMalloc((void**)&ob, n * 2);
+    fill_e4m3_kernel<<<2048, 256>>>(q, n, 11u); fill_e4m3_kernel<<<2048, 256>>>(k, n, 12u); fill_kernel<<<2048, 256>>>(vt, nv, 3u);
+    hipDeviceSynchronize();
+    const float scale = ldexpf(1.0f, -6) / 1.4426950408889634f;  // scale * log2(e) = 2^-6
+    AttnOut out{};
+    out.p1 = oa, out.ld1 = s.H * 128, out.bstride1 = (int64_t)s.L * s.H * 128;
+    double us[2];
+    for (int w = 0; w < 2; ++w) {
+      set_attention_w16(w == 1);
+      out.p1 = w ? ob : oa;
+      for (int i = 0; i < 3; ++i) launch_attention_ex((const bf16_t*)q, (const bf16_t*)k, vt, out, s.B, s.H, s.L, s.L, Lpad, scale, 96, nullptr, 1);
+      hipDeviceSynchronize();
+      hipEventRecord(e0, nullptr);
+      for (int i = 0; i < iters; ++i) launch_attention_ex((const bf16_t*)q, (const bf16_t*)k, vt, out, s.B, s.H, s.L, s.L, Lpad, scale, 96, nullptr, 1);
+      hipEventRecord(e1, nullptr);
+      hipEventSynchronize(e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      us[w] = ms / iters * 1e3;
+    }
+    std::vector<uint16_t> ha(n), hb(n);
+    hipMemcpy(ha.data(), oa, n * 2, hipMemcpyDeviceToHost);
+    hipMemcpy(hb.data(), ob, n * 2, hipMemcpyDeviceToHost);
+    auto tof = [](uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return (double)f; };
+    double num = 0, den = 0, mx = 0;
+    size_t nan = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const double a = tof(hb[i]), b = tof(ha[i]);
+      if (!(a == a)) ++nan;
+      num += (a - b) * (a - b), den += b * b, mx = std::max(mx, std::fabs(a - b));
+    }
+    printf("fp8 QK^T  B=%d H=%d L=%d   8-wave %6.1f us   one-wave (w16 QK8) %6.1f us   rel-L2 %.3e  max |diff| %.4g  NaN %zu%s\n", s.B, s.H, s.L, us[0], us[1],
+           std::sqrt(num / std::max(den, 1e-30)), mx, nan, hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
+    hipFree(q); hipFree(k); hipFree(vt); hipFree(oa); hipFree(ob);
+  }
+  set_attention_w16(true);
+}
+
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 20;
+  if (getenv("FMI_FP8_ONLY")) {
+    fp8_section(iters);
+    return 0;
+  }
   struct Shape { int B, H, L; };
   std::vector<Shape> shapes = {{1, 24, 4608}, {1, 24, 4112}, {2, 24, 4608}, {1, 4, 1000}, {1, 2, 64}, {1, 3, 200}, {1, 2, 128}, {1, 2, 192}, {1, 1, 116}, {1, 2, 127}, {1, 2, 129}, {1, 2, 512}};  // + ragged / tiny shapes for the bit-identity check
   hipEvent_t e0, e1;
@@ -124,5 +185,6 @@ int main(int argc, char** argv) {
     hipFree(o5);
     hipFree(q); hipFree(k); hipFree(vt); hipFree(o);
   }
+  fp8_section(iters);
   return 0;
 }

@@ -43,6 +43,15 @@ The fragment stream (each fragment read LOOKAHEAD MFMA slots ahead of its first 
 MFMA has left the front of the matrix pipe — rule 3 of DESIGN 4.4, asserted below) is continuous from pre to the loop's end;
 post drains and fetches its own first fragments.
 
+fp8 mode (AW16_MODE=fp8qk -> attention_w16f8_loop.inc; BASELINE configs[4]): Q and K arrive as OCP e4m3 bytes with
+static scales (the model's fp8 mode emits them from the fused QKV epilogue).  The score product is then ONE
+v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile — the whole head dimension in one instruction, 8 per block and tile instead
+of 32, at twice the rate — whose block scales carry 2^-n: the host picks the q scale so that scale * log2(e) / (sq * sk) is
+exactly a power of two, and the fold (-m as the accumulator's start value) works unchanged.  A K tile is 8 KiB (rows of 128
+bytes, 16-byte slot p of row r holds global slot p ^ f8(r), f8(r) = ((r & 7) >> 1) | ((r >> 4) & 1) << 2), a K fragment is 32
+bytes per lane (two ds_read_b128 into two adjacent fragment buffers), Q fragments are 8 registers.  P, V^T and the second
+product are the bf16 ones.
+
 Register map (pinned by the operand constraints in attention_w16.h):
   a[0:127]    O^T   O[b][dt][c]  -> a[((8b+dt)*2+c)*4 ..]        a[128:191]  Q fragments QF[b][c][s] -> a[128+((2b+c)*4+s)*4 ..]
   a[192:207]  OL[b][c]: the ones-row product (register 0 of lanes 0..15 = the row sum of query n)
@@ -61,6 +70,9 @@ TILE = 16384
 VT_RING = 4 * TILE
 NBUF = 8          # fragment buffers
 LOOKAHEAD = int(os.environ.get("AW16_LOOKAHEAD", "12"))    # a fragment is read this many MFMA slots ahead of its first use (about 6 reads in flight)
+MODE = os.environ.get("AW16_MODE", "bf16")  # "bf16" | "fp8qk": Q and K as OCP e4m3 (see the fp8 notes below), P and V^T stay bf16
+FP8 = MODE == "fp8qk"
+TILE_K = 8192 if FP8 else TILE  # bytes of a K tile in LDS (64 keys x 128 d)
 X = os.environ.get("AW16_X", "")  # timing experiments only (wrong results): novalu | noexp | nodma | nobarrier | halfreads | nomfma | nowait
 
 PMAX, TA, TB, T0, T1, AL, DL = (f"v{n}" for n in range(184, 191))
@@ -88,6 +100,14 @@ def QF(b, c, s):
     return f"a[{lo}:{lo + 3}]"
 
 
+def QF8(b, c):
+    lo = 128 + (2 * b + c) * 8
+    return f"a[{lo}:{lo + 7}]"
+
+
+SCA, SCB = "v172", "v173"  # fp8 mode: E8M0 block scales of the score product (2^-n on the K side, 1 on the Q side)
+
+
 def S(b, a, c):
     lo = ((4 * b + a) * 2 + c) * 4
     return f"v[{lo}:{lo + 3}]"
@@ -106,7 +126,15 @@ def Pr(b, kk, c, d):
     return f"v{64 + ((2 * b + kk) * 2 + c) * 4 + d}"
 
 
-def FR(n):
+NBUFK = 4  # fp8 mode: 32-byte K fragments live in their own pool of four 8-register buffers in the accumulator half, a[208:239]
+
+
+def FR(n, pool="V", half=None):
+    """register range of fragment buffer n of a pool: "V" = v[96:127] (8 x 4 registers: every bf16 fragment);  "K8" = a[208:239]
+    (4 x 8 registers; half = 0 / 1 selects the 16 bytes one ds_read_b128 fills)"""
+    if pool == "K8":
+        lo = 208 + 8 * (n % NBUFK)
+        return f"a[{lo}:{lo + 7}]" if half is None else f"a[{lo + 4 * half}:{lo + 4 * half + 3}]"
     lo = 96 + 4 * (n % NBUF)
     return f"v[{lo}:{lo + 3}]"
 
@@ -155,6 +183,8 @@ def pv_seq(b):
 
 
 def qk_seq(b):
+    if FP8:  # one MFMA per score tile: key block a = j >> 1, query block c = j & 1; fragment a (32 bytes per lane)
+        return [(f"v_mfma_scale_f32_16x16x128_f8f6f4 {S(b, j >> 1, j & 1)}, {{fr}}, {QF8(b, j & 1)}, {NM(b, j & 1)}, {SCA}, {SCB}", j >> 1) for j in range(8)]
     return [(qk_mfma(b, j), j >> 1) for j in range(32)]
 
 
@@ -165,12 +195,15 @@ def qk_mfma(b, j):
 
 
 def pv_frag(f):  # fragment f = 0..15 of a PV product: k-step kk = f >> 3, d block dt = f & 7
-    return VAD(f >> 3), (f & 7) * 2048
+    return [(VAD(f >> 3), (f & 7) * 2048)]
 
 
 def qk_frag(f):  # fragment f = 0..15 of a QK^T product: d-step s = f >> 2, key block a = f & 3
+    if FP8:  # fragment a = f: rows of 128 bytes; two 16-byte reads (KAD[0], KAD[1] = KAD[0] ^ 16) -> 8 registers
+        imm = (f >> 1) * 4096 + (f & 1) * 1024
+        return [(KAD(0), imm), (KAD(1), imm)]
     a = f & 3
-    return KAD(f >> 2), (a >> 1) * 8192 + (a & 1) * 2048
+    return [(KAD(f >> 2), (a >> 1) * 8192 + (a & 1) * 2048)]
 
 
 class Phase:
@@ -185,6 +218,18 @@ class Phase:
             pv, qk = pv_seq(pv_b), qk_seq(qk_b)
             # alternate PV / QK^T (consecutive MFMAs never share an accumulator); the phase's fragments are numbered in order of first use
             seq = []
+            if FP8:  # 36 PV MFMAs and 8 score MFMAs: spread the latter evenly
+                npv, nqk, ip, iq = len(pv), len(qk), 0, 0
+                while ip < npv or iq < nqk:
+                    if iq >= nqk or (ip < npv and (ip + 1) * nqk <= (iq + 1) * npv):
+                        t, f = pv[ip]
+                        ip += 1
+                        seq.append((t, None if f is None else ("V", f)))
+                    else:
+                        t, f = qk[iq]
+                        iq += 1
+                        seq.append((t, ("K", f)))
+                pv, qk = [], []
             while pv or qk:
                 if pv:
                     t, f = pv.pop(0)
@@ -200,11 +245,20 @@ class Phase:
                 self.mfma.append((t, None if key is None else index[key]))
         else:
             self.mfma = pv_seq(pv_b) if pv_b is not None else qk_seq(qk_b)
-            self.frags = [pv_frag(f) if pv_b is not None else qk_frag(f) for f in range(16)]
+            nfr = 1 + max(f for _, f in self.mfma if f is not None)
+            self.frags = [pv_frag(f) if pv_b is not None else qk_frag(f) for f in range(nfr)]
         self.n = len(self.mfma)
         self.fu = [min(i for i, (_, ff) in enumerate(self.mfma) if ff == f) for f in range(len(self.frags))]
         self.lu = [max(i for i, (_, ff) in enumerate(self.mfma) if ff == f) for f in range(len(self.frags))]
         assert self.fu == sorted(self.fu), self.fu
+        # fragment buffers: per pool, numbered in order of first use; a phase's span in each pool is padded to a multiple of the
+        # pool size, so every phase starts at buffer 0 of both pools
+        self.pool = ["K8" if len(fr) == 2 else "V" for fr in self.frags]
+        self.bpos, cnt = [], {"V": 0, "K8": 0}
+        for pl in self.pool:
+            self.bpos.append(cnt[pl])
+            cnt[pl] += 1
+        self.span = {"V": -(-cnt["V"] // NBUF) * NBUF, "K8": -(-cnt["K8"] // NBUFK) * NBUFK}
         self.buf0 = 0
 
 
@@ -335,10 +389,10 @@ def softmax_plan(ph, uid):
     gap 4 (>= 4 MFMAs = 64+ clocks behind; an MFMA result needs ~40)."""
     b, n = ph.sm_b, ph.n
     plan = [[] for _ in range(n)]
-    g_mask = 4
+    g_mask = 4 if n >= 16 else 0   # (fp8 mode's first phases are 8 MFMAs long and entered drained: S^T is complete at slot 0)
     skipm = f".Law16_nomask_{uid}_%="
     plan[g_mask] += [f"s_cmp_eq_u32 {S_FLAG}, 0", f"s_cbranch_scc1 {skipm}"] + mask_block(b) + [f"{skipm}:"]
-    span = 8 if n >= 64 else 4
+    span = 8 if n >= 64 else 4 if n >= 16 else 2
     spread(plan, max_stream(b), g_mask + 1, g_mask + span)
     g_dec = g_mask + span + 1
     skip, do = f".Law16_skip_{uid}_%=", f".Law16_resc_{uid}_%="
@@ -363,40 +417,45 @@ def emit_phase(ph, nxt, uid, own_prefetch=False, drain=False):
     n = ph.n
     nf = len(ph.frags)
     plan = softmax_plan(ph, uid) if ph.sm_b is not None else [[] for _ in range(n)]
-    # ---- the reads of every gap, in stream order
-    reads = [[] for _ in range(n)]           # (stream index relative to ph.buf0, reg, imm)
+    # ---- the read instructions of every gap, in stream order: (key, register range, reg, imm); key = (0, f) own fragment f, (1, f) the next phase's
+    def rd_regs(p_, f, k):
+        return FR(p_.bpos[f], p_.pool[f], k if p_.pool[f] == "K8" else None)
+
+    reads = [[] for _ in range(n)]
     early = []                               # read before slot 0 (previous phase's tail or own prefetch), in order
-    for f, (reg, imm) in enumerate(ph.frags):
+    for f, fr in enumerate(ph.frags):
         i = ph.fu[f] - LOOKAHEAD
-        (reads[i] if i >= 0 else early).append((f, reg, imm))
+        for k, (reg, imm) in enumerate(fr):
+            (reads[i] if i >= 0 else early).append(((0, f), rd_regs(ph, f, k), reg, imm))
     own_last_read = max([g for g in range(n) if reads[g]], default=-1)
-    nxt_first_read = n
     if nxt is not None:
-        for f, (reg, imm) in enumerate(nxt.frags):
+        for f, fr in enumerate(nxt.frags):
             i = n + nxt.fu[f] - LOOKAHEAD
             if i < n:
                 assert i > own_last_read, (ph.name, "next phase's reads must follow the own ones")
-                reads[i].append((nf + f, reg, imm))
-                nxt_first_read = min(nxt_first_read, i)
+                for k, (reg, imm) in enumerate(fr):
+                    reads[i].append(((1, f), rd_regs(nxt, f, k), reg, imm))
     if own_prefetch:
-        for (f, reg, imm) in early:
-            o.append(f"ds_read_b128 {FR(ph.buf0 + f)}, {reg} offset:{imm}")
-    # position of every read in issue order (early ones first): younger(f, i) = reads issued after f's and before MFMA slot i
-    order = [f for (f, _, _) in early]
+        for (_, b_, reg, imm) in early:
+            o.append(f"ds_read_b128 {b_}, {reg} offset:{imm}")
+    # position of every read in issue order (early ones first); last[f] = position of fragment f's last read
+    order = [key for (key, _, _, _) in early]
     issued_before_slot = [len(order)]
     for g in range(n):
-        order += [f for (f, _, _) in reads[g]]
+        order += [key for (key, _, _, _) in reads[g]]
         issued_before_slot.append(len(order))   # issued before MFMA slot g + 1
-    pos = {f: k for k, f in enumerate(order)}
+    last = {}
+    for k, key in enumerate(order):
+        last[key] = k
     # ---- ring-slot advance of the address registers: each register right behind the last own read that uses it (the next
     # phase's reads of that register come later by construction: asserted)
     adv_at = [[] for _ in range(n)]
     if ph.advance:
-        regs = ([(KAD(s_), S_MKK) for s_ in range(4)] if "K" in ph.advance else []) + ([(VAD(k_), S_MKV) for k_ in range(2)] if "V" in ph.advance else [])
+        regs = ([(KAD(s_), S_MKK) for s_ in range(2 if FP8 else 4)] if "K" in ph.advance else []) + ([(VAD(k_), S_MKV) for k_ in range(2)] if "V" in ph.advance else [])
         for reg, mask in regs:
-            own = [g for g in range(n) for (fs, r_, _) in reads[g] if fs < nf and r_ == reg]
+            own = [g for g in range(n) for (key, _, r_, _) in reads[g] if key[0] == 0 and r_ == reg]
             g_last = max(own, default=0)
-            nxt_use = [g for g in range(n) for (fs, r_, _) in reads[g] if fs >= nf and r_ == reg]
+            nxt_use = [g for g in range(n) for (key, _, r_, _) in reads[g] if key[0] == 1 and r_ == reg]
             assert all(g > g_last for g in nxt_use), (ph.name, reg, g_last, nxt_use)
             adv_at[g_last].append(f"v_xor_b32 {reg}, {mask}, {reg}")
     q = n // 4
@@ -405,7 +464,7 @@ def emit_phase(ph, nxt, uid, own_prefetch=False, drain=False):
         pre, post = [], []
         # ---- DMA pieces (4 per phase): B stages K(tile) once per quarter, A stages V^T(tile) in the second half (behind the barrier)
         dma = None
-        if ph.dma == "K" and i % q == q // 2 - 1 and X != "nodma":
+        if ph.dma == "K" and i % q == q // 2 - 1 and i // q < (2 if FP8 else 4) and X != "nodma":
             piece = i // q
             pre.append(f"s_add_i32 m0, {S_M0K}, {piece * 1024}")
             pre.append(f"v_cndmask_b32 {DMAT}, v{134 + piece}, v{142 + piece}, {S_MASK}")
@@ -418,11 +477,11 @@ def emit_phase(ph, nxt, uid, own_prefetch=False, drain=False):
         if i % 4 == 0:
             need = [f2 for f2 in range(nf) if i <= ph.fu[f2] < i + 4]
             if need:
-                younger = issued_before_slot[i] - pos[max(need)] - 1
+                younger = issued_before_slot[i] - last[(0, max(need))] - 1
                 assert 0 <= younger <= 15, (ph.name, i, younger)
                 pre.append(f"s_waitcnt lgkmcnt({younger})")
-        mf = text.format(fr=FR(ph.buf0 + f)) if f is not None else text
-        rd = [f"ds_read_b128 {FR(ph.buf0 + fs)}, {reg} offset:{imm}" for (fs, reg, imm) in reads[i]]
+        mf = text.format(fr=FR(ph.bpos[f], ph.pool[f])) if f is not None else text
+        rd = [f"ds_read_b128 {b_}, {reg} offset:{imm}" for (_, b_, reg, imm) in reads[i]]
         post += adv_at[i]
         post += plan[i]
         if X == "halfreads":
@@ -444,28 +503,37 @@ def emit_phase(ph, nxt, uid, own_prefetch=False, drain=False):
             o.append(dma)
         o += post
         if ph.barrier and i == n // 2 and X != "nobarrier":
-            o += ["s_waitcnt vmcnt(8)", "s_barrier"]
+            # everything but this wave's newest pieces — V^T(t+2) [4] and K(t+3) [4; 2 in fp8 mode] — has landed: K(t+2), V^T(t+1)
+            o += [f"s_waitcnt vmcnt({4 + (2 if FP8 else 4)})", "s_barrier"]
     if drain:
         o += ["s_waitcnt lgkmcnt(0)", "s_nop 15", "s_nop 15", "s_nop 15"]
     return o
+
+
+def early_reads(ph):
+    """the reads of ph's fragments that precede its slot 0 (what the previous phase's tail, or an own prefetch, issues), in order"""
+    out = []
+    for f, fr in enumerate(ph.frags):
+        if ph.fu[f] - LOOKAHEAD < 0:
+            for k, (reg, imm) in enumerate(fr):
+                out.append(f"ds_read_b128 {FR(ph.bpos[f], ph.pool[f], k if ph.pool[f] == 'K8' else None)}, {reg} offset:{imm}")
+    return out
 
 
 def check_rule3(seq):
     """Linearise a sequence of phases and assert that every read refills a buffer whose previous fragment's LAST MFMA sits
     strictly before the MFMA slot the read is issued behind (so a later MFMA has issued and the old operand has left the front
     of the matrix pipe), and that reads are issued in stream order."""
-    base, stream = 0, []
+    base, last_user, prev_rd = 0, {}, None
     for ph in seq:
-        for f in range(len(ph.frags)):
-            stream.append((base + ph.fu[f] - LOOKAHEAD, base + ph.fu[f], base + ph.lu[f], ph.name))
+        for f, fr in enumerate(ph.frags):
+            rd = base + ph.fu[f] - LOOKAHEAD
+            assert prev_rd is None or rd >= prev_rd, ("stream order", ph.name, f)
+            prev_rd = rd
+            pb = (ph.pool[f], ph.bpos[f] % (NBUFK if ph.pool[f] == "K8" else NBUF))
+            assert last_user.get(pb, -10**9) < rd, ("rule 3", ph.name, f, pb, last_user.get(pb), rd)
+            last_user[pb] = base + ph.lu[f]
         base += ph.n
-    for k, (rd, fu, lu, name) in enumerate(stream):
-        if k >= 1:
-            assert rd >= stream[k - 1][0], ("stream order", name, k)
-        if k >= NBUF:
-            assert stream[k - NBUF][2] < rd, ("rule 3", name, k, stream[k - NBUF], rd)
-        if rd >= 0 and k + 1 < len(stream):
-            pass
 
 
 def build():
@@ -479,30 +547,33 @@ def build():
 
 def loop():
     pre, a0, bt, at, post = build()
-    # buffer numbering: pre (16 fragments), A0 (16), then the loop body B (32), A (32): every phase starts at a multiple of NBUF
-    pos = 0
-    for ph in (pre, a0, bt, at):
-        ph.buf0 = pos
-        pos += len(ph.frags)
-        assert ph.buf0 % NBUF == 0
-    post.buf0 = 0
-    check_rule3([pre, a0, bt, at, bt, at, bt])
+    # every phase's fragment count is a multiple of the pool size (16 / 32 bf16 fragments, 4 fp8 K fragments): all start at buffer 0
+    for ph in (pre, a0, bt, at, post):
+        assert ph.span["V"] == sum(1 for p_ in ph.pool if p_ == "V") and ph.span["K8"] == sum(1 for p_ in ph.pool if p_ == "K8"), ph.name
+    if FP8:  # pre and A0 are only 8 MFMAs long there: each fetches its own first fragments and ends drained (see below)
+        check_rule3([pre])
+        check_rule3([a0])
+        check_rule3([bt, at, bt, at, bt])
+    else:
+        check_rule3([pre, a0, bt, at, bt, at, bt])
     check_rule3([post])
 
     def dma_setup():
         """scalar state of one loop iteration: the tile both DMA streams fetch, min(t + 3, n - 1), and its ring slot"""
+        kshift = 13 if FP8 else 14   # log2 of a K tile's bytes, in HBM and in LDS (64 keys x 128 d)
         return [f"s_add_i32 {S_TILE}, {S_T}, 3",
                 f"s_min_i32 {S_TILE}, {S_TILE}, %[ntm1]",
-                f"s_lshl_b32 {S_TMP}, {S_TILE}, 14",
+                f"s_lshl_b32 {S_TMP}, {S_TILE}, {kshift}",
                 f"s_add_u32 s80, %[kb_lo], {S_TMP}",
                 f"s_addc_u32 s81, %[kb_hi], 0",
                 f"s_lshl_b32 {S_TMP}, {S_TILE}, 7",
                 f"s_add_u32 s82, %[vb_lo], {S_TMP}",
                 f"s_addc_u32 s83, %[vb_hi], 0",
                 f"s_and_b32 {S_TMP}, {S_TILE}, 3",
+                f"s_lshl_b32 {S_M0K}, {S_TMP}, {kshift}",
+                f"s_add_i32 {S_M0K}, {S_M0K}, %[woffk]",
                 f"s_lshl_b32 {S_TMP}, {S_TMP}, 14",
-                f"s_add_i32 {S_M0K}, {S_TMP}, %[woff]",
-                f"s_add_i32 {S_M0V}, {S_M0K}, {VT_RING}",
+                f"s_add_i32 {S_M0V}, {S_TMP}, %[woffv]",
                 f"s_cmp_eq_u32 {S_TILE}, %[ntm1]",
                 f"s_cselect_b64 {S_MASK}, -1, 0"]
 
@@ -516,19 +587,29 @@ def loop():
     o = []
     # ---- pre, A0 (= "A(t+1)" with t = -1: it stages V^T(2) and moves the K address registers from slot 0 to slot 1)
     o += [f"s_mov_b32 {S_T}, -1"] + dma_setup()
-    o += [f"s_mov_b32 {S_MKK}, {TILE}",                 # K leaves slot 0: even slot -> xor 1 << 14
+    o += [f"s_mov_b32 {S_MKK}, {TILE_K}",               # K leaves slot 0: even slot -> xor with one slot size
           f"s_mov_b32 {S_RAG}, %[rag]",
           f"s_mov_b32 {S_FLAG}, 0"]                      # softmax(0,0): tile 0 is never the last (n >= 2)
-    o += emit_phase(pre, a0, "pre", own_prefetch=True)
-    o += emit_phase(a0, bt, "a0")
+    if FP8:
+        # the first two phases are 8 MFMAs each — shorter than the fragment lookahead and with all eight buffers holding their own
+        # four 32-byte K fragments — so each fetches its own first fragments and ends drained, and B(0)'s first fragments are
+        # fetched here, in front of the loop label, exactly as A(t+1)'s tail fetches them for B(t+1)
+        o += emit_phase(pre, None, "pre", own_prefetch=True, drain=True)
+        o += emit_phase(a0, None, "a0", own_prefetch=True, drain=True)
+        o += early_reads(bt)
+    else:
+        o += emit_phase(pre, a0, "pre", own_prefetch=True)
+        o += emit_phase(a0, bt, "a0")
     o += [f"s_mov_b32 {S_T}, 0",
           ".Law16_loop_%=:"]
     o += dma_setup()
     # ring-slot masks of A(t+1): K leaves slot t + 1, V^T slot t (slot s -> s + 1: xor 1 << 14 out of an even slot, 3 << 14 out of an odd one)
     o += [f"s_and_b32 {S_TMP}, {S_T}, 1",
-          f"s_lshl_b32 {S_TMP}, {S_TMP}, 15",
-          f"s_or_b32 {S_MKV}, {S_TMP}, {TILE}",
-          f"s_xor_b32 {S_MKK}, {S_MKV}, {2 * TILE}"]
+          f"s_lshl_b32 {S_TMP2}, {S_TMP}, 15",
+          f"s_or_b32 {S_MKV}, {S_TMP2}, {TILE}",               # V^T leaves slot t: t even -> 1 << 14, odd -> 3 << 14
+          f"s_xor_b32 {S_TMP}, {S_TMP}, 1",                    # K leaves slot t + 1
+          f"s_lshl_b32 {S_TMP}, {S_TMP}, {(13 if FP8 else 14) + 1}",
+          f"s_or_b32 {S_MKK}, {S_TMP}, {TILE_K}"]
     o += rag_flag(S_T)                                   # B(t): softmax(1, t)
     o += emit_phase(bt, at, "b")
     o += [f"s_cmp_eq_u32 {S_T}, %[ntm1]",
@@ -548,14 +629,15 @@ def loop():
 
 def main():
     lines = loop()
-    path = os.path.join(ROOT, "diffusion-rs_amd", "csrc", "attention_w16_loop.inc")
+    stem = "attention_w16f8_loop" if FP8 else "attention_w16_loop"
+    path = os.path.join(ROOT, "diffusion-rs_amd", "csrc", stem + ".inc")
     if X:
         os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
-        path = os.path.join(ROOT, "build", f"attention_w16_loop_{X}.inc")
+        path = os.path.join(ROOT, "build", f"{stem}_{X}.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_attention_w16.py — do not edit.  The whole KV stream of attention_w16_kernel as one asm\n")
         f.write("// statement (pre, A0, loop { B(t); A(t+1) }, post); register map and schedule: see the generator.\n")
-        f.write("#define FMI_AW16_LOOP_ASM \\\n")
+        f.write(f"#define FMI_AW16{'F8' if FP8 else ''}_LOOP_ASM \\\n")
         body = ['  "' + ln + '\\n\\t"' for ln in lines if not ln.startswith(";")]
         f.write(" \\\n".join(body))
         f.write("\n")
