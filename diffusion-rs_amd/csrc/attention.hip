@@ -596,11 +596,10 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
     // round 3: the one-wave kernel's fp8-QK^T stream (attention_w16.h, QK8) carries scale * log2(e) / (sq * sk) as an E8M0 block
     // scale of the score MFMA, so it serves the calls whose factor is a power of two 2^-n, n = 0 .. 126 — the model's fp8 mode
     // picks its q scale that way (flux_model.hip: fp8_q_scale_pow2); anything else runs on the 8-wave kernel below
-    int e2 = 0;
-    const float fr = frexpf(sl, &e2);  // sl = fr * 2^e2, fr in [0.5, 1)
-    const bool pow2 = sl > 0.f && fabsf(fr - 0.5f) <= 2e-7f && e2 - 1 <= 0 && e2 - 1 >= -126;
+    const int n2 = sl > 0.f ? (int)lrintf(log2f(sl)) : 1;  // nearest power of two (a few float roundings separate the host's factor from 2^n)
+    const bool pow2 = n2 <= 0 && n2 >= -126 && fabsf(sl / ldexpf(1.0f, n2) - 1.0f) <= 1e-6f;
     if (g_att_w16 && Lk > ATT_KV && pow2) {
-      const float sl2 = ldexpf(1.0f, e2 - 1);
+      const float sl2 = ldexpf(1.0f, n2);
       if (rescale_thr_x16 == 0)
         hipLaunchKernelGGL((attention_w16_kernel<0, true>), grid, dim3(AW16_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl2);
       else
