@@ -15,7 +15,7 @@ lib: $(LIB)
 oracle:
 	$(MAKE) -C oracle -s
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h $(CSRC)/attention_w4_loop.inc $(CSRC)/attention_w16.h $(CSRC)/attention_w16_loop.inc $(CSRC)/attention_w32.h $(CSRC)/attention_w32_loop.inc include/flux_mi355x.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h $(CSRC)/attention_w4_loop.inc $(CSRC)/attention_w16.h $(CSRC)/attention_w16_loop.inc $(CSRC)/attention_w16f8_loop.inc $(CSRC)/attention_w32.h $(CSRC)/attention_w32_loop.inc include/flux_mi355x.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -26,8 +26,13 @@ $(LIB): $(OBJS)
 $(CSRC)/attention_w4_loop.inc: tools/gen_attention_w4_loop.py
 	python3 tools/gen_attention_w4_loop.py > /dev/null
 
+# attention_w16_kernel / attention_w32_kernel: the whole KV stream is generated (committed; regenerate after editing a generator)
 $(CSRC)/attention_w16_loop.inc: tools/gen_attention_w16.py
 	python3 tools/gen_attention_w16.py
+$(CSRC)/attention_w16f8_loop.inc: tools/gen_attention_w16.py
+	AW16_MODE=fp8qk python3 tools/gen_attention_w16.py
+$(CSRC)/attention_w32_loop.inc: tools/gen_attention_w32.py
+	python3 tools/gen_attention_w32.py
 
 clean:
 	rm -rf build $(LIB)
