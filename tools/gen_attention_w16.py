@@ -82,7 +82,6 @@ PMX = [f"v{n}" for n in range(199, 214)]  # partial maxima of the tree
 LKEY, DMAT = "v146", "v147"
 S_KP, S_VP, S_MASK = "s[80:81]", "s[82:83]", "s[84:85]"
 S_T, S_TILE, S_M0K, S_M0V, S_TMP, S_MKK, S_MKV, S_RAG, S_TMP2, S_FLAG = "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95"
-ONES = "0x3f803f80"  # bf16 (1.0, 1.0)
 NEG_BIG = "0xf149f2ca"  # -1e30f
 
 
@@ -487,6 +486,10 @@ def emit_phase(ph, nxt, uid, own_prefetch=False, drain=False):
         if X == "halfreads":
             rd = [r_ if k % 2 == 0 else "s_nop 0" for k, r_ in enumerate(rd)] if i % 4 < 2 else ["s_nop 0" for _ in rd]
         if X == "nomfma":
+            mf = "s_nop 0"
+        if X == "halfpv" and f is not None and ph.pool[f] == "V" and (i // 2) % 2:  # every second PV MFMA pair dropped: what would fp8 P V buy?
+            mf = "s_nop 0"
+        if X == "nopv" and (f is None or ph.pool[f] == "V"):
             mf = "s_nop 0"
         if X == "nowait":
             pre = [p_ for p_ in pre if not p_.startswith("s_waitcnt lgkmcnt")]
