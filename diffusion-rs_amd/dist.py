@@ -52,21 +52,26 @@ class StateExportUnsupported(RuntimeError):
     """The source rank's checkpoint cannot travel as flat arenas (LLM.int8 matrices): every rank loads it itself."""
 
 
-def agree_or_raise(error: Optional[BaseException], what: str = "load") -> None:
-    """Collective error check: every rank reports whether its `what` step failed; if any did, ALL ranks raise (instead of the
-    healthy ones blocking in the next collective until the RCCL timeout).  No-op without torch.distributed."""
-    rank, ws = world()
+def agree_or_raise(error: Optional[BaseException], what: str = "load", group=None) -> None:
+    """Collective error check over `group` (default: all ranks): every rank reports whether its `what` step failed; if any did,
+    ALL of them raise (instead of the healthy ones blocking in the next collective until the RCCL timeout).  No-op without
+    torch.distributed."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if error is not None:
+            raise error
+        return
+    ws = dist.get_world_size(group)
     if ws == 1:
         if error is not None:
             raise error
         return
     msgs = [None] * ws
-    dist.all_gather_object(msgs, None if error is None else f"{type(error).__name__}: {error}")
+    dist.all_gather_object(msgs, None if error is None else f"{type(error).__name__}: {error}", group=group)
     bad = [(r, m) for r, m in enumerate(msgs) if m is not None]
     if bad:
         if error is not None:
             raise error
-        raise RuntimeError(f"{what} failed on rank {bad[0][0]}: {bad[0][1]}")
+        raise RuntimeError(f"{what} failed on rank {bad[0][0]} of the group: {bad[0][1]}")
 
 
 def broadcast_state(model, device, src: int = 0, chunk_bytes: int = STATE_CHUNK, comm: "Optional[RcclComm]" = None) -> dict:
@@ -153,7 +158,7 @@ class RcclComm:
                     L.check(self.lib.fmi_comm_create((C.c_uint8 * 128).from_buffer_copy(ident[0]), self.rank, self.world_size, C.byref(h)))
             except Exception as e:
                 err = e
-        agree_or_raise(err, "RCCL communicator creation")
+        agree_or_raise(err, "RCCL communicator creation", group)
         self.h = h
 
     def _stream(self, stream=None):

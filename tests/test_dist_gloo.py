@@ -1,6 +1,7 @@
 """world_size-2 tests of the multi-GPU paths on CPU (gloo): sample -> rank mapping, weight broadcast from rank 0
 (tensor-wise and as flat arenas), ragged gather back to rank 0 in prompt order, Pipeline.forward's sharded front door
-(SURVEY §8e), the index math of the Ulysses head redistribution and the token shards of dist.SequenceParallel."""
+(SURVEY §8e), the index math of the Ulysses head redistribution, the token shards of dist.SequenceParallel and the
+collective error agreement (one rank's failure raises on every rank)."""
 import os
 import socket
 
@@ -119,6 +120,27 @@ def _worker(rank, world, port, n_prompts, q):
         raise AssertionError("7 tokens must not split over 2 ranks")
     except ValueError:
         pass
+
+    # 7. collective error agreement: a failure on ONE rank raises on ALL of them (nobody is left waiting in the next collective),
+    #    and a source whose state cannot travel as flat arenas (LLM.int8) is announced before the first data message
+    try:
+        fd.agree_or_raise(ValueError("boom") if rank == 1 else None, "test step")
+        raise AssertionError("agree_or_raise must raise on every rank")
+    except ValueError:
+        assert rank == 1
+    except RuntimeError as e:
+        assert rank == 0 and "rank 1" in str(e) and "boom" in str(e)
+    fd.agree_or_raise(None, "nothing failed")
+
+    class Int8Stub(StubModel):
+        def state_export(self):
+            raise RuntimeError("state_export: LLM.int8 matrices are not part of the flat state")
+
+    try:
+        fd.broadcast_state(Int8Stub(), "cpu")
+        raise AssertionError("broadcast_state must announce an unexportable state")
+    except fd.StateExportUnsupported as e:
+        assert "LLM.int8" in str(e)
 
     q.put((rank, {k: v.numpy() for k, v in got.items()}, None if out is None else out.numpy(), fd.shard_indices(n_prompts, rank, world),
            state_sum, None if fwd is None else fwd.numpy()))
