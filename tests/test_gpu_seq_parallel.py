@@ -121,8 +121,15 @@ def test_sequence_parallel_forward_is_bit_identical_to_one_device(env, cfg_name,
     Hr, Lpl = H // N, (Ll + 63) // 64 * 64
     assert ranks.bytes_per_peer[0] == {(2 * Hr * Ll * 128 + Hr * 128 * Lpl) * 2, Ll * Hr * 128 * 2}
     mism = int((got.view(torch.int32) != ref.view(torch.int32)).sum())
-    print(f"SP forward {cfg_name} N={N} S={S_hw} T={T}: {mism} mismatching elements of {got.numel()}, max |diff| {float((got - ref).abs().max()):.3e}")
-    assert mism == 0
+    # and against the CPU oracle directly ("the SP tests compare the HIP path with the HIP path"): the sharded forward is
+    # Flux::forward (model.rs:790-833) of the whole image, at the tolerance of the single-device forward
+    from oracle import oracle as orc
+    from tests.util import host, rel_l2
+    om = orc.Flux(cfg)
+    om.load(sd)
+    err = rel_l2(host(got), om.forward(img, ids, txt, txt_ids, t, y, g))
+    print(f"SP forward {cfg_name} N={N} S={S_hw} T={T}: {mism} mismatching elements of {got.numel()}, max |diff| {float((got - ref).abs().max()):.3e}; vs oracle {err:.3e}")
+    assert mism == 0 and err <= 1e-2
 
 
 def test_sequence_parallel_denoise_is_bit_identical_and_switches_off(env):
