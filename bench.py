@@ -426,17 +426,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
 
-        def usable_cpus():
-            n = len(os.sched_getaffinity(0))
-            try:  # cgroup v2 CPU quota (the GPU box exposes 256 logical CPUs but caps the container)
-                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-                if q != "max":
-                    n = min(n, max(1, int(int(q) / int(per))))
-            except Exception:
-                pass
-            return n
-
-        orc.set_threads(usable_cpus())
+        orc.set_threads(orc.usable_cpus())  # affinity capped by the cgroup CPU quota (16 of the box's 256 logical CPUs)
         Sc, Tc = (S, T) if not args.cpu_baseline_tokens else (args.cpu_baseline_tokens * 3 // 4, args.cpu_baseline_tokens // 4)
         Lc = Sc + Tc
         cfg1 = dict(d.FLUX_DEV, num_layers=1, num_single_layers=1)

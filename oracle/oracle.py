@@ -33,6 +33,7 @@ def lib():
     if _lib is None:
         build()
         _lib = C.CDLL(_SO)
+        _lib.orc_set_threads(usable_cpus())  # (the default OpenMP team would be one thread per visible CPU, quota or not)
         _lib.orc_calculate_shift.restype = C.c_double
         _lib.orc_round_bf16.restype = C.c_float
         _lib.orc_round_bf16.argtypes = [C.c_float]
@@ -63,6 +64,20 @@ def _opt(a):
     if a is None:
         return None, None
     return _f(a)
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the scheduler affinity capped by the cgroup-v2 CPU quota (the GPU box shows 256 logical
+    CPUs and caps the container at 16: an OpenMP team of 256 threads on 16 CPUs' worth of quota runs ~4x slower than one of 16)."""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
 
 
 def set_threads(n):
