@@ -240,6 +240,45 @@ def test_c2_dev_1024_one_forward_of_the_full_model_matches_oracle(full_models):
     assert np.isfinite(got).all() and err <= 2e-2
 
 
+def test_batch_of_8_at_full_size_equals_the_samples_run_alone(full_models):
+    """`Pipeline.MAX_BATCH` = 8 at the headline shape: FLUX.1-dev in full, 8 samples x (4096 + 512) tokens in ONE denoise call (36 864
+    rows per launch, a 1.6 GB fused-projection buffer, 8 x 3 = 24 rows in the modulation precompute) — every row of every kernel is
+    computed independently of the rows it shares a launch with, so each sample must equal the same sample run alone, bit for bit.
+    (Round 3 found two size bugs that only a full-size, large-batch run exposes: 32-bit operand offsets beyond 4 GiB and an LDS
+    staging limit of the embedder GEMV at B > 5.)"""
+    torch, d, orc, gm = (full_models[k] for k in ("torch", "d", "orc", "gm_dev"))
+    cfg = dict(d.FLUX_DEV)
+    B, T = 8, 512
+    rng = np.random.default_rng(82)
+    lat = rng.standard_normal((B, 16, 128, 128)).astype(np.float32)
+    t5 = bf16_round(rng.standard_normal((B, T, cfg["joint_attention_dim"])).astype(np.float32))
+    clip = rng.standard_normal((B, cfg["pooled_projection_dim"])).astype(np.float32)
+    img, ids = orc.pack_latents(lat)
+    txt_ids = np.zeros((B, T, 3), np.float32)
+    g = np.full((B,), 3.5, np.float32)
+    sched = d.SchedulerConfig()
+    ts = sched.get_timesteps(3, sched.calculate_shift(4096))
+    run = lambda sl: host(gm.denoise(dev(img[sl]), dev(ids[sl]), dev(t5[sl], torch.bfloat16), dev(txt_ids[sl]), dev(clip[sl]), dev(g[sl]), ts))
+    # the modulation precompute picks its path by row count (steps x batch: 24 rows -> one GEMM on bf16 silu(vec); 3 rows -> f32 GEMV
+    # passes), so bit-identity is asked for with the path pinned, and the default paths are compared to rounding
+    from diffusion_rs_amd import _lib as L
+    L.check(gm.lib.fmi_flux_set_modulation_gemm(gm.h, 0))
+    try:
+        full = run(slice(0, 8))
+        assert np.isfinite(full).all()
+        for i in (0, 5, 7):
+            one = run(slice(i, i + 1))
+            nbad = int((one[0].view(np.uint32) != full[i].view(np.uint32)).sum())
+            assert nbad == 0, (i, nbad)
+    finally:
+        L.check(gm.lib.fmi_flux_set_modulation_gemm(gm.h, 1))
+    dflt = run(slice(0, 8))
+    e = rel_l2(dflt, full)
+    print(f"batch 8 at 1024x1024 (36 864 token rows per launch), 3 steps: samples 0, 5, 7 identical to their single-sample runs; "
+          f"default modulation path (one GEMM, 24 rows) vs the GEMV passes: rel-L2 {e:.2e}")
+    assert e <= 5e-3
+
+
 def test_c3_nf4_full_model_forward_matches_oracle_on_dequantised_weights(full_models):
     """BASELINE configs[2] (C3: Q4-bnb) with the FULL model: every block and modulation Linear of FLUX.1-dev as bitsandbytes nf4
     (blocksize 64; 7.4 GiB resident, no bf16 copy), one `Flux::forward` at 1024 image + 256 text tokens — above 383 rows, so the
