@@ -70,14 +70,14 @@ __device__ __forceinline__ uint16_t f32_to_f16(float f) {
 
 // GELU tanh approximation (core/op.rs:539-582, f32 arm) and SiLU (op.rs:699-721)
 __device__ __forceinline__ float gelu_tanh(float v) {
-  const float k = 0.79788456080286535587989211986876373f;
-  float u = k * v * (1.0f + 0.044715f * v * v);
-  // tanh(u) = 1 - 2/(exp(2u)+1); saturates cleanly for large |u|
-  float e = __expf(2.0f * u);
-  // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions): the GELU of a 256 x 256 tile is 128 of
-  // these per lane in the GEMM epilogue; the error is far below the bf16 rounding of the result
-  float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-  return 0.5f * v * (1.0f + t);
+  // 0.5 v (1 + tanh(u)), u = k v (1 + 0.044715 v^2), written as v sigmoid(2u) = v - v / (2^(v (c1 + c2 v^2)) + 1) with
+  // c1 = 2 k log2(e), c2 = 0.044715 c1: 6 VALU + v_exp_f32 + v_rcp_f32 (1 ulp each) per element instead of 11 + 2 for the
+  // tanh form — the GELU of a 256 x 256 tile is 128 of these per lane in the GEMM epilogue.  Saturates cleanly: 2^(+big) = inf
+  // -> v, 2^(-big) = 0 -> 0.  The differences to the f32 arm of the reference formula are rounding (far below the bf16 result).
+  const float c1 = 2.0f * 0.79788456080286535587989211986876373f * 1.44269504088896340736f;
+  const float c2 = c1 * 0.044715f;
+  const float e = __builtin_amdgcn_exp2f(v * fmaf(c2, v * v, c1));
+  return fmaf(-v, __builtin_amdgcn_rcpf(e + 1.0f), v);
 }
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
 

@@ -152,8 +152,11 @@ __device__ __forceinline__ void stage_tile_q4(const GemmProblem& P, int n0, int 
 // columns n = n0 + wn*32*NJ + j*32 + 8q + 4(lane>>5) + {0..3} in registers 4q..4q+3.
 // `smem` (>= 8 * 8192*NJ bytes) is free for staging once every wave has passed the leading barrier.
 // Accumulator views: which (row, 4 consecutive columns) of its wave's 128 x (32 NJ) sub-tile a lane owns, so that the epilogues
-// below are written once for both MFMA shapes.  each<HALF>(f) calls f(r, c, v) for every group the lane owns — r = row inside the
-// sub-tile, c = index of the 4-column group (column = 4 c), v = the four f32 — for all rows (HALF = -1) or one 64-row half.
+// below are written once for both MFMA shapes.  each<HALF>(f) calls f(r, c, v, slot) for every group the lane owns — r = row inside
+// the sub-tile, c = index of the 4-column group (column = 4 c), v = the four f32 — for all rows (HALF = -1) or one 64-row half.
+// A lane owns only kSlots distinct column groups (the same ones in every row block): `slot` numbers them (a compile-time value
+// after unrolling), cols(f) calls f(slot, c) once for each — what the epilogues use to fetch the bias ONCE, in one round trip,
+// instead of one dependent global load in front of every group (measured: 32 serialised L2 round trips per lane and tile).
 //   Acc32: v_mfma_f32_32x32x16_bf16 / 32x32x64_f8 with swapped operands: acc[i][j] is rows 32 i + (lane & 31), columns
 //          32 j + 8 q + 4 (lane >> 5) + {0..3} in registers 4 q .. 4 q + 3.
 //   Acc16: v_mfma_f32_16x16x32_bf16: acc[tm][tn] is rows 16 tm + (lane & 15), columns 16 tn + 4 (lane >> 4) + {0..3}.
@@ -163,6 +166,15 @@ struct Acc32 {
   f32x16 (&a)[4][NJ];
   int lane;
   static constexpr bool kFence = NJ == 4;
+  static constexpr int kSlots = 4 * NJ;
+  template <class F>
+  __device__ __forceinline__ void cols(F&& f) const {
+    const int hl = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) f(j * 4 + q, j * 8 + q * 2 + hl);
+  }
   template <int HALF, class F>
   __device__ __forceinline__ void each(F&& f) const {
     const int hl = lane >> 5, l31 = lane & 31;
@@ -176,7 +188,7 @@ struct Acc32 {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = a[i][j][q * 4 + e];
-          f(i * 32 + l31, j * 8 + q * 2 + hl, v);
+          f(i * 32 + l31, j * 8 + q * 2 + hl, v, j * 4 + q);
           // 4-wave kernels: the accumulators sit in AGPRs; without a fence the scheduler hoists all 256 reads and spills
           if constexpr (kFence) __builtin_amdgcn_sched_barrier(0);
         }
@@ -188,6 +200,13 @@ struct Acc16 {
   f32x4 (&a)[8][2 * NJ];
   int lane;
   static constexpr bool kFence = NJ == 4;
+  static constexpr int kSlots = 2 * NJ;
+  template <class F>
+  __device__ __forceinline__ void cols(F&& f) const {
+    const int l4 = lane >> 4;
+#pragma unroll
+    for (int tn = 0; tn < 2 * NJ; ++tn) f(tn, tn * 4 + l4);
+  }
   template <int HALF, class F>
   __device__ __forceinline__ void each(F&& f) const {
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -199,7 +218,7 @@ struct Acc16 {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = a[tm][tn][e];
-        f(tm * 16 + l15, tn * 4 + l4, v);
+        f(tm * 16 + l15, tn * 4 + l4, v, tn);
         if constexpr (kFence) __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -217,9 +236,12 @@ template <class ACC>
 __device__ __forceinline__ void qkv_relayout_stage(const GemmProblem& P, const ACC& acc, char* smem, int n0, int wave, int lane) {
   const int wm = wave >> 2, wn = wave & 3;
   const int part = n0 / P.qk_D;                     // 0 q, 1 k, 2 v
-  auto biased = [&](int n, float (&v)[4]) {
+  // the lane's kSlots bias groups, fetched once (see the accumulator views)
+  uint2 bc[ACC::kSlots];
+  if (P.bias) acc.cols([&](int slot, int c) { bc[slot] = *reinterpret_cast<const uint2*>(P.bias + n0 + wn * 64 + 4 * c); });
+  auto biased = [&](int slot, float (&v)[4]) {
     if (P.bias) {
-      const uint2 b = *reinterpret_cast<const uint2*>(P.bias + n);
+      const uint2 b = bc[slot];
       v[0] += bf16_to_f32((bf16_t)(b.x & 0xffff));
       v[1] += bf16_to_f32((bf16_t)(b.x >> 16));
       v[2] += bf16_to_f32((bf16_t)(b.y & 0xffff));
@@ -229,9 +251,8 @@ __device__ __forceinline__ void qkv_relayout_stage(const GemmProblem& P, const A
   if (part < 2) {
     // ---- stage the bf16 tile in the wave-private swizzled regions of the normal store path
     char* cw = smem + wave * 16384;
-    const int ncol0 = n0 + wn * 64;
-    acc.template each<-1>([&](int r, int c, float (&v)[4]) {
-      biased(ncol0 + 4 * c, v);
+    acc.template each<-1>([&](int r, int c, float (&v)[4], int slot) {
+      biased(slot, v);
       *reinterpret_cast<uint2*>(cw + r * 128 + ((c ^ (r & 15)) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     });
   } else {
@@ -239,11 +260,11 @@ __device__ __forceinline__ void qkv_relayout_stage(const GemmProblem& P, const A
     // attention kernel's kv permutation (swap bits 2,3 inside groups of 16) applied to the token
     // index on the way in, so that a row leaves as plain 16-B pieces of consecutive stored positions
     bf16_t* tp = reinterpret_cast<bf16_t*>(smem);
-    acc.template each<-1>([&](int r, int c, float (&v)[4]) {
+    acc.template each<-1>([&](int r, int c, float (&v)[4], int slot) {
       const int tl = wm * 128 + r;
       const int tpos = (tl & ~12) | ((tl & 4) << 1) | ((tl & 8) >> 1);
       const int dc = wn * 64 + 4 * c;
-      biased(n0 + dc, v);
+      biased(slot, v);
 #pragma unroll
       for (int e = 0; e < 4; ++e) tp[(dc + e) * 256 + tpos] = f32_to_bf16(v[e]);
     });
@@ -353,25 +374,21 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, const A
   // ---- epilogue: which rows / 4-column groups a lane holds is the accumulator view's business (Acc32 / Acc16)
   const int epi = P.epi;
   const float alpha = P.alpha;
-  // alpha, bias, activation on 4 consecutive columns starting at n
-  auto finish = [&](int n, float (&v)[4], bool full) {
+  auto add_bias = [](const uint2 b, float (&v)[4]) {
+    v[0] += bf16_to_f32((bf16_t)(b.x & 0xffff));
+    v[1] += bf16_to_f32((bf16_t)(b.x >> 16));
+    v[2] += bf16_to_f32((bf16_t)(b.y & 0xffff));
+    v[3] += bf16_to_f32((bf16_t)(b.y >> 16));
+  };
+  auto scale = [&](float (&v)[4]) {
     if constexpr (ACT == 3 || ACT == -1) {
       if (epi == EPI_STORE_F32 || epi == EPI_SCALE_BF16) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= alpha;
       }
     }
-    if (P.bias) {
-      if (full) {
-        const uint2 b = *reinterpret_cast<const uint2*>(P.bias + n);
-        v[0] += bf16_to_f32((bf16_t)(b.x & 0xffff));
-        v[1] += bf16_to_f32((bf16_t)(b.x >> 16));
-        v[2] += bf16_to_f32((bf16_t)(b.y & 0xffff));
-        v[3] += bf16_to_f32((bf16_t)(b.y >> 16));
-      } else {
-        for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(P.bias[n + e]);
-      }
-    }
+  };
+  auto activate = [&](int n, float (&v)[4]) {
     if constexpr (ACT == -1) {
       if (epi == EPI_GELU_BF16 || (epi == EPI_GELU_FROM_COL && n >= P.gelu_from)) {
 #pragma unroll
@@ -395,6 +412,18 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, const A
       }
     }
   };
+  // alpha, bias, activation on 4 consecutive columns starting at n (direct path: the bias is read per group)
+  auto finish = [&](int n, float (&v)[4], bool full) {
+    scale(v);
+    if (P.bias) {
+      if (full) {
+        add_bias(*reinterpret_cast<const uint2*>(P.bias + n), v);
+      } else {
+        for (int e = 0; e < 4 && n + e < P.N; ++e) v[e] += bf16_to_f32(P.bias[n + e]);
+      }
+    }
+    activate(n, v);
+  };
   const bool f32_out = (epi == EPI_RESID_GATE_F32 || epi == EPI_STORE_F32);
   // Staged path: the C tile goes through LDS (free after the K loop) and leaves as whole 128-B
   // (bf16) / 256-B (f32) row segments with 16-B stores.  Direct per-lane stores touch 32 partial
@@ -405,11 +434,19 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, const A
     __syncthreads();  // every wave is done with the operand tiles
     char* cw = smem + wave * (8192 * NJ);  // wave-private staging region
     const int ncol0 = n0 + wn * 32 * NJ;
+    // the lane's kSlots bias groups in one round trip (see the accumulator views)
+    uint2 bc[ACC::kSlots];
+    if (P.bias) acc.cols([&](int slot, int c) { bc[slot] = *reinterpret_cast<const uint2*>(P.bias + ncol0 + 4 * c); });
+    auto finish_s = [&](int slot, int n, float (&v)[4]) {
+      scale(v);
+      if (P.bias) add_bias(bc[slot], v);
+      activate(n, v);
+    };
     if (!f32_out) {
       constexpr int RB = 64 * NJ;   // bytes per staged row (32*NJ bf16)
       constexpr int NS8 = 8 * NJ;   // 8-byte slots per row
-      acc.template each<-1>([&](int r, int c, float (&v)[4]) {
-        finish(ncol0 + 4 * c, v, true);
+      acc.template each<-1>([&](int r, int c, float (&v)[4], int slot) {
+        finish_s(slot, ncol0 + 4 * c, v);
         *reinterpret_cast<uint2*>(cw + r * RB + ((c ^ (r & (NS8 - 1))) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -437,8 +474,8 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, const A
       auto f32_pass = [&](auto pass_tag) {
         constexpr int pass = decltype(pass_tag)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        acc.template each<pass>([&](int rg, int c, float (&v)[4]) {
-          finish(ncol0 + 4 * c, v, true);
+        acc.template each<pass>([&](int rg, int c, float (&v)[4], int slot) {
+          finish_s(slot, ncol0 + 4 * c, v);
           const int r = rg - pass * 64;  // row inside this 64-row pass
           *reinterpret_cast<float4*>(cw + r * RBF + ((c ^ (r & (NS16 - 1))) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
         });
@@ -492,7 +529,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, const A
     return;
   }
   // ---- direct path (ragged N tile, unaligned output, bf16 residual add)
-  acc.template each<-1>([&](int r, int c, float (&v)[4]) {
+  acc.template each<-1>([&](int r, int c, float (&v)[4], int) {
     const int m = m0 + wm * 128 + r;
     const int n = n0 + wn * 32 * NJ + 4 * c;
     if (m >= P.M || n >= P.N) return;
