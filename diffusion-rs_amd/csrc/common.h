@@ -79,6 +79,10 @@ __device__ __forceinline__ float gelu_tanh(float v) {
   const float e = __builtin_amdgcn_exp2f(v * fmaf(c2, v * v, c1));
   return fmaf(-v, __builtin_amdgcn_rcpf(e + 1.0f), v);
 }
+// 1 / sqrt(mean of squares over the 128 elements of a head + 1e-6): the QkNorm factor (model.rs:186-209) on v_rsq_f32 (1 ulp) —
+// the IEEE sqrt + division pair is ~25 instructions per head row; shared by the stand-alone kernel and the GEMM's fused relayout
+// so that both produce the same bits
+__device__ __forceinline__ float rms_inv128(float ss) { return __builtin_amdgcn_rsqf(ss * (1.0f / 128.0f) + 1e-6f); }
 __device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs (MFMA A/B operand)

@@ -282,56 +282,80 @@ __device__ __forceinline__ void qkv_relayout_emit(const GemmProblem& P, char* sm
     bf16_t* osel = part == 0 ? P.qk_qh : P.qk_kh;
     const uint4 wraw = *reinterpret_cast<const uint4*>(wsel + sub * 8);
     const bf16_t* we = reinterpret_cast<const bf16_t*>(&wraw);
-#pragma unroll 2
-    for (int it = 0; it < 16; ++it) {
-      const int item = wave * 64 + it * 4 + grp;
-      const int r = item >> 1, hh = item & 1;
-      const int m = m0 + r;
-      // source: staging region of wave (r>>7, 2*hh + (sub>>3)), row r&127, 16 B = 8-B slots 2*(sub&7), +1
-      const int rr = r & 127;
-      const char* reg = smem + ((r >> 7) * 4 + 2 * hh + (sub >> 3)) * 16384 + rr * 128;
-      const int sp = ((2 * (sub & 7)) ^ (rr & 15)) & ~1;
-      uint4 raw = *reinterpret_cast<const uint4*>(reg + (sp << 3));
-      if (rr & 1) raw = make_uint4(raw.z, raw.w, raw.x, raw.y);  // odd rows hold the slot pair swapped
-      const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw);
-      float v[8];
-      float ss = 0.f;
+    // GRP rows at a time: their RoPE table entries are requested first (clamped row, no branch between the loads), then the
+    // rows are normalised, rotated and stored — one L2 round trip per GRP rows; written row by row the loads of row i + 1 cannot
+    // move above the store of row i (they may alias for all the compiler knows) and every row pays its own round trip
+    // sample and position of a row: one division per tile (a tile rarely spans more than two samples), not one per row
+    const int b0 = m0 / P.qk_rows;
+    auto locate = [&](int m, int& b, int& pos) {
+      b = b0;
+      int rem = m - b0 * P.qk_rows;
+      while (rem >= P.qk_rows) rem -= P.qk_rows, ++b;
+      pos = P.qk_row_off + rem;
+    };
+    constexpr int GRP = 4;
+#pragma unroll 1
+    for (int it0 = 0; it0 < 16; it0 += GRP) {
+      float4 pc01[GRP], pc23[GRP];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v[i] = bf16_to_f32(e[i]);
-        ss += v[i] * v[i];
-      }
-      ss += __shfl_xor(ss, 1, 64);
-      ss += __shfl_xor(ss, 2, 64);
-      ss += __shfl_xor(ss, 4, 64);
-      ss += __shfl_xor(ss, 8, 64);
-      if (m < P.M) {
-        const int b = m / P.qk_rows, pos = P.qk_row_off + (m - b * P.qk_rows);
+      for (int u = 0; u < GRP; ++u) {
+        const int mc = min(m0 + ((wave * 64 + (it0 + u) * 4 + grp) >> 1), P.M - 1);
+        int b, pos;
+        locate(mc, b, pos);
         const float4* pp = reinterpret_cast<const float4*>(P.qk_pe + (int64_t)b * P.qk_pe_bstride + ((int64_t)pos * 64 + 4 * sub) * 2);
-        const float4 c01 = pp[0], c23 = pp[1];
-        const float cs[4] = {c01.x, c01.z, c23.x, c23.z};
-        const float sn[4] = {c01.y, c01.w, c23.y, c23.w};
-        const float inv = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
-        float rr8[8];
+        pc01[u] = pp[0], pc23[u] = pp[1];
+      }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float x0 = v[2 * p] * inv * bf16_to_f32(we[2 * p]);
-          const float x1 = v[2 * p + 1] * inv * bf16_to_f32(we[2 * p + 1]);
-          rr8[2 * p] = cs[p] * x0 - sn[p] * x1;
-          rr8[2 * p + 1] = sn[p] * x0 + cs[p] * x1;
+      for (int u = 0; u < GRP; ++u) {
+        const int item = wave * 64 + (it0 + u) * 4 + grp;
+        const int r = item >> 1, hh = item & 1;
+        const int m = m0 + r;
+        // source: staging region of wave (r>>7, 2*hh + (sub>>3)), row r&127, 16 B = 8-B slots 2*(sub&7), +1
+        const int rr = r & 127;
+        const char* reg = smem + ((r >> 7) * 4 + 2 * hh + (sub >> 3)) * 16384 + rr * 128;
+        const int sp = ((2 * (sub & 7)) ^ (rr & 15)) & ~1;
+        uint4 raw = *reinterpret_cast<const uint4*>(reg + (sp << 3));
+        if (rr & 1) raw = make_uint4(raw.z, raw.w, raw.x, raw.y);  // odd rows hold the slot pair swapped
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw);
+        float v[8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[i] = bf16_to_f32(e[i]);
+          ss += v[i] * v[i];
         }
-        const int64_t row = ((int64_t)b * P.qk_H + head0 + hh) * P.qk_Ltot + pos;
-        if (P.qk_q8 > 0.f) {  // fp8 attention operands: e4m3(value * static scale), 8 bytes per lane
-          const float sc8 = part == 0 ? P.qk_q8 : P.qk_k8;
-          int lo = 0, hi = 0;
-          lo = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[0] * sc8, rr8[1] * sc8, lo, false);
-          lo = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[2] * sc8, rr8[3] * sc8, lo, true);
-          hi = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[4] * sc8, rr8[5] * sc8, hi, false);
-          hi = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[6] * sc8, rr8[7] * sc8, hi, true);
-          *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(osel) + row * 128 + sub * 8) = make_uint2((uint32_t)lo, (uint32_t)hi);
-        } else {
-          bf16_t* dst = osel + row * 128 + sub * 8;
-          *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(rr8[0], rr8[1]), pack_bf16x2(rr8[2], rr8[3]), pack_bf16x2(rr8[4], rr8[5]), pack_bf16x2(rr8[6], rr8[7]));
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        ss += __shfl_xor(ss, 4, 64);
+        ss += __shfl_xor(ss, 8, 64);
+        if (m < P.M) {
+          int b, pos;
+          locate(m, b, pos);
+          const float4 c01 = pc01[u], c23 = pc23[u];
+          const float cs[4] = {c01.x, c01.z, c23.x, c23.z};
+          const float sn[4] = {c01.y, c01.w, c23.y, c23.w};
+          const float inv = rms_inv128(ss);
+          float rr8[8];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float x0 = v[2 * p] * inv * bf16_to_f32(we[2 * p]);
+            const float x1 = v[2 * p + 1] * inv * bf16_to_f32(we[2 * p + 1]);
+            rr8[2 * p] = cs[p] * x0 - sn[p] * x1;
+            rr8[2 * p + 1] = sn[p] * x0 + cs[p] * x1;
+          }
+          const int64_t row = ((int64_t)b * P.qk_H + head0 + hh) * P.qk_Ltot + pos;
+          if (P.qk_q8 > 0.f) {  // fp8 attention operands: e4m3(value * static scale), 8 bytes per lane
+            const float sc8 = part == 0 ? P.qk_q8 : P.qk_k8;
+            int lo = 0, hi = 0;
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[0] * sc8, rr8[1] * sc8, lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[2] * sc8, rr8[3] * sc8, lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[4] * sc8, rr8[5] * sc8, hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(rr8[6] * sc8, rr8[7] * sc8, hi, true);
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(osel) + row * 128 + sub * 8) = make_uint2((uint32_t)lo, (uint32_t)hi);
+          } else {
+            bf16_t* dst = osel + row * 128 + sub * 8;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(rr8[0], rr8[1]), pack_bf16x2(rr8[2], rr8[3]), pack_bf16x2(rr8[4], rr8[5]), pack_bf16x2(rr8[6], rr8[7]));
+          }
         }
       }
     }
@@ -1000,8 +1024,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
           for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] *= sa[i] * sn[c];
       }
   }
-  if constexpr (FP8) gemm_epilogue<NJ, 4, ACT>(P, Acc32<NJ>{acc, lane}, smem, m0, n0, wave, lane);
-  else gemm_epilogue<NJ, 4, ACT>(P, Acc16<NJ>{acc16, lane}, smem, m0, n0, wave, lane);
+  // the lane id is laundered (as in w4_epilogue): what the epilogue derives from it is then computed here, not hoisted above the
+  // K loop, held across 256 registers of loop state, spilled and reloaded (a scratch reload waits vmcnt(0): the stores serialise)
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  if constexpr (FP8) gemm_epilogue<NJ, 4, ACT>(P, Acc32<NJ>{acc, lane_e}, smem, m0, n0, wave, lane_e);
+  else gemm_epilogue<NJ, 4, ACT>(P, Acc16<NJ>{acc16, lane_e}, smem, m0, n0, wave, lane_e);
 }
 
 

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
     ss += __shfl_xor(ss, 2, 64);
     ss += __shfl_xor(ss, 4, 64);
     ss += __shfl_xor(ss, 8, 64);
-    const float inv = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+    const float inv = rms_inv128(ss);
     uint32_t o[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
