@@ -79,6 +79,26 @@ __device__ __forceinline__ float gelu_tanh(float v) {
   const float e = __builtin_amdgcn_exp2f(v * fmaf(c2, v * v, c1));
   return fmaf(-v, __builtin_amdgcn_rcpf(e + 1.0f), v);
 }
+// The same GELU on two values per instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32; exp2 and rcp stay scalar): component by
+// component the operations of gelu_tanh — mul, fma, mul, exp2, add, rcp, fma — so the results are the same bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_tanh4(float (&v)[4]) {
+  const float c1 = 2.0f * 0.79788456080286535587989211986876373f * 1.44269504088896340736f;
+  const float c2 = c1 * 0.044715f;
+  const f32x2 k1 = {c1, c1}, k2 = {c2, c2}, one = {1.0f, 1.0f};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x2 x = {v[2 * h], v[2 * h + 1]};
+    f32x2 t = x * x;
+    t = __builtin_elementwise_fma(k2, t, k1);
+    t = x * t;
+    f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    e = e + one;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    const f32x2 o = __builtin_elementwise_fma(-x, r, x);
+    v[2 * h] = o.x, v[2 * h + 1] = o.y;
+  }
+}
 // 1 / sqrt(mean of squares over the 128 elements of a head + 1e-6): the QkNorm factor (model.rs:186-209) on v_rsq_f32 (1 ulp) —
 // the IEEE sqrt + division pair is ~25 instructions per head row; shared by the stand-alone kernel and the GEMM's fused relayout
 // so that both produce the same bits

@@ -89,13 +89,18 @@ __global__ __launch_bounds__(256) void layernorm_mod_fp8_kernel(const float* __r
   const int row = blockIdx.x;
   const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
   const int nv = D >> 2;
-  float4 v[LN_MAXV];
+  float4 v[LN_MAXV], ksc[LN_MAXV], ksh[LN_MAXV];
   float s = 0.f, s2 = 0.f;
+  const int batch = rows_per_batch > 0 ? row / rows_per_batch : 0;
+  const float4* sc = scale ? reinterpret_cast<const float4*>(scale + (int64_t)batch * mod_bstride) : nullptr;
+  const float4* sh = shift ? reinterpret_cast<const float4*>(shift + (int64_t)batch * mod_bstride) : nullptr;
 #pragma unroll
   for (int c = 0; c < LN_MAXV; ++c) {
     const int i = threadIdx.x + c * 256;
     if (i < nv) {
       v[c] = xr[i];
+      if (sc) ksc[c] = sc[i];  // requested with the row: their latency hides behind the reduction
+      if (sh) ksh[c] = sh[i];
       s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
       s2 += (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w);
     }
@@ -113,9 +118,6 @@ __global__ __launch_bounds__(256) void layernorm_mod_fp8_kernel(const float* __r
   const float mean = s / (float)D;
   const float var = s2 / (float)D - mean * mean;
   const float inv_std = 1.0f / sqrtf(var + eps);
-  const int batch = rows_per_batch > 0 ? row / rows_per_batch : 0;
-  const float4* sc = scale ? reinterpret_cast<const float4*>(scale + (int64_t)batch * mod_bstride) : nullptr;
-  const float4* sh = shift ? reinterpret_cast<const float4*>(shift + (int64_t)batch * mod_bstride) : nullptr;
   float am = 0.f;
 #pragma unroll
   for (int c = 0; c < LN_MAXV; ++c) {
@@ -123,11 +125,11 @@ __global__ __launch_bounds__(256) void layernorm_mod_fp8_kernel(const float* __r
     if (i < nv) {
       float a = (v[c].x - mean) * inv_std, b = (v[c].y - mean) * inv_std, cc = (v[c].z - mean) * inv_std, d = (v[c].w - mean) * inv_std;
       if (sc) {
-        const float4 k = sc[i];
+        const float4 k = ksc[c];
         a *= (k.x + 1.0f), b *= (k.y + 1.0f), cc *= (k.z + 1.0f), d *= (k.w + 1.0f);
       }
       if (sh) {
-        const float4 k = sh[i];
+        const float4 k = ksh[c];
         a += k.x, b += k.y, cc += k.z, d += k.w;
       }
       v[c] = make_float4(a, b, cc, d);

@@ -412,23 +412,21 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, const A
       }
     }
   };
+  const int tile_gelu = n0 >= P.gelu_from ? 1 : (n0 + BN <= P.gelu_from ? -1 : 0);  // all / none / mixed (ACT == 2)
   auto activate = [&](int n, float (&v)[4]) {
     if constexpr (ACT == -1) {
       if (epi == EPI_GELU_BF16 || (epi == EPI_GELU_FROM_COL && n >= P.gelu_from)) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+        gelu_tanh4(v);
       } else if (epi == EPI_SILU_BF16) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
       }
     } else if constexpr (ACT == 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+      gelu_tanh4(v);
     } else if constexpr (ACT == 2) {
-      if (n >= P.gelu_from) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-      }
+      // whole tiles lie on one side of gelu_from in the model's launches (a multiple of the tile width): decided per tile, the
+      // per-lane comparison only where a tile straddles it
+      if (tile_gelu > 0 || (tile_gelu == 0 && n >= P.gelu_from)) gelu_tanh4(v);
     } else if constexpr (ACT == 3) {
       if (epi == EPI_SILU_BF16) {
 #pragma unroll
@@ -459,11 +457,29 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmProblem& P, const A
     char* cw = smem + wave * (8192 * NJ);  // wave-private staging region
     const int ncol0 = n0 + wn * 32 * NJ;
     // the lane's kSlots bias groups in one round trip (see the accumulator views)
-    uint2 bc[ACC::kSlots];
-    if (P.bias) acc.cols([&](int slot, int c) { bc[slot] = *reinterpret_cast<const uint2*>(P.bias + ncol0 + 4 * c); });
+    // — zeros without a bias, so that the add is unconditional; with few slots (16 x 16 accumulators) also widened to f32 once
+    // (no unpacking per group), with more (32 x 32) kept packed: the wider cache would spill next to 128 live accumulators
+    constexpr bool WIDE = ACC::kSlots <= 4;
+    uint2 bc[WIDE ? 1 : ACC::kSlots];
+    float bf[WIDE ? ACC::kSlots : 1][4];
+    acc.cols([&](int slot, int c) {
+      uint2 b = make_uint2(0u, 0u);
+      if (P.bias) b = *reinterpret_cast<const uint2*>(P.bias + ncol0 + 4 * c);
+      if constexpr (WIDE) {
+        bf[slot][0] = bf16_to_f32((bf16_t)(b.x & 0xffff)), bf[slot][1] = bf16_to_f32((bf16_t)(b.x >> 16));
+        bf[slot][2] = bf16_to_f32((bf16_t)(b.y & 0xffff)), bf[slot][3] = bf16_to_f32((bf16_t)(b.y >> 16));
+      } else {
+        bc[slot] = b;
+      }
+    });
     auto finish_s = [&](int slot, int n, float (&v)[4]) {
       scale(v);
-      if (P.bias) add_bias(bc[slot], v);
+      if constexpr (WIDE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bf[slot][e];
+      } else {
+        add_bias(bc[slot], v);
+      }
       activate(n, v);
     };
     if (!f32_out) {

@@ -22,8 +22,11 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
   const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
   const int nv = D >> 2;
   constexpr int MAXV = 4;
-  float4 keep[MAXV];
+  float4 keep[MAXV], ksc[MAXV], ksh[MAXV];
   float s = 0.f, s2 = 0.f;
+  const int batch = rows_per_batch > 0 ? row / rows_per_batch : 0;
+  const float4* sc = scale ? reinterpret_cast<const float4*>(scale + (int64_t)batch * mod_bstride) : nullptr;
+  const float4* sh = shift ? reinterpret_cast<const float4*>(shift + (int64_t)batch * mod_bstride) : nullptr;
   if constexpr (REG) {
 #pragma unroll
     for (int c = 0; c < MAXV; ++c) {
@@ -31,6 +34,9 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
       if (i < nv) {
         const float4 v = xr[i];
         keep[c] = v;
+        // the modulation vectors are requested with the row, not after the reduction (their latency hides behind it)
+        if (sc) ksc[c] = sc[i];
+        if (sh) ksh[c] = sh[i];
         s += (v.x + v.y) + (v.z + v.w);
         s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
       }
@@ -55,21 +61,18 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
   const float mean = s / (float)D;
   const float var = s2 / (float)D - mean * mean;  // E[x^2]-mean^2, as nn/ops.rs:1029-1031
   const float inv_std = 1.0f / sqrtf(var + eps);
-  const int batch = rows_per_batch > 0 ? row / rows_per_batch : 0;
-  const float4* sc = scale ? reinterpret_cast<const float4*>(scale + (int64_t)batch * mod_bstride) : nullptr;
-  const float4* sh = shift ? reinterpret_cast<const float4*>(shift + (int64_t)batch * mod_bstride) : nullptr;
   uint2* o = reinterpret_cast<uint2*>(out + (int64_t)row * D);
-  auto emit = [&](int i, const float4 v) {
+  auto emit = [&](int i, const float4 v, const float4 ksc_i, const float4 ksh_i) {
     float a = (v.x - mean) * inv_std, b = (v.y - mean) * inv_std, c = (v.z - mean) * inv_std, d = (v.w - mean) * inv_std;
     if (sc) {
-      const float4 k = sc[i];
+      const float4 k = ksc_i;
       a *= (k.x + 1.0f);
       b *= (k.y + 1.0f);
       c *= (k.z + 1.0f);
       d *= (k.w + 1.0f);
     }
     if (sh) {
-      const float4 k = sh[i];
+      const float4 k = ksh_i;
       a += k.x;
       b += k.y;
       c += k.z;
@@ -81,10 +84,11 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restr
 #pragma unroll
     for (int c = 0; c < MAXV; ++c) {
       const int i = threadIdx.x + c * 256;
-      if (i < nv) emit(i, keep[c]);
+      if (i < nv) emit(i, keep[c], ksc[c], ksh[c]);
     }
   } else {
-    for (int i = threadIdx.x; i < nv; i += 256) emit(i, xr[i]);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x; i < nv; i += 256) emit(i, xr[i], sc ? sc[i] : z, sh ? sh[i] : z);
   }
 }
 
