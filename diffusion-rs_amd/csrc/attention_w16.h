@@ -62,37 +62,6 @@ __global__ __launch_bounds__(AW16_THREADS, 1) void attention_w16_kernel(const bf
   typedef int i32x16 __attribute__((ext_vector_type(16)));
   typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-  // ---- Q fragments (MFMA B operand, rows = d): QF[b][c][s] = bf16(Q[q0 + 32 b + 16 c + n][32 s + 8 g .. + 7] * scale * log2(e));
-  // fp8: QF8[b][c] = the 32 bytes Q8[q][32 g .. + 31] as they are (the scale rides in the MFMA's block scale)
-  i32x32 QA[2];
-#pragma unroll
-  for (int r = 0; r < 32; ++r) QA[1][r] = 0;
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int qr = min(q0 + 32 * b + 16 * c + n16, Lq - 1);
-      if constexpr (QK8) {
-        const char* qp = reinterpret_cast<const char*>(Q) + ((int64_t)bh * Lq + qr) * 128 + 32 * g;
-        const uint4 lo = *reinterpret_cast<const uint4*>(qp), hi = *reinterpret_cast<const uint4*>(qp + 16);
-        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) QA[0][(2 * b + c) * 8 + e] = (int)w[e];
-      } else {
-        const bf16_t* qp = Q + ((int64_t)bh * Lq + qr) * HD + 8 * g;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const uint4 raw = *reinterpret_cast<const uint4*>(qp + 32 * s);
-          const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float lo = __uint_as_float(w[e] << 16) * scale_log2e, hi = __uint_as_float(w[e] & 0xffff0000u) * scale_log2e;
-            QA[b][(c * 4 + s) * 4 + e] = (int)pack_bf16x2(lo, hi);
-          }
-        }
-      }
-    }
-
   // ---- LDS-DMA: 16 one-KiB chunks per tile and operand, 4 per wave.  Destination is lane-linear, the swizzle sits in the source
   // offsets (loop invariants); a tile index past the end is clamped in the stream (the last tile is fetched again: identical bytes).
   i32x16 R0, R1;
@@ -171,6 +140,39 @@ __global__ __launch_bounds__(AW16_THREADS, 1) void attention_w16_kernel(const bf
 #pragma unroll
       for (int i = 0; i < 4; ++i) stage_v(t, i);
     }
+  __builtin_amdgcn_sched_barrier(0);
+  // (after the first DMA pieces have been issued: the loads and the scale-and-round of Q run while those are in flight)
+  // ---- Q fragments (MFMA B operand, rows = d): QF[b][c][s] = bf16(Q[q0 + 32 b + 16 c + n][32 s + 8 g .. + 7] * scale * log2(e));
+  // fp8: QF8[b][c] = the 32 bytes Q8[q][32 g .. + 31] as they are (the scale rides in the MFMA's block scale)
+  i32x32 QA[2];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) QA[1][r] = 0;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int qr = min(q0 + 32 * b + 16 * c + n16, Lq - 1);
+      if constexpr (QK8) {
+        const char* qp = reinterpret_cast<const char*>(Q) + ((int64_t)bh * Lq + qr) * 128 + 32 * g;
+        const uint4 lo = *reinterpret_cast<const uint4*>(qp), hi = *reinterpret_cast<const uint4*>(qp + 16);
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) QA[0][(2 * b + c) * 8 + e] = (int)w[e];
+      } else {
+        const bf16_t* qp = Q + ((int64_t)bh * Lq + qr) * HD + 8 * g;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const uint4 raw = *reinterpret_cast<const uint4*>(qp + 32 * s);
+          const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(w[e] << 16) * scale_log2e, hi = __uint_as_float(w[e] & 0xffff0000u) * scale_log2e;
+            QA[b][(c * 4 + s) * 4 + e] = (int)pack_bf16x2(lo, hi);
+          }
+        }
+      }
+    }
+
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
