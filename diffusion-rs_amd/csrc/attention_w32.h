@@ -39,11 +39,9 @@ __global__ __launch_bounds__(AW32_THREADS, 1) void attention_w32_kernel(const bf
   const bf16_t* Vb = Vt + (int64_t)bh * HD * Lkpad;
   const int ntiles = (Lk + ATT_KV - 1) / ATT_KV;  // >= 2 (the launcher sends single-tile problems to the 8-wave kernel)
 
-  typedef __attribute__((ext_vector_type(4))) int frag_t;
   typedef float f32x32 __attribute__((ext_vector_type(32)));
   typedef int i32x32 __attribute__((ext_vector_type(32)));
   typedef int i32x16 __attribute__((ext_vector_type(16)));
-  typedef int i32x8 __attribute__((ext_vector_type(8)));
 
   // ---- Q fragments (MFMA B operand): QF[b][s] = bf16(Q[q0 + 32 b + l31][16 s + 8 hl .. + 7] * scale * log2(e))
   i32x32 QA[2];

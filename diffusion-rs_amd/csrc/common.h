@@ -103,7 +103,9 @@ __device__ __forceinline__ void gelu_tanh4(float (&v)[4]) {
 // the IEEE sqrt + division pair is ~25 instructions per head row; shared by the stand-alone kernel and the GEMM's fused relayout
 // so that both produce the same bits
 __device__ __forceinline__ float rms_inv128(float ss) { return __builtin_amdgcn_rsqf(ss * (1.0f / 128.0f) + 1e-6f); }
-__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+// v sigmoid(v) on v_exp_f32 + v_rcp_f32 (1 ulp each; the IEEE division it replaces is ~10 instructions, and the VAE's GroupNorm + SiLU
+// passes over up to 134 M elements are ALU-bound)
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f)); }
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 4 VGPRs (MFMA A/B operand)
 typedef __attribute__((ext_vector_type(4))) float f32x4;

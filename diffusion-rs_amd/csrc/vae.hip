@@ -49,9 +49,16 @@ __global__ void conv_weight_relayout_kernel(const bf16_t* __restrict w, bf16_t* 
 }
 
 // ---------------------------------------------------------------- GroupNorm (NHWC)
-constexpr int GN_PIX_PER_BLOCK = 1024;
+// pixels per statistics block: about a thousand blocks per sample at every resolution of the decoder (a fixed 1024 pixels left the
+// 128 x 128 stages of a 1024 x 1024 decode on 16 of the 256 CUs)
+static inline int gn_pix_per_block(int HW) {
+  const int p = HW / 1024;
+  return p < 32 ? 32 : (p > 1024 ? 1024 : p);
+}
+static inline int gn_chunks(int HW) { return cdiv(HW, gn_pix_per_block(HW)); }
+static inline int gn_max_chunks(int HW) { return std::max(2048, cdiv(HW, 1024)); }  // bound of gn_chunks over every HW' <= HW
 // partial[(b*nchunks + chunk)*G + g] = {sum, sumsq} over the chunk's pixels; requires C%8==0, cpg%4==0
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict x, float2* __restrict partial, int HW, int C, int G) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict x, float2* __restrict partial, int HW, int C, int G, int ppb) {
   __shared__ float4 part[256];  // per-thread {sum_lo, sumsq_lo, sum_hi, sumsq_hi} (channels 0-3 / 4-7 of its 8)
   const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
   const int tpp = C >> 3;  // threads per pixel
@@ -59,9 +66,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict 
   const int c8 = threadIdx.x % tpp;
   const int pstep = 256 / tpp;
   const int nact = tpp * pstep;
-  const int p0 = chunk * GN_PIX_PER_BLOCK, p1 = min(HW, p0 + GN_PIX_PER_BLOCK);
+  const int p0 = chunk * ppb, p1 = min(HW, p0 + ppb);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
   if ((int)threadIdx.x < nact) {
+#pragma unroll 4  // four 16-byte loads in flight per thread (one per iteration left the kernel latency-bound at 1.5 TB/s)
     for (int p = p0 + threadIdx.x / tpp; p < p1; p += pstep) {
       const uint4 raw = *reinterpret_cast<const uint4*>(x + ((int64_t)b * HW + p) * C + c8 * 8);
       const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw);
@@ -81,36 +89,51 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict 
   }
   part[threadIdx.x] = make_float4(s0, q0, s1, q1);
   __syncthreads();
-  // fixed-order combine (no atomics: results are bit-reproducible run to run)
+  // fixed-order combine (no atomics: results are bit-reproducible run to run), in two steps: the pstep threads that share a channel
+  // octet, then the octet halves of a group — 32 threads each scanning all 256 partials (the first version) cost more than the loads
+  if ((int)threadIdx.x < tpp) {
+    float4 a = part[threadIdx.x];
+    for (int k = 1; k < pstep; ++k) {
+      const float4 v = part[threadIdx.x + k * tpp];
+      a.x += v.x, a.y += v.y, a.z += v.z, a.w += v.w;
+    }
+    part[threadIdx.x] = a;
+  }
+  __syncthreads();
   for (int g = threadIdx.x; g < G; g += 256) {
     float s = 0.f, q = 0.f;
-    for (int t = 0; t < nact; ++t) {
-      const int tc = (t % tpp) * 8;
-      const float4 v = part[t];
-      if (tc / cpg == g) {
-        s += v.x;
-        q += v.y;
-      }
-      if ((tc + 4) / cpg == g) {
-        s += v.z;
-        q += v.w;
-      }
+    for (int o = (g * cpg) >> 3; o <= ((g + 1) * cpg - 1) >> 3; ++o) {
+      const float4 v = part[o];
+      if ((o * 8) / cpg == g) s += v.x, q += v.y;
+      if ((o * 8 + 4) / cpg == g) s += v.z, q += v.w;
     }
     partial[((int64_t)b * nchunks + chunk) * G + g] = make_float2(s, q);
   }
 }
-// stats[b*G+g] = {mean, 1/sqrt(var+eps)}; f64 combine of the f32 partials
-__global__ void gn_finalize_kernel(const float2* __restrict partial, float2* __restrict stats, int nchunks, int G, double count, float eps) {
-  const int b = blockIdx.x;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    double s = 0.0, q = 0.0;
-    for (int c = 0; c < nchunks; ++c) {
-      const float2 v = partial[((int64_t)b * nchunks + c) * G + g];
-      s += v.x;
-      q += v.y;
+// stats[b*G+g] = {mean, 1/sqrt(var+eps)}; f64 combine of the f32 partials.  One 256-thread block per (group, sample): at 1024 x 1024 a
+// group has 4096 partials, and one thread walking them (the first version) is 4096 dependent loads = 250 us for a 32 KB reduction.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restrict partial, float2* __restrict stats, int nchunks, int G, double count, float eps) {
+  __shared__ double red[2][256];
+  const int g = blockIdx.x, b = blockIdx.y;
+  double s = 0.0, q = 0.0;
+  for (int c = threadIdx.x; c < nchunks; c += 256) {
+    const float2 v = partial[((int64_t)b * nchunks + c) * G + g];
+    s += v.x;
+    q += v.y;
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {  // fixed tree: the same sums in the same order on every run
+    if ((int)threadIdx.x < w) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + w];
+      red[1][threadIdx.x] += red[1][threadIdx.x + w];
     }
-    const double mean = s / count;
-    double var = q / count - mean * mean;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mean = red[0][0] / count;
+    double var = red[1][0] / count - mean * mean;
     var = var < 0.0 ? 0.0 : var;
     stats[b * G + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
   }
@@ -119,17 +142,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict 
                                                        const float* __restrict bia, bf16_t* __restrict out, int HW, int C, int G, int silu_on,
                                                        int64_t nvec) {
   const int tpp = C >> 3, cpg = C / G;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // a thread keeps its 8 channels for the whole grid-stride walk whenever the stride is a multiple of the threads per pixel (every
+  // FLUX width: C / 8 divides 256): the affine weights are then loop invariants instead of four dependent loads per 16 bytes of x
+  const bool fixed = stride % tpp == 0;
+  float ww[8], bb[8];
+  auto load_affine = [&](int c8) {
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c8 * 8), w1 = *reinterpret_cast<const float4*>(w + c8 * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(bia + c8 * 8), b1 = *reinterpret_cast<const float4*>(bia + c8 * 8 + 4);
+    ww[0] = w0.x, ww[1] = w0.y, ww[2] = w0.z, ww[3] = w0.w, ww[4] = w1.x, ww[5] = w1.y, ww[6] = w1.z, ww[7] = w1.w;
+    bb[0] = b0.x, bb[1] = b0.y, bb[2] = b0.z, bb[3] = b0.w, bb[4] = b1.x, bb[5] = b1.y, bb[6] = b1.z, bb[7] = b1.w;
+  };
+  if (fixed && i0 < nvec) load_affine((int)(i0 % tpp));
+#pragma unroll 2
+  for (int64_t i = i0; i < nvec; i += stride) {
     const int c8 = (int)(i % tpp);
     const int64_t p = i / tpp;
     const int b = (int)(p / HW);
     const uint4 raw = *reinterpret_cast<const uint4*>(x + i * 8);
     const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw);
     const float2 st0 = stats[b * G + (c8 * 8) / cpg], st1 = stats[b * G + (c8 * 8 + 4) / cpg];
-    const float4 w0 = *reinterpret_cast<const float4*>(w + c8 * 8), w1 = *reinterpret_cast<const float4*>(w + c8 * 8 + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(bia + c8 * 8), b1 = *reinterpret_cast<const float4*>(bia + c8 * 8 + 4);
-    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    if (!fixed) load_affine(c8);
     float v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -145,9 +179,9 @@ int launch_groupnorm_nhwc(const bf16_t* x, const float* w, const float* b, bf16_
                           float2* partial, float2* stats, hipStream_t s) {
   if (C % 8 || C % G || (C / G) % 4) return fail(FMI_ERR_UNSUPPORTED, "groupnorm: needs C % 8 == 0 and (C/groups) % 4 == 0");
   if (C / 8 > 256) return fail(FMI_ERR_UNSUPPORTED, "groupnorm: C > 2048 not supported");
-  const int nchunks = cdiv(HW, GN_PIX_PER_BLOCK);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, x, partial, HW, C, G);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, partial, stats, nchunks, G, (double)HW * (C / G), eps);
+  const int nchunks = gn_chunks(HW);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, x, partial, HW, C, G, gn_pix_per_block(HW));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, s, partial, stats, nchunks, G, (double)HW * (C / G), eps);
   const int64_t nvec = (int64_t)B * HW * (C / 8);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(nvec, 256), 256 * 16)), dim3(256), 0, s, x, stats, w, b, out, HW, C, G,
                      silu_on, nvec);
@@ -330,7 +364,7 @@ int vae_workspace(fmi_vae* v, int B, int h, int w) {
   const size_t hw = (size_t)h * w;
   const size_t score_bytes = c.mid_block_add_attention ? (hw * hw * 2 + 255) / 256 * 256 : 256;
   const int G = c.norm_num_groups;
-  const size_t part_bytes = ((size_t)B * cdiv((int)((size_t)H * W), GN_PIX_PER_BLOCK) * G * sizeof(float2) + 255) / 256 * 256;
+  const size_t part_bytes = ((size_t)B * gn_max_chunks((int)((size_t)H * W)) * G * sizeof(float2) + 255) / 256 * 256;
   const size_t stat_bytes = ((size_t)B * G * sizeof(float2) + 255) / 256 * 256;
   const size_t total = 4 * act_bytes + score_bytes + part_bytes + stat_bytes;
   if (v->ws) {
@@ -704,7 +738,7 @@ extern "C" int fmi_groupnorm_nhwc(const void* x_bf16, const float* weight, const
   if (!x_bf16 || !weight || !bias || !out_bf16) return fail(FMI_ERR_INVALID, "groupnorm_nhwc: null pointer");
   hipStream_t s = (hipStream_t)stream;
   float2* tmp = nullptr;
-  const int nchunks = cdiv(HW, GN_PIX_PER_BLOCK);
+  const int nchunks = gn_chunks(HW);
   FMI_HIP_TRY(hipMalloc((void**)&tmp, ((size_t)B * nchunks * groups + (size_t)B * groups) * sizeof(float2)));
   int rc = launch_groupnorm_nhwc((const bf16_t*)x_bf16, weight, bias, (bf16_t*)out_bf16, B, HW, C, groups, eps, fuse_silu, tmp,
                                  tmp + (size_t)B * nchunks * groups, s);
