@@ -1,5 +1,6 @@
 // common.h — shared device/host helpers for libflux_mi355x (gfx950 / CDNA4 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -98,6 +99,20 @@ __device__ __forceinline__ void gelu_tanh4(float (&v)[4]) {
     const f32x2 o = __builtin_elementwise_fma(-x, r, x);
     v[2 * h] = o.x, v[2 * h + 1] = o.y;
   }
+}
+// Sum over the 16 lanes of a DPP row, every lane receiving the total, on the VALU (quad_perm, row_half_mirror, row_mirror) instead
+// of four dependent ds_bpermute round trips: the same additions in the same order as the __shfl_xor(1, 2, 4, 8) tree — after the
+// two quad steps a quad's lanes agree, so mirroring inside 8 / 16 lanes fetches what lane ^ 4 / lane ^ 8 holds — hence the same bits.
+__device__ __forceinline__ float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl_tag) {
+    constexpr int ctrl = decltype(ctrl_tag)::value;
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]  = lane ^ 1
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]  = lane ^ 2
+  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror      ~ lane ^ 4 (quads agree)
+  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror           ~ lane ^ 8 (halves agree)
+  return v;
 }
 // 1 / sqrt(mean of squares over the 128 elements of a head + 1e-6): the QkNorm factor (model.rs:186-209) on v_rsq_f32 (1 ulp) —
 // the IEEE sqrt + division pair is ~25 instructions per head row; shared by the stand-alone kernel and the GEMM's fused relayout

@@ -324,10 +324,7 @@ __device__ __forceinline__ void qkv_relayout_emit(const GemmProblem& P, char* sm
           v[i] = bf16_to_f32(e[i]);
           ss += v[i] * v[i];
         }
-        ss += __shfl_xor(ss, 1, 64);
-        ss += __shfl_xor(ss, 2, 64);
-        ss += __shfl_xor(ss, 4, 64);
-        ss += __shfl_xor(ss, 8, 64);
+        ss = row16_sum(ss);
         if (m < P.M) {
           int b, pos;
           locate(m, b, pos);

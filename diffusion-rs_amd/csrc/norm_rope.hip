@@ -140,10 +140,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
       v[i] = bf16_to_f32(e[i]);
       ss += v[i] * v[i];
     }
-    ss += __shfl_xor(ss, 1, 64);
-    ss += __shfl_xor(ss, 2, 64);
-    ss += __shfl_xor(ss, 4, 64);
-    ss += __shfl_xor(ss, 8, 64);
+    ss = row16_sum(ss);
     const float inv = rms_inv128(ss);
     uint32_t o[4];
 #pragma unroll

@@ -51,6 +51,31 @@ def test_linear_bf16(env, M, N, K, epi, bias):
     assert rel_l2(got, ref) <= 4e-3
 
 
+@pytest.mark.parametrize("epi,M,N", [(1, 256, 64), (2, 256, 64), (1, 512, 256)])  # 256-wide: the ping-pong kernel's packed-pair GELU epilogue
+def test_activation_epilogues_over_the_whole_range(env, epi, M, N):
+    """GELU (v - v / (2^z + 1), `gelu_tanh` / `gelu_tanh4`) and SiLU (`v_rcp_f32` form) through an identity weight: exact zeros,
+    the saturating tails on both sides, tiny and huge magnitudes — element by element against the oracle (core/op.rs:539-582,
+    699-721, f32 arm) within one bf16 ulp of the result, finite for every finite input."""
+    torch, L, lib, orc = env["torch"], env["L"], env["lib"], env["orc"]
+    K = N
+    special = np.array([0.0, -0.0, 1e-30, -1e-30, 1e-3, -1e-3, 0.5, -0.5, 1, -1, 2.5, -2.5, 4, -4, 6, -6, 9, -9, 17, -17, 40, -40, 100, -100,
+                        1e4, -1e4, 3e38, -3e38], dtype=np.float32)
+    rng = np.random.default_rng(epi)
+    x = bf16_round(np.concatenate([np.tile(special, (M * K) // (2 * special.size)),
+                                   (rng.standard_normal(M * K - special.size * ((M * K) // (2 * special.size))) * 3).astype(np.float32)]).reshape(M, K))
+    w = np.eye(N, K, dtype=np.float32)
+    ref = orc.gelu(x) if epi == 1 else orc.silu(x)
+    xd, wd = dev(x, torch.bfloat16), dev(w, torch.bfloat16)
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.fmi_linear_bf16(_p(xd), _p(wd), None, _p(y), M, N, K, epi, None))
+    torch.cuda.synchronize()
+    got = host(y)
+    assert np.isfinite(got).all()
+    tol = np.maximum(np.abs(ref) * 2.0 ** -7, 1e-6)  # one bf16 ulp (8 significant bits) of the reference, absolute floor for the vanishing tail
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), (x[bad][:8], got[bad][:8], ref[bad][:8])
+
+
 def test_linear_rejects_bad_k(env):
     torch, L, lib = env["torch"], env["L"], env["lib"]
     x = torch.zeros((8, 100), dtype=torch.bfloat16, device="cuda")
@@ -243,7 +268,9 @@ def test_randn_is_seeded_normal(env):
     assert not np.array_equal(a[0], a[1])
 
 
-@pytest.mark.parametrize("C,G,HW,silu", [(64, 16, 100, 0), (128, 32, 4096, 1), (512, 32, 300, 1)])
+# (96, 8, 37 * 53): 12 threads per pixel do not divide the grid stride (the per-iteration affine path of gn_apply) and the pixel count
+# is not a multiple of the statistics chunk; (128, 32, 70001): many ragged chunks through the two-step combine and the parallel finalize
+@pytest.mark.parametrize("C,G,HW,silu", [(64, 16, 100, 0), (128, 32, 4096, 1), (512, 32, 300, 1), (96, 8, 37 * 53, 1), (128, 32, 70001, 0)])
 def test_groupnorm_nhwc(env, C, G, HW, silu):
     torch, L, lib, orc = env["torch"], env["L"], env["lib"], env["orc"]
     rng = np.random.default_rng(C)
