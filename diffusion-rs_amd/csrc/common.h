@@ -275,6 +275,13 @@ int launch_rope_table(const float* txt_ids, const float* img_ids, int B, int T, 
                       int theta, float* pe, hipStream_t stream);
 // LayerNorm(no affine) * (1+scale) + shift; x f32 (rows, D) -> bf16. scale/shift per batch
 // (vector + batch*mod_bstride), batch = row / rows_per_batch.
+// two row sets in one launch (the image and text streams of a double block); rows2 = 0: one set
+int launch_layernorm_mod2(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch, bf16_t* out, int rows,
+                          const float* x2, const float* scale2, const float* shift2, int rows_per_batch2, bf16_t* out2, int rows2, int D, float eps,
+                          hipStream_t stream);
+int launch_layernorm_mod_fp8_2(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch, uint8_t* out,
+                               float* out_scale, int rows, const float* x2, const float* scale2, const float* shift2, int rows_per_batch2, uint8_t* out2,
+                               float* out_scale2, int rows2, int D, float eps, hipStream_t stream);
 int launch_layernorm_mod(const float* x, const float* scale, const float* shift, int mod_bstride,
                          int rows_per_batch, bf16_t* out, int rows, int D, float eps, hipStream_t stream);
 // y(M,N) f32 (+)= act_in(x(M,K) f32) W(N,K)^T bf16 + bias bf16 ; M <= 8

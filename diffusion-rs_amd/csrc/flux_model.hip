@@ -829,11 +829,10 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     {
       PhaseTimer pt(m, s, PH_LN);
       if (fp8) {
-        FMI_TRY(launch_layernorm_mod_fp8(w.x_img, mi + D, mi, nmod, S, w.a8 + (size_t)BT * D, w.a8s + BT, B * S, D, 1e-6f, s));
-        FMI_TRY(launch_layernorm_mod_fp8(w.x_txt, mt + D, mt, nmod, T, w.a8, w.a8s, B * T, D, 1e-6f, s));
+        FMI_TRY(launch_layernorm_mod_fp8_2(w.x_img, mi + D, mi, nmod, S, w.a8 + (size_t)BT * D, w.a8s + BT, B * S, w.x_txt, mt + D, mt, T, w.a8, w.a8s,
+                                           B * T, D, 1e-6f, s));
       } else {
-        FMI_TRY(launch_layernorm_mod(w.x_img, mi + D, mi, nmod, S, xm_img, B * S, D, 1e-6f, s));
-        FMI_TRY(launch_layernorm_mod(w.x_txt, mt + D, mt, nmod, T, xm_txt, B * T, D, 1e-6f, s));
+        FMI_TRY(launch_layernorm_mod2(w.x_img, mi + D, mi, nmod, S, xm_img, B * S, w.x_txt, mt + D, mt, T, xm_txt, B * T, D, 1e-6f, s));
       }
     }
     {
@@ -892,11 +891,11 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     {
       PhaseTimer pt(m, s, PH_LN);
       if (fp8) {
-        FMI_TRY(launch_layernorm_mod_fp8(w.x_img, mi + 4 * D, mi + 3 * D, nmod, S, w.a8 + (size_t)BT * D, w.a8s + BT, B * S, D, 1e-6f, s));
-        FMI_TRY(launch_layernorm_mod_fp8(w.x_txt, mt + 4 * D, mt + 3 * D, nmod, T, w.a8, w.a8s, B * T, D, 1e-6f, s));
+        FMI_TRY(launch_layernorm_mod_fp8_2(w.x_img, mi + 4 * D, mi + 3 * D, nmod, S, w.a8 + (size_t)BT * D, w.a8s + BT, B * S, w.x_txt, mt + 4 * D,
+                                           mt + 3 * D, T, w.a8, w.a8s, B * T, D, 1e-6f, s));
       } else {
-        FMI_TRY(launch_layernorm_mod(w.x_img, mi + 4 * D, mi + 3 * D, nmod, S, xm_img, B * S, D, 1e-6f, s));
-        FMI_TRY(launch_layernorm_mod(w.x_txt, mt + 4 * D, mt + 3 * D, nmod, T, xm_txt, B * T, D, 1e-6f, s));
+        FMI_TRY(launch_layernorm_mod2(w.x_img, mi + 4 * D, mi + 3 * D, nmod, S, xm_img, B * S, w.x_txt, mt + 4 * D, mt + 3 * D, T, xm_txt, B * T, D,
+                                      1e-6f, s));
       }
     }
     {

@@ -81,12 +81,23 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __
 // them in registers instead.
 constexpr int LN_MAXV = 4;  // float4 per thread held in registers: D <= 256 * 4 * 4 = 4096
 
-__global__ __launch_bounds__(256) void layernorm_mod_fp8_kernel(const float* __restrict x, const float* __restrict scale,
-                                                                const float* __restrict shift, int mod_bstride, int rows_per_batch,
-                                                                uint8_t* __restrict out, float* __restrict out_scale, int D, float eps) {
+__global__ __launch_bounds__(256) void layernorm_mod_fp8_kernel(const float* __restrict x1, const float* __restrict scale1,
+                                                                const float* __restrict shift1, int mod_bstride, int rows_per_batch1,
+                                                                uint8_t* __restrict out1, float* __restrict out_scale1, int D, float eps, int rows1,
+                                                                const float* __restrict x2, const float* __restrict scale2,
+                                                                const float* __restrict shift2, int rows_per_batch2, uint8_t* __restrict out2,
+                                                                float* __restrict out_scale2) {
   __shared__ float red[2][4];
   __shared__ float redm[4];
-  const int row = blockIdx.x;
+  // (a second row set in the same launch, as layernorm_mod_kernel)
+  const bool second = (int)blockIdx.x >= rows1;
+  const int row = second ? blockIdx.x - rows1 : blockIdx.x;
+  const float* x = second ? x2 : x1;
+  const float* scale = second ? scale2 : scale1;
+  const float* shift = second ? shift2 : shift1;
+  const int rows_per_batch = second ? rows_per_batch2 : rows_per_batch1;
+  uint8_t* out = second ? out2 : out1;
+  float* out_scale = second ? out_scale2 : out_scale1;
   const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
   const int nv = D >> 2;
   float4 v[LN_MAXV], ksc[LN_MAXV], ksh[LN_MAXV];
@@ -157,14 +168,20 @@ int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* 
   return FMI_OK;
 }
 
-int launch_layernorm_mod_fp8(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch, uint8_t* out,
-                             float* out_scale, int rows, int D, float eps, hipStream_t stream) {
-  if (rows <= 0) return FMI_OK;
+int launch_layernorm_mod_fp8_2(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch, uint8_t* out,
+                               float* out_scale, int rows, const float* x2, const float* scale2, const float* shift2, int rows_per_batch2, uint8_t* out2,
+                               float* out_scale2, int rows2, int D, float eps, hipStream_t stream) {
+  if (rows + rows2 <= 0) return FMI_OK;
   if (D % 4 || D > 256 * 4 * LN_MAXV) return fail(FMI_ERR_INVALID, "layernorm_mod_fp8: D must be a multiple of 4 and <= 4096");
-  hipLaunchKernelGGL(layernorm_mod_fp8_kernel, dim3(rows), dim3(256), 0, stream, x, scale, shift, mod_bstride, rows_per_batch, out, out_scale, D,
-                     eps);
+  hipLaunchKernelGGL(layernorm_mod_fp8_kernel, dim3(rows + rows2), dim3(256), 0, stream, x, scale, shift, mod_bstride, rows_per_batch, out, out_scale, D,
+                     eps, rows, x2, scale2, shift2, rows_per_batch2, out2, out_scale2);
   FMI_LAUNCH_CHECK();
   return FMI_OK;
+}
+int launch_layernorm_mod_fp8(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch, uint8_t* out,
+                             float* out_scale, int rows, int D, float eps, hipStream_t stream) {
+  return launch_layernorm_mod_fp8_2(x, scale, shift, mod_bstride, rows_per_batch, out, out_scale, rows, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                                    D, eps, stream);
 }
 
 }  // namespace fmi
