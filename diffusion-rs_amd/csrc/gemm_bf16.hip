@@ -38,7 +38,10 @@
 
 namespace fmi {
 
-constexpr int TILE_BAND = 8;  // tile-rows per band of the tile order (see the kernels; 8 measured best)
+// Tile-rows per band of the tile order (see the kernels).  8 is the default (8 x 4 patches per XCD; measured best on the shapes whose
+// tile-row count is a multiple of 8); launch_gemm picks another height per problem when 8 would leave a ragged last band
+// (pick_tile_band: M = 4608 has 18 tile rows -> 6 + 6 + 6 instead of 8 + 8 + 2, -11 % L2-miss bytes).
+constexpr int TILE_BAND = 8;
 constexpr int BM = 256, BK = 64;
 constexpr int GEMM_THREADS = 512;
 constexpr int A_TILE_BYTES = BM * BK * 2;  // 32 KiB
@@ -47,8 +50,20 @@ constexpr int MAX_PROBLEMS = 8;
 struct GemmBatch {
   GemmProblem p[MAX_PROBLEMS];
   int tile_start[MAX_PROBLEMS + 1];
+  int band[MAX_PROBLEMS];  // tile-rows per band of problem i's tile order (pick_tile_band)
   int nprob;
 };
+
+// Logical tile t of a problem -> (tm, tn).  Tiles are numbered band by band (gh tile-rows each), column by column inside a band, so
+// the ~32 consecutive tiles an XCD runs at any time form a compact gh x (32 / gh) patch: gh + 32 / gh distinct A / W panels per K
+// step instead of 33 (L2 hits).  Bijective for any gh >= 1.
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int gh, int& tm, int& tn) {
+  const int band = t / (gh * tiles_n);
+  const int band_h = min(gh, tiles_m - band * gh);
+  const int tin = t - band * gh * tiles_n;
+  tn = tin / band_h;
+  tm = band * gh + tin % band_h;
+}
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -637,13 +652,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   const int t = lid - batch.tile_start[pi];
   const int tiles_m = (P.M + BM - 1) / BM;
   const int tiles_n = (P.N + BN - 1) / BN;
-  // Logical ids walk bands of GH tile-rows column by column, so the ~32 tiles an XCD runs at any
-  // time form a compact GH x 4 patch: 12 distinct A/W panels per K step instead of 20 (L2 hits).
-  constexpr int GH = TILE_BAND;
-  const int band = t / (GH * tiles_n);
-  const int band_h = min(GH, tiles_m - band * GH);
-  const int tin = t - band * GH * tiles_n;
-  const int tn = tin / band_h, tm = band * GH + tin % band_h;
+  int tm, tn;
+  tile_coords(t, tiles_m, tiles_n, batch.band[pi], tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = P.K / BK;
 
@@ -851,11 +861,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
   const int t_in = lid - batch.tile_start[pi];
   const int tiles_m = (P.M + BM - 1) / BM;
   const int tiles_n = (P.N + BN - 1) / BN;
-  constexpr int GH = TILE_BAND;  // same band/patch order as gemm_bf16_kernel
-  const int band = t_in / (GH * tiles_n);
-  const int band_h = min(GH, tiles_m - band * GH);
-  const int tin = t_in - band * GH * tiles_n;
-  const int tn = tin / band_h, tm = band * GH + tin % band_h;
+  int tm, tn;  // same band / patch order as gemm_bf16_kernel
+  tile_coords(t_in, tiles_m, tiles_n, batch.band[pi], tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = P.K * ES / (BK * 2);  // 128-byte K tiles
 
@@ -1175,11 +1182,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
   const int t_in = lid - batch.tile_start[pi];
   const int tiles_m = (P.M + BM - 1) / BM;
   const int tiles_n = (P.N + BN - 1) / BN;
-  constexpr int GH = TILE_BAND;
-  const int band = t_in / (GH * tiles_n);
-  const int band_h = min(GH, tiles_m - band * GH);
-  const int tin = t_in - band * GH * tiles_n;
-  const int tn = tin / band_h, tm = band * GH + tin % band_h;
+  int tm, tn;
+  tile_coords(t_in, tiles_m, tiles_n, batch.band[pi], tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = P.K * ES / (BK * 2);
 
@@ -1361,6 +1365,30 @@ void set_gemm_w4q_min_rows(int rows) { g_w4q_min_rows = rows; }
 void set_gemm_w4(bool on) { g_w4 = on; }
 void set_gemm_pingpong(bool on) { g_pingpong = on; }
 
+// Band height of a problem's tile order.  An XCD runs ~32 consecutive tiles at a time; in a band of r tile-rows they span 32 / r
+// columns, i.e. r + 32 / r operand panels per K step for 32 tiles — the L2-miss bytes of the launch are proportional to the
+// tile-weighted mean of that figure (measured: FETCH_SIZE of 4608 x 21504 x 3072 1.07 GB at 8 + 8 + 2 rows, 0.95 GB at 6 + 6 + 6;
+// the model says 12.67 vs 11.33, profiles/r03_band_probe.txt).  Multiples of 8 rows keep 8 (measured best on M = 4096 in round 1);
+// otherwise the height in 5 .. 10 with the least modelled traffic, the ragged last band included.  FMI_GEMM_BAND=<n> pins one height
+// (A/B runs).  Any height gives the same results: the map is a bijection of the tiles.
+static int pick_tile_band(int tiles_m) {
+  static const int pinned = [] {
+    const char* e = getenv("FMI_GEMM_BAND");
+    return e ? atoi(e) : 0;
+  }();
+  if (pinned > 0) return pinned;
+  if (tiles_m <= TILE_BAND || tiles_m % TILE_BAND == 0) return TILE_BAND;
+  auto panels = [](int r) { return (double)r + 32.0 / r; };
+  int best = TILE_BAND;
+  double best_cost = 1e30;
+  for (int h = 5; h <= 10; ++h) {
+    const int rag = tiles_m % h;
+    const double cost = (tiles_m - rag) * panels(h) + (rag ? rag * panels(rag) : 0.0);
+    if (cost < best_cost - 1e-9) best_cost = cost, best = h;
+  }
+  return best;
+}
+
 int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   if (nprob <= 0) return FMI_OK;
   if (nprob > MAX_PROBLEMS) return fail(FMI_ERR_INVALID, "launch_gemm: too many grouped problems");
@@ -1392,9 +1420,11 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
     }
     b.p[i] = p;
     b.tile_start[i] = total;
+    b.band[i] = pick_tile_band(cdiv(p.M, BM));
     total += cdiv(p.M, BM) * cdiv(p.N, bn);
   }
   for (int i = nprob; i <= MAX_PROBLEMS; ++i) b.tile_start[i] = total;
+  for (int i = nprob; i < MAX_PROBLEMS; ++i) b.band[i] = TILE_BAND;
   const dim3 grid(total), blk(GEMM_THREADS);
 #define FMI_GEMM_LAUNCH(MODE)                                                               \
   do {                                                                                      \

@@ -55,10 +55,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const GemmBatch
   const int t_in = lid - batch.tile_start[pi];
   const int tiles_m = (P.M + BM - 1) / BM;
   const int tiles_n = (P.N + 255) / 256;
-  const int band = t_in / (TILE_BAND * tiles_n);
-  const int band_h = min(TILE_BAND, tiles_m - band * TILE_BAND);
-  const int tin = t_in - band * TILE_BAND * tiles_n;
-  const int tn = tin / band_h, tm = band * TILE_BAND + tin % band_h;
+  int tm, tn;
+  tile_coords(t_in, tiles_m, tiles_n, batch.band[pi], tm, tn);
   const int m0 = tm * BM, n0 = tn * 256;
   const int nk = P.K / BK;
   const int klast = nk - 1;
