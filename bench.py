@@ -110,6 +110,60 @@ def maybe_self_launch(args, argv):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def measure_traffic_live(quant_args, denoise_steps=4, timeout=300):
+    """roofline.traffic measured by THIS run: two short rocprofv3 counter passes (--pmc FETCH_SIZE, then --pmc WRITE_SIZE: the TCC
+    cannot hold both, and counters are never combined with traces) over a child `bench.py` that runs `denoise_steps` steps of the
+    same workload, summed over the block-linear GEMM kernels and divided by their dispatch count.  FETCH_SIZE x 2 is the gfx950
+    correction of MI355X_MICROARCH.md (HBM section).  Returns (bytes per launch | None, note)."""
+    import glob
+    import re
+    import shutil
+    import signal
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ):
+        return None, "this run is itself under a profiler: no nested counter passes"
+    rx = re.compile(r"fmi::gemm_(pp|w4|w4q)_kernel<")
+    kib, disp = {}, 0
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fmi_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary",
+                   "--no-profile-pass", "--no-live-traffic", "--denoise-steps", str(denoise_steps), "--steps", "1", "--warmup", "0"] + list(quant_args)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)  # exactly the process group started above
+                pr.wait()
+                return None, f"rocprofv3 --pmc {counter} pass timed out after {timeout} s"
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if rc != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} pass failed (exit code {rc})"
+            con = sqlite3.connect(dbs[0])
+            rows = [r for r in con.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name=? group by kernel_name",
+                                           (counter,)) if rx.search(r[0])]
+            con.close()
+            n = sum(r[1] for r in rows)
+            if not n:
+                return None, f"no block-linear GEMM dispatch in the --pmc {counter} pass"
+            kib[counter], disp = sum(r[2] for r in rows) / n, n
+        except Exception as e:  # a missing table, an unreadable database ...
+            return None, f"--pmc {counter} pass: {type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    note = (f"measured by this run: HBM-side (L2-miss) bytes per block-linear launch = FETCH_SIZE*2 + WRITE_SIZE, two separate rocprofv3 --pmc passes "
+            f"(FETCH_SIZE {kib['FETCH_SIZE']:.0f} KiB, WRITE_SIZE {kib['WRITE_SIZE']:.0f} KiB per launch as reported; x2 = the gfx950 FETCH_SIZE correction) over a child "
+            f"`bench.py --denoise-steps {denoise_steps} --steps 1 --warmup 0` of the same workload, {disp} GEMM dispatches; Infinity-Cache hits are included")
+    return int((2 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024), note
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +182,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the nf4 (C3) and fp8 (C5 shape) legs appended to the N = 1 line")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from profiles/pmc_summary_latest.json instead of two rocprofv3 --pmc passes of a short child run (~1 min)")
     ap.add_argument("--cpu-baseline-tokens", type=int, default=0, help="override L of the CPU sample (debug)")
     args = ap.parse_args()
     maybe_self_launch(args, sys.argv[1:])
@@ -342,14 +398,22 @@ def main():
     if rank == 0 and not args.no_profile_pass and spg is None:  # (the profiled pass is a single-device pass)
         traffic = tnote = None
         if args.quant == "none":
-            try:  # HBM-side bytes per launch from the separate rocprofv3 --pmc passes of this round (gpurun refuses counters beside traces)
-                with open(os.path.join(ROOT, "profiles", "pmc_summary_latest.json")) as f:
-                    pm = json.load(f)
-                traffic = pm.get("traffic_bytes_per_launch")
-                tnote = ("HBM-side bytes per block-linear launch = FETCH_SIZE*2 + WRITE_SIZE from separate rocprofv3 --pmc passes of the same command "
-                         f"({pm.get('source', 'profiles/')}); read from profiles/pmc_summary_latest.json, not re-measured inside this run")
-            except Exception:
-                pass
+            live_note = None
+            if world == 1 and not args.no_live_traffic and (args.height, args.width, args.batch) == (1024, 1024, 1):
+                torch.cuda.synchronize()
+                traffic, live_note = measure_traffic_live([])
+                if traffic is not None:
+                    tnote = live_note
+            if traffic is None:
+                try:  # the committed summary of this round's separate rocprofv3 --pmc passes (tools/profile_round.sh)
+                    with open(os.path.join(ROOT, "profiles", "pmc_summary_latest.json")) as f:
+                        pm = json.load(f)
+                    traffic = pm.get("traffic_bytes_per_launch")
+                    tnote = ("HBM-side bytes per block-linear launch = FETCH_SIZE*2 + WRITE_SIZE from separate rocprofv3 --pmc passes of the same command "
+                             f"({pm.get('source', 'profiles/')}); read from profiles/pmc_summary_latest.json, not re-measured inside this run"
+                             + (f" ({live_note})" if live_note else ""))
+                except Exception:
+                    pass
         roof, ex, img = wl.profile(flux, KDESC[args.quant], 5000.0 if args.quant == "fp8" else 2500.0, traffic, tnote)
         roof["peak_note"] = PEAK_NOTE
         extra.update(ex)

@@ -7,7 +7,7 @@ cd "$ROOT"
 OUT=gpurun_out/band_ab
 mkdir -p "$OUT"
 REPS=${1:-3}
-ARGS="--no-cpu-baseline --no-secondary --steps 1 --warmup 1 $BENCH_ARGS"
+ARGS="--no-cpu-baseline --no-secondary --no-live-traffic --steps 1 --warmup 1 $BENCH_ARGS"
 for i in $(seq 1 $REPS); do
   FMI_GEMM_BAND=8 python bench.py $ARGS > "$OUT/A_$i.json" 2> "$OUT/A_$i.err"
   python bench.py $ARGS > "$OUT/B_$i.json" 2> "$OUT/B_$i.err"

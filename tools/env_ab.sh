@@ -8,7 +8,7 @@ SW="$1"
 REPS=${2:-3}
 OUT=gpurun_out/env_ab_$(echo "$SW$BENCH_ARGS" | tr -c 'A-Za-z0-9\n' _)
 mkdir -p "$OUT"
-ARGS="--no-cpu-baseline --no-secondary --steps 1 --warmup 1 $BENCH_ARGS"
+ARGS="--no-cpu-baseline --no-secondary --no-live-traffic --steps 1 --warmup 1 $BENCH_ARGS"
 for i in $(seq 1 $REPS); do
   env $SW python bench.py $ARGS > "$OUT/A_$i.json" 2> "$OUT/A_$i.err"
   python bench.py $ARGS > "$OUT/B_$i.json" 2> "$OUT/B_$i.err"

@@ -11,7 +11,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python "$ROOT/bench.py" --no-cpu-baseline --no-secondary $BENCH_ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err" || tail -5 "$OUT/kt.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python "$ROOT/bench.py" --no-cpu-baseline --no-secondary --no-live-traffic $BENCH_ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err" || tail -5 "$OUT/kt.err"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o pmc -- python "$ROOT/bench.py" --no-cpu-baseline --no-secondary $BENCH_ARGS --no-profile-pass --denoise-steps $PMC_STEPS --steps 1 --warmup 0 > "$OUT/pmc_$C.log" 2>&1 || tail -5 "$OUT/pmc_$C.log"
 done
