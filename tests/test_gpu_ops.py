@@ -51,6 +51,31 @@ def test_linear_bf16(env, M, N, K, epi, bias):
     assert rel_l2(got, ref) <= 4e-3
 
 
+@pytest.mark.parametrize("tiles_m,N", [(9, 768), (11, 512), (18, 1024), (29, 512), (33, 384), (13, 128)])
+def test_linear_bf16_tile_order_band_heights(env, tiles_m, N):
+    """launch_gemm picks the band height of the tile order per problem (pick_tile_band: 18 tile rows -> 6 + 6 + 6, 29 -> 6 x 4 + 5, 33 -> ..., a
+    ragged last band, a partial last tile row): whatever it picks must be a bijection of the tiles — every 256 x 256 (or 256 x 128) tile of the
+    output is written exactly once with the right rows and columns.  Rows carry their index in the data, so a swapped or duplicated tile
+    cannot hide; compared per tile with the oracle's linear."""
+    torch, L, lib, orc = env["torch"], env["L"], env["lib"], env["orc"]
+    M, K = tiles_m * 256 - 37, 64  # the last tile row is partial
+    rng = np.random.default_rng(tiles_m)
+    x = bf16_round((rng.standard_normal((M, K)) + (np.arange(M)[:, None] % 17) * 0.25).astype(np.float32))
+    w = bf16_round((rng.standard_normal((N, K)) / np.sqrt(K) + (np.arange(N)[:, None] % 5) * 0.125).astype(np.float32))
+    ref = orc.linear(x, w, None)
+    xd, wd = dev(x, torch.bfloat16), dev(w, torch.bfloat16)
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.fmi_linear_bf16(_p(xd), _p(wd), None, _p(y), M, N, K, 0, None))
+    torch.cuda.synchronize()
+    got = host(y)
+    assert np.isfinite(got).all()
+    bn = 128 if N <= 128 else 256
+    for tm in range(tiles_m):
+        for tn in range((N + bn - 1) // bn):
+            g, r = got[tm * 256:(tm + 1) * 256, tn * bn:(tn + 1) * bn], ref[tm * 256:(tm + 1) * 256, tn * bn:(tn + 1) * bn]
+            assert rel_l2(g, r) <= 4e-3, (tm, tn)
+
+
 @pytest.mark.parametrize("epi,M,N", [(1, 256, 64), (2, 256, 64), (1, 512, 256)])  # 256-wide: the ping-pong kernel's packed-pair GELU epilogue
 def test_activation_epilogues_over_the_whole_range(env, epi, M, N):
     """GELU (v - v / (2^z + 1), `gelu_tanh` / `gelu_tanh4`) and SiLU (`v_rcp_f32` form) through an identity weight: exact zeros,
