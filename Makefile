@@ -10,6 +10,12 @@ SRCS := $(wildcard $(CSRC)/*.hip)
 OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(SRCS))
 LIB := $(PKG)/libflux_mi355x.so
 
+# Source identity of the library: sha256 over csrc/*, include/*.h and this Makefile (sorted by path), first 16 hex digits.  It is compiled
+# into the .so (fmi_build_id()), and __graft_entry__.build() recomputes it from the tree: a prebuilt binary that does not match the
+# sources it travels with is rebuilt instead of passing the "does it build" check by being newer than them.
+ID_FILES := $(sort $(wildcard $(CSRC)/*) $(wildcard include/*.h) Makefile)
+BUILD_ID := $(shell cat $(ID_FILES) | sha256sum | cut -c1-16)
+
 all: lib oracle
 lib: $(LIB)
 oracle:
@@ -17,7 +23,15 @@ oracle:
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h $(CSRC)/attention_w4_loop.inc $(CSRC)/attention_w16.h $(CSRC)/attention_w16_loop.inc $(CSRC)/attention_w16f8_loop.inc $(CSRC)/attention_w32.h $(CSRC)/attention_w32_loop.inc include/flux_mi355x.h
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -Ibuild -c $< -o $@
+
+build/build_id.h: FORCE
+	@mkdir -p build
+	@echo '#define FMI_BUILD_ID "$(BUILD_ID)"' > $@.tmp
+	@cmp -s $@.tmp $@ || cp $@.tmp $@
+	@rm -f $@.tmp
+build/capi.o: build/build_id.h
+FORCE:
 
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -Wl,-soname,libflux_mi355x.so
@@ -38,4 +52,7 @@ clean:
 	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle clean
+.PHONY: all lib oracle clean FORCE
+
+print-build-id:
+	@echo $(BUILD_ID)

@@ -11,7 +11,14 @@ LIB_PATH = os.path.join(_HERE, "libflux_mi355x.so")
 
 
 class FmiError(RuntimeError):
-    pass
+    """A non-zero fmi_status; `code` is the status (include/flux_mi355x.h: fmi_status), None for loader errors."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+ERR_INVALID, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED, ERR_NOMEM = -1, -2, -3, -4, -5
 
 
 class FluxConfig(C.Structure):
@@ -77,6 +84,7 @@ def load():
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     lib.fmi_last_error.restype = C.c_char_p
     lib.fmi_device_info.restype = C.c_char_p
+    lib.fmi_build_id.restype = C.c_char_p
     lib.fmi_flux_missing_name.restype = C.c_char_p
     lib.fmi_vae_missing_name.restype = C.c_char_p
     lib.fmi_flux_phase_name.restype = C.c_char_p
@@ -165,14 +173,29 @@ def load():
     return lib
 
 
+def tree_build_id(root=None):
+    """The build id of the SOURCE TREE, computed exactly as the Makefile does (sha256 over csrc/*, include/*.h, Makefile sorted by path;
+    16 hex digits).  Equal to load().fmi_build_id() iff the .so was built from these sources."""
+    import glob
+    import hashlib
+    root = root or os.path.dirname(_HERE)
+    files = sorted(glob.glob(os.path.join(root, "diffusion-rs_amd", "csrc", "*")) + glob.glob(os.path.join(root, "include", "*.h")) +
+                   [os.path.join(root, "Makefile")], key=lambda p: os.path.relpath(p, root))
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def check(rc):
     if rc != 0:
-        raise FmiError(f"fmi status {rc}: {load().fmi_last_error().decode(errors='replace')}")
+        raise FmiError(f"fmi status {rc}: {load().fmi_last_error().decode(errors='replace')}", code=int(rc))
 
 
 # every symbol include/flux_mi355x.h declares (tests/test_host_logic.py::test_library_exports_every_header_symbol checks they are all exported)
 EXPORTED = [
-    "fmi_last_error", "fmi_abi_version", "fmi_init", "fmi_device_info", "fmi_flux_default_config", "fmi_flux_create", "fmi_flux_destroy",
+    "fmi_last_error", "fmi_abi_version", "fmi_init", "fmi_device_info", "fmi_build_id", "fmi_flux_default_config", "fmi_flux_create", "fmi_flux_destroy",
     "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_set_linear_int8", "fmi_flux_set_quant_dense_cache", "fmi_flux_set_sequence_parallel", "fmi_flux_set_split_k", "fmi_set_bnb4_onewave_min_rows", "fmi_flux_set_attention_rescale_threshold", "fmi_flux_state_buffer_count", "fmi_flux_state_export", "fmi_flux_state_adopt", "fmi_flux_state_buffer", "fmi_flux_set_modulation_gemm", "fmi_flux_quantize_fp8", "fmi_flux_set_fp8_attention", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
     "fmi_flux_forward", "fmi_flux_denoise", "fmi_flux_set_profiling", "fmi_flux_set_fused_qkv_relayout", "fmi_flux_phase_count", "fmi_flux_phase_name", "fmi_flux_phase_ms",
     "fmi_vae_default_config", "fmi_vae_create", "fmi_vae_destroy", "fmi_vae_set_tensor", "fmi_vae_missing_count", "fmi_vae_missing_name",
@@ -182,7 +205,7 @@ EXPORTED = [
     "fmi_clip_missing_count", "fmi_clip_missing_name", "fmi_clip_size_in_bytes", "fmi_clip_forward", "fmi_pack_latents", "fmi_unpack_latents", "fmi_postprocess_u8",
     "fmi_randn", "fmi_philox_u32", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_linear_int8_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_set_attention_kernel", "fmi_layernorm_mod",
     "fmi_groupnorm_nhwc", "fmi_conv2d_nhwc",
-    "fmi_comm_unique_id", "fmi_comm_create", "fmi_comm_destroy", "fmi_comm_rank", "fmi_comm_world_size", "fmi_comm_stats", "fmi_comm_all_to_all",
+    "fmi_comm_probe", "fmi_comm_unique_id", "fmi_comm_create", "fmi_comm_destroy", "fmi_comm_rank", "fmi_comm_world_size", "fmi_comm_stats", "fmi_comm_all_to_all",
     "fmi_comm_broadcast", "fmi_comm_gather",
     "dequantize_blockwise_f32_int8", "dequantize_blockwise_f32_fp4", "dequantize_blockwise_f32_nf4", "dequantize_blockwise_f16_int8",
     "dequantize_blockwise_f16_fp4", "dequantize_blockwise_f16_nf4", "dequantize_blockwise_bf16_int8", "dequantize_blockwise_bf16_fp4",

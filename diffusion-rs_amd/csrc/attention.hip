@@ -574,8 +574,11 @@ static std::atomic<bool> g_att_w32{[] {
 }()};
 void set_attention_w32(bool on) { g_att_w32 = on; }
 
+static std::atomic<unsigned long long> g_fp8_fallbacks{0};  // fp8-QK^T launches that did not get the one-wave stream
+unsigned long long attention_fp8_fallbacks() { return g_fp8_fallbacks.load(std::memory_order_relaxed); }
+
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
-                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8, float* lse, int k_hstride) {  // (k_hstride: see the lse branch)
+                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8, float* lse, int k_hstride, int score_exp2) {  // (k_hstride: see the lse branch)
   if (Lq <= 0 || Lk <= 0) return fail(FMI_ERR_INVALID, "attention: empty sequence");
   if (Lkpad % ATT_KV != 0 || Lkpad < Lk) return fail(FMI_ERR_INVALID, "attention: Lkpad must be a multiple of 64 and >= Lk");
   dim3 grid(cdiv(Lq, ATT_QBLK) * B * H);
@@ -586,9 +589,9 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
       return fail(FMI_ERR_UNSUPPORTED, "attention: a key-split launch needs bf16 operands, B = 1, one token-major output and >= 2 KV tiles per part");
     const dim3 gs(grid.x * nsplit);
     if (rescale_thr_x16 == 0)
-      hipLaunchKernelGGL((attention_w4_kernel<0, true>), gs, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, Lk, lse, nsplit);
+      FMI_LAUNCH_LDS((attention_w4_kernel<0, true>), 8 * 16384, gs, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, Lk, lse, nsplit);
     else
-      hipLaunchKernelGGL((attention_w4_kernel<96, true>), gs, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, Lk, lse, nsplit);
+      FMI_LAUNCH_LDS((attention_w4_kernel<96, true>), 8 * 16384, gs, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, Lk, lse, nsplit);
     FMI_LAUNCH_CHECK();
     return FMI_OK;
   }
@@ -596,14 +599,22 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
     // round 3: the one-wave kernel's fp8-QK^T stream (attention_w16.h, QK8) carries scale * log2(e) / (sq * sk) as an E8M0 block
     // scale of the score MFMA, so it serves the calls whose factor is a power of two 2^-n, n = 0 .. 126 — the model's fp8 mode
     // picks its q scale that way (flux_model.hip: fp8_q_scale_pow2); anything else runs on the 8-wave kernel below
-    const int n2 = sl > 0.f ? (int)lrintf(log2f(sl)) : 1;  // nearest power of two (a few float roundings separate the host's factor from 2^n)
-    const bool pow2 = n2 <= 0 && n2 >= -126 && fabsf(sl / ldexpf(1.0f, n2) - 1.0f) <= 1e-6f;
+    // The exponent comes from the caller as an integer when it has one (score_exp2); a bare float (fmi_sdpa_fp8qk) qualifies only if it
+    // IS a power of two, bit for bit — no tolerance window: a factor a few ulps off means the caller did not construct it as one.
+    int n2 = 1;
+    if (score_exp2 != ATT_NO_EXP2) n2 = score_exp2;
+    else if (sl > 0.f) {
+      int e;
+      if (frexpf(sl, &e) == 0.5f) n2 = e - 1;
+    }
+    const bool pow2 = n2 <= 0 && n2 >= -126;
+    if (!(g_att_w16 && Lk > ATT_KV && pow2)) g_fp8_fallbacks.fetch_add(1, std::memory_order_relaxed);
     if (g_att_w16 && Lk > ATT_KV && pow2) {
       const float sl2 = ldexpf(1.0f, n2);
       if (rescale_thr_x16 == 0)
-        hipLaunchKernelGGL((attention_w16_kernel<0, true>), grid, dim3(AW16_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl2);
+        FMI_LAUNCH_LDS((attention_w16_kernel<0, true>), 8 * 16384, grid, dim3(AW16_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl2);
       else
-        hipLaunchKernelGGL((attention_w16_kernel<96, true>), grid, dim3(AW16_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl2);
+        FMI_LAUNCH_LDS((attention_w16_kernel<96, true>), 8 * 16384, grid, dim3(AW16_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl2);
       FMI_LAUNCH_CHECK();
       return FMI_OK;
     }
@@ -613,19 +624,19 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
       hipLaunchKernelGGL((attention_pp_kernel<96, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
   } else if (g_att_w32 && Lk > ATT_KV) {  // (a single KV tile has no steady state to pipeline: the 8-wave kernel serves it)
     if (rescale_thr_x16 == 0)
-      hipLaunchKernelGGL((attention_w32_kernel<0>), grid, dim3(AW32_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+      FMI_LAUNCH_LDS((attention_w32_kernel<0>), 8 * 16384, grid, dim3(AW32_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
     else
-      hipLaunchKernelGGL((attention_w32_kernel<96>), grid, dim3(AW32_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+      FMI_LAUNCH_LDS((attention_w32_kernel<96>), 8 * 16384, grid, dim3(AW32_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
   } else if (g_att_w16 && Lk > ATT_KV) {
     if (rescale_thr_x16 == 0)
-      hipLaunchKernelGGL((attention_w16_kernel<0>), grid, dim3(AW16_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+      FMI_LAUNCH_LDS((attention_w16_kernel<0>), 8 * 16384, grid, dim3(AW16_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
     else
-      hipLaunchKernelGGL((attention_w16_kernel<96>), grid, dim3(AW16_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+      FMI_LAUNCH_LDS((attention_w16_kernel<96>), 8 * 16384, grid, dim3(AW16_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
   } else if (g_att_w4 && Lk > ATT_KV) {
     if (rescale_thr_x16 == 0)
-      hipLaunchKernelGGL((attention_w4_kernel<0>), grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, 0, nullptr, 1);
+      FMI_LAUNCH_LDS((attention_w4_kernel<0>), 8 * 16384, grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, 0, nullptr, 1);
     else
-      hipLaunchKernelGGL((attention_w4_kernel<96>), grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, 0, nullptr, 1);
+      FMI_LAUNCH_LDS((attention_w4_kernel<96>), 8 * 16384, grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, 0, nullptr, 1);
   } else if (g_att_pingpong) {
     if (rescale_thr_x16 == 0)
       hipLaunchKernelGGL((attention_pp_kernel<0, false>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);

@@ -95,8 +95,7 @@ __global__ __launch_bounds__(AW16_THREADS, 1) void attention_w16_kernel(const bf
     const char* base = reinterpret_cast<const char*>(Vb) + (int64_t)tile * (ATT_KV * 2);
     __builtin_amdgcn_global_load_lds((glb_void*)(base + v_voff[i]), (lds_void*)(smem + VT_RING + (tile & 3) * TILE + (wave * 4 + i) * 1024), 16, 0, 0);
   };
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-  if (lds0 != 0) __builtin_trap();  // the ring-slot xor in the stream assumes the K ring at LDS byte 0 (smem is the only __shared__ object)
+  // (smem sits at LDS byte 0 — the ring-slot xor rely on it: it is the kernel's only __shared__ object, which the host checks before the first launch, FMI_LDS_GUARD)
   // Fragment read addresses.  K fragment (key block a, d-step s): lane (g, m) reads row 32 (a >> 1) + 8 (a & 1) + (m & 7) + 16 (m >> 3)
   // — the key whose score the V^T k-permutation expects in row m of block a — global slot 4 s + g, at KAD[s] + the block's
   // immediate offset.  V^T fragment (d block dt, k-step kk): row 16 dt + m, slot 4 kk + g, at VAD[kk] + 2048 dt.

@@ -84,8 +84,7 @@ __global__ __launch_bounds__(AW32_THREADS, 1) void attention_w32_kernel(const bf
     const char* base = reinterpret_cast<const char*>(Vb) + (int64_t)tile * (ATT_KV * 2);
     __builtin_amdgcn_global_load_lds((glb_void*)(base + v_voff[i]), (lds_void*)(smem + VT_RING + (tile & 3) * TILE + (wave * 4 + i) * 1024), 16, 0, 0);
   };
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-  if (lds0 != 0) __builtin_trap();  // the ring-slot xor in the stream assumes the K ring at LDS byte 0 (smem is the only __shared__ object)
+  // (smem sits at LDS byte 0 — the ring-slot xor rely on it: it is the kernel's only __shared__ object, which the host checks before the first launch, FMI_LDS_GUARD)
   // Fragment read addresses: K fragment (key half u, d-step s) at KAD[s] + 8192 u, V^T fragment (d block dt, k-step c) at VAD[c] + 4096 dt
   {
 #pragma unroll

@@ -118,8 +118,7 @@ __global__ __launch_bounds__(AW4_THREADS, 1) void attention_w4_kernel(const bf16
   // (d block dt, k-step c) at v_ad[c] + 4096 dt — one VGPR per swizzle phase, the block offset is the instruction's immediate.
   // B(t) and A(t+1) read the same ring slots (K(t+1), V^T(t)), so one set serves a loop iteration and is advanced by one
   // slot (2 VALU per register) behind A's last own read.
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-  if (lds0 != 0) __builtin_trap();  // the ring wrap below assumes the K ring at LDS byte 0 (smem is the only __shared__ object)
+  // (smem sits at LDS byte 0 — the ring wrap rely on it: it is the kernel's only __shared__ object, which the host checks before the first launch, FMI_LDS_GUARD)
   uint32_t k_ad[8], v_ad[4];
 #pragma unroll
   for (int s = 0; s < 8; ++s) k_ad[s] = (l31 * 256 + ((hl ^ (lane & 15)) << 4)) ^ (s << 5);

@@ -26,6 +26,31 @@ int fail(fmi_status st, const std::string& msg);
     if (_rc != FMI_OK) return _rc; \
   } while (0)
 #define FMI_LAUNCH_CHECK() FMI_HIP_TRY(hipGetLastError())
+// Kernels whose hand-scheduled instruction streams address LDS from byte 0 (the generated attention streams' ring-slot xor, the fused
+// 4-bit GEMM's table look-ups) need their one __shared__ array to be the workgroup's WHOLE static LDS allocation.  That is a property
+// of the code object, so it is checked on the host, once per kernel instantiation, before its first launch: the kernel's static LDS size
+// must equal the array's size (any further __shared__ object would make it larger).  A violation is a refused launch with
+// FMI_ERR_STATE — not a device-side trap that takes the process down.
+inline int lds_sole_owner(const void* kernel, size_t expect_bytes, const char* what) {
+  hipFuncAttributes a{};
+  hipError_t e = hipFuncGetAttributes(&a, kernel);
+  if (e != hipSuccess) return fail(FMI_ERR_HIP, std::string("hipFuncGetAttributes(") + what + "): " + hipGetErrorString(e));
+  if ((size_t)a.sharedSizeBytes != expect_bytes)
+    return fail(FMI_ERR_STATE, std::string(what) + ": static LDS is " + std::to_string((size_t)a.sharedSizeBytes) + " bytes, the kernel's ring is " +
+                                   std::to_string(expect_bytes) + " — another __shared__ object would move it off LDS byte 0; launch refused");
+  return FMI_OK;
+}
+#define FMI_LDS_GUARD(kernel, bytes)                                                    \
+  do {                                                                                  \
+    static const int once_ = ::fmi::lds_sole_owner((const void*)(kernel), (bytes), #kernel); \
+    if (once_ != FMI_OK) return ::fmi::lds_sole_owner((const void*)(kernel), (bytes), #kernel); \
+  } while (0)
+// guard + launch as ONE statement (usable as the body of an unbraced if / else)
+#define FMI_LAUNCH_LDS(kernel, bytes, ...)        \
+  do {                                            \
+    FMI_LDS_GUARD(kernel, bytes);                 \
+    hipLaunchKernelGGL(kernel, __VA_ARGS__);      \
+  } while (0)
 // A handle remembers the device it was created on; every entry point makes it the calling thread's current device
 // (hipSetDevice is per thread, and the Python front door calls from whichever thread holds the pipeline lock).
 inline int current_device() {
@@ -241,8 +266,15 @@ struct AttnOut {
   int head_major;
 };
 // qk_fp8 != 0: q and k are e4m3 bytes (B,H,L,128), QK^T runs on the fp8 MFMA (scale must already hold 1 / (q scale * k scale))
+constexpr int ATT_NO_EXP2 = 1 << 30;
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
-                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8 = 0, float* lse = nullptr, int nsplit = 0);
+                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8 = 0, float* lse = nullptr, int nsplit = 0,
+                        int score_exp2 = ATT_NO_EXP2);
+// score_exp2 (fp8 QK^T only): the caller KNOWS that scale * log2(e) == 2^score_exp2 exactly and says so as an integer (the model's fp8
+// mode constructs its q scale that way) -> the one-wave stream, which carries the factor in the MFMA's E8M0 block scale.  ATT_NO_EXP2 =
+// unknown: the launcher recognises an exact power of two itself, anything else runs on the 8-wave kernel and is COUNTED
+// (attention_fp8_fallbacks(), visible in fmi_device_info) — a silent slide to the slower, numerically different kernel was ADVICE r3's finding.
+unsigned long long attention_fp8_fallbacks();
 void set_attention_pingpong(bool on);  // 8-wave kernels: ping-pong (default) or the single-barrier one
 void set_attention_w4(bool on);        // bf16 operands: one-wave-per-SIMD kernel (default) or the 8-wave ones
 void set_attention_w16(bool on);       // bf16 operands: the 16x16x32-MFMA one-wave kernel in front of the others (default on)

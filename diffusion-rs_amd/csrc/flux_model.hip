@@ -158,6 +158,7 @@ struct fmi_flux {
   // QkNorm'ed, rotated head vector has norm sqrt(128) * |w|, so no element can exceed the e4m3 range
   bool fp8_attn = true;
   std::vector<float> q8_dbl, k8_dbl, q8_sgl, k8_sgl;
+  std::vector<int> n8_dbl, n8_sgl;  // fp8 attention: softmax_scale * log2(e) / (q8 * k8) == 2^-n8 EXACTLY (q_scale_pow2); handed to the attention as an integer
 };
 
 namespace {
@@ -870,7 +871,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       o.p1 = w.attn_img, o.ld1 = D, o.bstride1 = (int64_t)S * D;
       const float sc = qk8 ? att_scale / (m->q8_dbl[i] * m->k8_dbl[i]) : att_scale;
       if (sp) FMI_TRY(attention_sp(m, o, T, S, sc, s));
-      else FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0));
+      else FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0, nullptr, 0, qk8 ? -m->n8_dbl[i] : ATT_NO_EXP2));
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
@@ -962,7 +963,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       o.p1 = w.big + 2 * D, o.ld1 = ldbig, o.bstride1 = (int64_t)L * ldbig;
       const float sc = qk8 ? att_scale / (m->q8_sgl[i] * m->k8_sgl[i]) : att_scale;
       if (sp) FMI_TRY(attention_sp(m, o, T, S, sc, s));
-      else FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0));
+      else FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0, nullptr, 0, qk8 ? -m->n8_sgl[i] : ATT_NO_EXP2));
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
@@ -1452,18 +1453,23 @@ extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) {
       *out = mx;
       return FMI_OK;
     };
-    auto scale_of = [](float mx) { return 448.0f / (11.3137085f * std::max(mx, 1e-20f)); };  // sqrt(128)
+    // (the same expressions, constant for constant, as flux_oracle.cpp: fp8_attn_scale / fp8_q_scale_pow2 — the oracle is a separate
+    // program by rule, so the definition is shared as text, and tests/test_gpu_fp8.py compares the resulting codes bit for bit)
+    auto scale_of = [](float mx) { return 448.0f / (sqrtf(128.0f) * std::max(mx, 1e-20f)); };
     // The q scale is then lowered (by less than a factor 2: e4m3 keeps its relative precision) to the value that makes the
     // attention's score factor softmax_scale * log2(e) / (sq * sk) an exact power of two 2^-n: the one-wave fp8 attention
     // (attention_w16.h, QK8) folds it into the E8M0 block scale of its score MFMA.  The oracle applies the same rule
     // (flux_oracle.cpp: fp8_q_scale_pow2).
-    auto q_scale_pow2 = [](float q8, float k8) {
+    // n is kept: the attention gets the score factor 2^-n as an INTEGER exponent, not as a float to be recognised again
+    auto q_scale_pow2 = [](float q8, float k8, int* n_out) {
       const float c0 = (1.0f / sqrtf(128.0f)) * 1.4426950408889634f;
       const int n = (int)floorf(log2f(q8 * k8 / c0));
+      *n_out = n;
       return c0 * ldexpf(1.0f, n) / k8;
     };
     m->q8_dbl.assign(m->dbl.size(), 0.f), m->k8_dbl.assign(m->dbl.size(), 0.f);
     m->q8_sgl.assign(m->sgl.size(), 0.f), m->k8_sgl.assign(m->sgl.size(), 0.f);
+    m->n8_dbl.assign(m->dbl.size(), 0), m->n8_sgl.assign(m->sgl.size(), 0);
     for (size_t i = 0; i < m->dbl.size(); ++i) {
       float a, b, c, d;
       FMI_TRY(wmax(m->dbl[i].nq[0], &a));
@@ -1471,14 +1477,14 @@ extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) {
       FMI_TRY(wmax(m->dbl[i].nk[0], &c));
       FMI_TRY(wmax(m->dbl[i].nk[1], &d));
       m->k8_dbl[i] = scale_of(std::max(c, d));  // both streams feed one attention call: one scale
-      m->q8_dbl[i] = q_scale_pow2(scale_of(std::max(a, b)), m->k8_dbl[i]);
+      m->q8_dbl[i] = q_scale_pow2(scale_of(std::max(a, b)), m->k8_dbl[i], &m->n8_dbl[i]);
     }
     for (size_t i = 0; i < m->sgl.size(); ++i) {
       float a, c;
       FMI_TRY(wmax(m->sgl[i].nq, &a));
       FMI_TRY(wmax(m->sgl[i].nk, &c));
       m->k8_sgl[i] = scale_of(c);
-      m->q8_sgl[i] = q_scale_pow2(scale_of(a), m->k8_sgl[i]);
+      m->q8_sgl[i] = q_scale_pow2(scale_of(a), m->k8_sgl[i], &m->n8_sgl[i]);
     }
   }
   if (m->ws.base) {  // the fp8 workspace has two more buffers: rebuild on the next call

@@ -1469,6 +1469,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   else if (quant && bn == 256 && w4q_ok) {
     // fused dequant-GEMM, one wave per SIMD (gemm_w4q.h)
     const dim3 g4(total), b4(W4_THREADS);
+    FMI_LDS_GUARD((gemm_w4q_kernel<0>), W4Q_LUT_BYTES + 4 * A_TILE_BYTES);  // (the four instantiations share the LDS layout)
     if (act == 0) hipLaunchKernelGGL((gemm_w4q_kernel<0>), g4, b4, 0, stream, b);
     else if (act == 1) hipLaunchKernelGGL((gemm_w4q_kernel<1>), g4, b4, 0, stream, b);
     else if (act == 2) hipLaunchKernelGGL((gemm_w4q_kernel<2>), g4, b4, 0, stream, b);

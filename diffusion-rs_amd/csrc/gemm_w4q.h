@@ -69,8 +69,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const GemmBatch
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-  if (lds0 != 0) __builtin_trap();  // the table lookups address LDS byte 0 directly (smem is the only __shared__ object)
+  // (smem sits at LDS byte 0 — the table lookups rely on it: it is the kernel's only __shared__ object, which the host checks before the first launch, FMI_LDS_GUARD)
   {  // packed byte -> the two code values, weight order (high nibble first); fp4: value * sign of the tree in dequant.cu:12-37
     const float fp4[8] = {0.0f, 5.208333333e-03f, 0.66666667f, 1.0f, 0.33333333f, 0.5f, 0.16666667f, 0.25f};
     auto val = [&](int c) { return P.q_type == 2 ? kNF4[c] : ((c & 8) ? -fp4[c & 7] : fp4[c & 7]); };

@@ -86,6 +86,16 @@ struct fmi_comm {
 
 static_assert(sizeof(ncclUniqueId) == FMI_COMM_ID_BYTES, "fmi_comm id size");
 
+// Non-collective availability check: librccl opens with every symbol and this thread has a current device.  A host calls it on
+// EVERY rank and agrees on the result before the first collective call (fmi_comm_create blocks inside ncclCommInitRank until all
+// ranks arrive: a rank that failed earlier would leave the healthy ones there until the RCCL timeout).
+extern "C" int fmi_comm_probe(void) {
+  FMI_TRY(need_rccl());
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return fail(FMI_ERR_HIP, "comm_probe: no current device");
+  return FMI_OK;
+}
+
 extern "C" int fmi_comm_unique_id(void* id_out) {
   if (!id_out) return fail(FMI_ERR_INVALID, "comm_unique_id: null");
   FMI_TRY(need_rccl());
@@ -161,17 +171,25 @@ extern "C" int fmi_comm_gather(fmi_comm* c, const void* send, void* recv, size_t
   if (!bytes) return FMI_OK;
   hipStream_t s = (hipStream_t)stream;
   FMI_NCCL_TRY("ncclGroupStart", g_rccl.GroupStart());
+  // Inside the group nothing returns early: the first error is recorded and ncclGroupEnd is ALWAYS called, so the calling
+  // thread never stays in group mode (later RCCL calls on it, torch's included, would be deferred and hang silently).
+  ncclResult_t first = ncclSuccess;
+  const char* where = nullptr;
   if (c->rank == root) {
-    for (int r = 0; r < c->world; ++r) {
+    for (int r = 0; r < c->world && first == ncclSuccess; ++r) {
       if (r == root) continue;
-      FMI_NCCL_TRY("ncclRecv", g_rccl.Recv((char*)recv + (size_t)r * bytes, bytes, ncclUint8, r, c->comm, s));
+      first = g_rccl.Recv((char*)recv + (size_t)r * bytes, bytes, ncclUint8, r, c->comm, s);
+      if (first != ncclSuccess) where = "ncclRecv";
     }
   } else {
-    FMI_NCCL_TRY("ncclSend", g_rccl.Send(send, bytes, ncclUint8, root, c->comm, s));
-    c->bytes_sent += (unsigned long long)bytes;
+    first = g_rccl.Send(send, bytes, ncclUint8, root, c->comm, s);
+    if (first != ncclSuccess) where = "ncclSend";
   }
-  FMI_NCCL_TRY("ncclGroupEnd", g_rccl.GroupEnd());
+  ncclResult_t end = g_rccl.GroupEnd();
+  if (first != ncclSuccess) return nccl_fail(where, first);
+  if (end != ncclSuccess) return nccl_fail("ncclGroupEnd", end);
   if (c->rank == root) FMI_HIP_TRY(hipMemcpyAsync((char*)recv + (size_t)root * bytes, send, bytes, hipMemcpyDeviceToDevice, s));
+  else c->bytes_sent += (unsigned long long)bytes;  // counted only once the send has really been submitted
   c->calls++;
   return FMI_OK;
 }

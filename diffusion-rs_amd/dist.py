@@ -90,15 +90,26 @@ def broadcast_state(model, device, src: int = 0, chunk_bytes: int = STATE_CHUNK,
     if ws == 1:
         return {"bytes": 0, "messages": 0, "seconds": 0.0}
     head = [None]
+    local_error = None
     if rank == src:
         try:
             head = [("ok", model.state_export())]
-        except Exception as e:  # e.g. FMI_ERR_UNSUPPORTED: LLM.int8 matrices are not part of the flat state
-            head = [("unsupported", f"{type(e).__name__}: {e}")]
+        except Exception as e:
+            # Only FMI_ERR_UNSUPPORTED (LLM.int8 matrices are not part of the flat state) means "every rank loads the checkpoint
+            # itself"; anything else (a HIP error, out of memory, a bug) is a hard error on ALL ranks, announced through the
+            # same head message so that nobody blocks in the data collectives.
+            from ._lib import ERR_UNSUPPORTED
+            kind = "unsupported" if getattr(e, "code", None) == ERR_UNSUPPORTED or isinstance(e, StateExportUnsupported) else "error"
+            head = [(kind, f"{type(e).__name__}: {e}")]
+            local_error = e
     dist.broadcast_object_list(head, src=src)
     kind, blob = head[0]
-    if kind != "ok":
+    if kind == "unsupported":
         raise StateExportUnsupported(blob)
+    if kind != "ok":
+        if local_error is not None:
+            raise local_error
+        raise RuntimeError(f"state export failed on rank {src}: {blob}")
     if rank != src:
         model.state_adopt(blob)
     total = msgs = 0
@@ -129,7 +140,13 @@ def _sync(device):
 class RcclComm:
     """fmi_comm (csrc/rccl_comm.hip): this process's RCCL communicator behind the C-ABI, created collectively — rank 0 draws the
     128-byte id, torch.distributed (whatever its backend) carries it to the others, every rank calls fmi_comm_create on its
-    current device.  Operations are enqueued on the current torch stream unless a stream pointer is given."""
+    current device.  Operations are enqueued on the current torch stream unless a stream pointer is given.
+
+    THE CONSTRUCTOR IS A COLLECTIVE over `group`: every rank must construct it, in the same order relative to other collectives.
+    It runs in three agreed stages so that a rank that cannot take part never leaves the others blocked inside ncclCommInitRank:
+    (1) a non-collective probe on every rank (fmi_comm_probe: librccl opens, a device is current) + agree_or_raise;
+    (2) rank 0 draws the id, broadcast_object_list carries it (or the failure) + agree_or_raise;
+    (3) fmi_comm_create (ncclCommInitRank) + agree_or_raise."""
 
     def __init__(self, device, group=None):
         import ctypes as C
@@ -139,6 +156,14 @@ class RcclComm:
         self.lib = L.load()
         self.device = torch.device(device)
         self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
+        self.h = None
+        err = None
+        try:  # stage 1: can this rank take part at all?  (no collective inside)
+            with torch.cuda.device(self.device):
+                L.check(self.lib.fmi_comm_probe())
+        except Exception as e:
+            err = e
+        agree_or_raise(err, "RCCL availability probe", group)
         ident, err = [None], None
         if self.rank == 0:
             buf = (C.c_uint8 * 128)()
@@ -152,12 +177,12 @@ class RcclComm:
         h = C.c_void_p()
         if ident[0] is None:
             err = err or RuntimeError("rank 0 could not create an RCCL id")
-        else:
-            try:
-                with torch.cuda.device(self.device):
-                    L.check(self.lib.fmi_comm_create((C.c_uint8 * 128).from_buffer_copy(ident[0]), self.rank, self.world_size, C.byref(h)))
-            except Exception as e:
-                err = e
+        agree_or_raise(err, "RCCL id creation", group)  # stage 2: nobody enters ncclCommInitRank unless everybody holds the id
+        try:
+            with torch.cuda.device(self.device):
+                L.check(self.lib.fmi_comm_create((C.c_uint8 * 128).from_buffer_copy(ident[0]), self.rank, self.world_size, C.byref(h)))
+        except Exception as e:
+            err = e
         agree_or_raise(err, "RCCL communicator creation", group)
         self.h = h
 
@@ -313,7 +338,12 @@ class _DeviceBytes:
 
 
 class SequenceParallel:
-    """Sequence-parallel group for ONE image: rank r holds txt tokens [r*T/N, (r+1)*T/N) and img tokens [r*S/N, (r+1)*S/N)."""
+    """Sequence-parallel group for ONE image: rank r holds txt tokens [r*T/N, (r+1)*T/N) and img tokens [r*S/N, (r+1)*S/N).
+
+    On the "nccl" backend THE CONSTRUCTOR IS A COLLECTIVE over `group` (it creates the library's own RCCL communicator, a second
+    one next to torch's: RcclComm) — every rank of the group must construct it.  FMI_SP_TORCH_A2A (1 = keep the Python
+    all_to_all_single callback instead) must have the SAME value on every rank: ranks that disagree would wait for each other in
+    different collectives; the constructor checks that and raises on all ranks."""
 
     def __init__(self, device, group=None):
         if not (dist.is_available() and dist.is_initialized()):
@@ -329,7 +359,13 @@ class SequenceParallel:
         # round-2 path (a Python callback per exchange that calls torch.distributed.all_to_all_single) for A/B runs
         import os
         self.comm = None
-        if self.backend == "nccl" and os.environ.get("FMI_SP_TORCH_A2A", "0") != "1":
+        native = self.backend == "nccl" and os.environ.get("FMI_SP_TORCH_A2A", "0") != "1"
+        if self.backend == "nccl" and self.world_size > 1:  # the choice must be unanimous (see the class docstring)
+            votes = [None] * self.world_size
+            dist.all_gather_object(votes, bool(native), group=group)
+            if len(set(votes)) != 1:
+                raise RuntimeError(f"FMI_SP_TORCH_A2A differs between the ranks of the sequence-parallel group: native exchange = {votes}")
+        if native:
             self.comm = RcclComm(self.device, group)
 
     @property

@@ -65,8 +65,13 @@ const char* fmi_last_error(void);
 int fmi_abi_version(void);
 /* Select the HIP device for this thread (hipSetDevice) and warm the runtime. */
 int fmi_init(int device_ordinal);
-/* Device / build info as a JSON string (static storage, valid until next call). */
+/* Device / build info as a JSON string (static storage, valid until next call); includes "build_id" and the count of fp8-QK^T
+ * attention launches that fell back from the one-wave stream to the 8-wave kernel ("fp8_attention_fallbacks"). */
 const char* fmi_device_info(void);
+/* Source identity of this binary: the first 16 hex digits of sha256 over diffusion-rs_amd/csrc/*, include/*.h and the Makefile
+ * (sorted by path, concatenated) at build time.  __graft_entry__.build() recomputes it from the tree and rebuilds on a mismatch,
+ * so a stale prebuilt .so cannot stand in for the sources next to it. */
+const char* fmi_build_id(void);
 
 /* ------------------------------------------------------------------------------------
  * FLUX DiT — replaces diffusion_rs_core::models::flux::Flux (model.rs:709-838)
@@ -167,6 +172,9 @@ int fmi_flux_set_sequence_parallel(fmi_flux*, int rank, int world_size, fmi_all_
  *   fmi_comm_gather      rank r's `bytes` land at recv + r*bytes on root (decoded u8 images to rank 0). */
 #define FMI_COMM_ID_BYTES 128
 typedef struct fmi_comm fmi_comm;
+/* Non-collective: FMI_OK iff librccl is usable and the thread has a current device.  Call it on every rank and agree on the
+ * results over the host channel BEFORE fmi_comm_create, which blocks in ncclCommInitRank until every rank has arrived. */
+int fmi_comm_probe(void);
 int fmi_comm_unique_id(void* id_out /* FMI_COMM_ID_BYTES */);
 int fmi_comm_create(const void* id, int rank, int world_size, fmi_comm** out);
 void fmi_comm_destroy(fmi_comm*);

@@ -705,7 +705,10 @@ extern "C" orc_flux* orc_flux_create(int in_channels, int pooled_projection_dim,
   return m;
 }
 extern "C" void orc_flux_destroy(orc_flux* m) { delete m; }
-extern "C" void orc_flux_set_fp8(orc_flux* m, int on) { m->fp8 = on; }
+extern "C" void orc_flux_set_fp8(orc_flux* m, int on) {
+  if (m->fp8 != on) m->fp8_w.clear();
+  m->fp8 = on;
+}
 extern "C" void orc_flux_set_fp8_attention(orc_flux* m, int on) { m->fp8_attn = on; }
 extern "C" int orc_flux_set_tensor(orc_flux* m, const char* name, const float* data, int64_t numel) {
   m->t[name] = std::vector<float>(data, data + numel);
@@ -742,8 +745,62 @@ Lin get_lin(const orc_flux* m, const std::string& p, int in, int out, bool bias 
 void lin_fwd(const Lin& l, const float* x, int rows, float* y) { gemm_nt(x, l.in, l.w, l.in, l.b, rows, l.out, l.in, y, l.out, 1.0f); }
 // A DiT block Linear: lin_fwd, or the fp8 recipe when orc_flux_set_fp8 is on:
 // y[m,n] = (sum_k qx[m,k] qw[n,k]) * (sx[m] * sw[n]) + b[n]
+// orc_flux_set_fp8 modes.  1 is THE recipe (what the HIP path implements).  2..6 exist for the noise study of
+// tools/fp8_noise_study.py only (DESIGN 4.3 "the e4m3 noise floor"): they answer "would another scaling granularity or
+// keeping one operand exact bring the mode inside the bf16 tolerance?" with the same f32 GEMM behind each quantiser.
+//   1  e4m3, one scale per row (token / output channel), both operands
+//   2  e4m3, one power-of-two (E8M0) scale per 32 consecutive k (the MX block format of v_mfma_scale_*), both operands
+//   3  as 1, weights only (activations exact)      4  as 1, activations only (weights exact)
+//   5  int8, absmax / 127 per row, both operands   6  as 2, activations only
+static void study_quantise(const float* x, int rows, int K, int kind, float* out) {
+  // kind 0: copy, 1: e4m3 per row, 2: e4m3 per 32-block with a power-of-two scale that never clips, 5: int8 per row
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r) {
+    const float* xr = x + (int64_t)r * K;
+    float* o = out + (int64_t)r * K;
+    if (kind == 0) {
+      memcpy(o, xr, sizeof(float) * K);
+    } else if (kind == 2) {
+      for (int k0 = 0; k0 < K; k0 += 32) {
+        const int n = std::min(32, K - k0);
+        float am = 0.f;
+        for (int k = 0; k < n; ++k) am = fmaxf(am, fabsf(xr[k0 + k]));
+        if (am == 0.f) {
+          for (int k = 0; k < n; ++k) o[k0 + k] = 0.f;
+          continue;
+        }
+        const float sc = ldexpf(1.0f, (int)ceilf(log2f(am / 448.0f)));
+        for (int k = 0; k < n; ++k) o[k0 + k] = orc_e4m3_to_f32(orc_f32_to_e4m3(xr[k0 + k] / sc)) * sc;
+      }
+    } else {
+      float am = 0.f;
+      for (int k = 0; k < K; ++k) am = fmaxf(am, fabsf(xr[k]));
+      am = fmaxf(am, 1e-30f);
+      if (kind == 1) {
+        const float inv = 448.0f / am, sc = am / 448.0f;
+        for (int k = 0; k < K; ++k) o[k] = orc_e4m3_to_f32(orc_f32_to_e4m3(xr[k] * inv)) * sc;
+      } else {
+        const float inv = 127.0f / am, sc = am / 127.0f;
+        for (int k = 0; k < K; ++k) o[k] = nearbyintf(xr[k] * inv) * sc;
+      }
+    }
+  }
+}
 void lin_blk(orc_flux* m, const Lin& l, const float* x, int rows, float* y) {
   if (!m->fp8) return lin_fwd(l, x, rows, y);
+  if (m->fp8 != 1) {  // study modes: dequantised operands through the plain f32 GEMM
+    static const int wk[7] = {0, 1, 2, 1, 0, 5, 0}, ak[7] = {0, 1, 2, 0, 1, 5, 2};
+    const int mode = std::min(std::max(m->fp8, 2), 6);
+    Fp8Weight& fw = m->fp8_w[l.w];
+    if (fw.q.empty()) {
+      fw.q.resize((size_t)l.out * l.in);
+      study_quantise(l.w, l.out, l.in, wk[mode], fw.q.data());
+    }
+    std::vector<float> xq((size_t)rows * l.in);
+    study_quantise(x, rows, l.in, ak[mode], xq.data());
+    gemm_nt(xq.data(), l.in, fw.q.data(), l.in, l.b, rows, l.out, l.in, y, l.out, 1.0f);
+    return;
+  }
   Fp8Weight& fw = m->fp8_w[l.w];
   if (fw.q.empty()) {
     std::vector<uint8_t> codes((size_t)l.out * l.in);

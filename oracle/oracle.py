@@ -408,11 +408,12 @@ class Flux:
         a = np.ascontiguousarray(bits, np.uint16)
         lib().orc_flux_set_tensor_bf16(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), C.c_int64(a.size))
 
-    def set_fp8(self, on=True, attention=False):
+    def set_fp8(self, on=True, attention=False, study_mode=None):
         """Block linears on the fp8 recipe (flux_oracle.cpp: parity unpinned, no reference counterpart); attention=True
         also puts q and k of the attention on e4m3 with the static scales (what the library does when both streams of a
-        block take the fused QKV epilogue: token counts / offsets multiples of 16)."""
-        lib().orc_flux_set_fp8(self.h, int(bool(on)))
+        block take the fused QKV epilogue: token counts / offsets multiples of 16).  study_mode 2..6 = the alternative
+        quantisers of tools/fp8_noise_study.py (flux_oracle.cpp: lin_blk), never what the library is compared with."""
+        lib().orc_flux_set_fp8(self.h, int(study_mode) if (on and study_mode) else int(bool(on)))
         lib().orc_flux_set_fp8_attention(self.h, int(bool(on and attention)))
 
     def forward(self, img, img_ids, txt, txt_ids, timesteps, y, guidance=None):
