@@ -124,7 +124,7 @@ struct fmi_flux {
   float *mod_steps = nullptr, *vec_steps = nullptr;
   bf16_t* vec_steps_bf = nullptr;  // silu(vec_steps) in bf16: A operand of the modulation GEMM
   size_t mod_steps_rows = 0;
-  bool mod_gemm = true;  // fmi_flux_denoise: all steps' modulation vectors in one MFMA GEMM (else GEMV passes of 4 rows)
+  int mod_gemm = 1;  // fmi_flux_denoise: 1 = all steps' modulation vectors in one MFMA GEMM when there are more than 4 rows (else GEMV passes of 4 rows), 0 = always GEMV, 2 = always the GEMM
   bool fuse_qkv_relayout = true;  // QkNorm + RoPE + head/transposed relayout in the QKV GEMM's epilogue
   // Quantised block linears (nf4 / fp4 / LLM.int8): only the packed codes are resident; small launches multiply from them
   // (fused dequant-GEMM), large ones expand per call into a scratch and run the dense kernel (densify()).
@@ -1337,7 +1337,7 @@ extern "C" int fmi_flux_denoise(fmi_flux* m, const fmi_flux_inputs* in, float* i
     {
       PhaseTimer pt(m, s, PH_MOD);
       constexpr int GEMV_MAXROWS = 4;  // rows * D * 4 B of x staged in LDS per block (<= 64 KiB)
-      if (m->mod_all.q_type || (m->mod_gemm && R > GEMV_MAXROWS && m->D % 64 == 0 && nmod % 8 == 0 && R * nmod < (1ull << 31))) {
+      if (m->mod_all.q_type || (m->mod_gemm && (R > GEMV_MAXROWS || m->mod_gemm == 2) && m->D % 64 == 0 && nmod % 8 == 0 && R * nmod < (1ull << 31))) {
         // all rows in ONE pass over the matrix on the MFMA GEMM (silu(vec) rounded to bf16 like every other
         // GEMM input): the matrix is read once per image instead of once per 4 steps
         FMI_TRY(launch_silu_to_bf16(m->vec_steps, m->vec_steps_bf, (int64_t)R * m->D, s));
@@ -1379,10 +1379,11 @@ extern "C" int fmi_flux_set_fused_qkv_relayout(fmi_flux* m, int enable) {
   m->fuse_qkv_relayout = enable != 0;
   return FMI_OK;
 }
-// fmi_flux_denoise's modulation precompute: 1 (default) one MFMA GEMM over all steps, 0 f32 GEMV passes of 4 rows
+// fmi_flux_denoise's modulation precompute: 1 (default) one MFMA GEMM over all steps (when they are more than 4 rows), 0 f32 GEMV passes of 4 rows,
+// 2 the GEMM at any row count (how a 2-step full-size run is compared with the oracle THROUGH the 6.5 GB one-GEMM path)
 extern "C" int fmi_flux_set_modulation_gemm(fmi_flux* m, int enable) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
-  m->mod_gemm = enable != 0;
+  m->mod_gemm = enable == 2 ? 2 : (enable != 0);
   return FMI_OK;
 }
 // how quantised block linears are multiplied: 0 (default) by size, 1 expanded once into bf16 copies (dense cache), 2 always fused

@@ -209,7 +209,8 @@ int fmi_flux_state_adopt(fmi_flux*, const uint8_t* blob_host, size_t len);
 int fmi_flux_state_buffer(fmi_flux*, int index, void** ptr, size_t* bytes);
 /* fmi_flux_denoise computes every step's modulation vectors (they depend on t, guidance and y only) before
  * the loop: 1 (default) = one MFMA GEMM (n_steps*B, D) x (n_mod, D)^T with silu(vec) rounded to bf16, the
- * 6.5 GB modulation matrix read once per image; 0 = f32 GEMV passes of 4 rows (one pass per 4 steps). */
+ * 6.5 GB modulation matrix read once per image, taken when n_steps * B > 4; 0 = f32 GEMV passes of 4 rows (one pass per
+ * 4 steps); 2 = the GEMM at any row count (test hook: lets a 2-step run at full size go through the one-GEMM path). */
 int fmi_flux_set_modulation_gemm(fmi_flux*, int enable);
 /* fp8 inference mode (BASELINE.json configs[4]; the reference has no fp8 path, SURVEY.md §8d — the recipe
  * is this library's own, restated in oracle/flux_oracle.cpp:orc_quantize_rows_fp8).  Call once after all

@@ -132,15 +132,33 @@ def _worker(rank, world, port, n_prompts, q):
         assert rank == 0 and "rank 1" in str(e) and "boom" in str(e)
     fd.agree_or_raise(None, "nothing failed")
 
+    from diffusion_rs_amd._lib import ERR_HIP, ERR_UNSUPPORTED, FmiError
+
     class Int8Stub(StubModel):
-        def state_export(self):
-            raise RuntimeError("state_export: LLM.int8 matrices are not part of the flat state")
+        def state_export(self):  # what FluxModel.state_export raises for LLM.int8 matrices: FMI_ERR_UNSUPPORTED
+            raise FmiError("fmi status -4: state_export: LLM.int8 matrices are not part of the flat state", code=ERR_UNSUPPORTED)
 
     try:
         fd.broadcast_state(Int8Stub(), "cpu")
         raise AssertionError("broadcast_state must announce an unexportable state")
     except fd.StateExportUnsupported as e:
         assert "LLM.int8" in str(e)
+
+    # ... but ONLY that status means "every rank loads the checkpoint itself": any other failure of the export (a HIP error, out of
+    # memory, a bug) is a hard error on every rank, never a silent fall-back to N local loads
+    class BrokenStub(StubModel):
+        def state_export(self):
+            raise FmiError("fmi status -2: hipMemcpy: an illegal memory access was encountered", code=ERR_HIP)
+
+    try:
+        fd.broadcast_state(BrokenStub(), "cpu")
+        raise AssertionError("a failed export must raise")
+    except fd.StateExportUnsupported:
+        raise AssertionError("a HIP error is not 'unsupported'")
+    except FmiError as e:
+        assert rank == 0 and e.code == ERR_HIP
+    except RuntimeError as e:
+        assert rank == 1 and "illegal memory access" in str(e) and "rank 0" in str(e)
 
     q.put((rank, {k: v.numpy() for k, v in got.items()}, None if out is None else out.numpy(), fd.shard_indices(n_prompts, rank, world),
            state_sum, None if fwd is None else fwd.numpy()))

@@ -210,13 +210,14 @@ def test_c1_schnell_full_width_full_depth_matches_oracle(full_models):
     assert np.isfinite(got).all() and err <= 3e-2
 
 
-def test_c2_dev_1024_one_forward_of_the_full_model_matches_oracle(full_models):
+def test_c2_dev_1024_forward_and_two_step_trajectory_of_the_full_model_match_oracle(full_models):
     """BASELINE configs[1] — the headline config — at FULL size for one model evaluation: FLUX.1-dev, D = 3072, 19 + 38 blocks,
     S = 4096 image tokens (1024 x 1024), T = 512 text tokens, guidance 3.5: `Flux::forward` (model.rs:790-833) on the GPU against
     the f32 CPU oracle (7.4e13 FLOP: about two minutes on the box's host cores).  Every production launch shape — the
     4608 x 21504 x 3072 single-block projection with its fused q|k|v relayout, the 4608-token attention of 24 heads, the gated
     residual GEMMs at K = 15360 — is in this one comparison.  Tolerance: rel-L2 <= 2e-2 (the full-depth bar of
-    tests/test_gpu_fulldepth.py).  Needs the oracle's f32 weights in memory (48 GB): skipped on hosts without it."""
+    tests/test_gpu_fulldepth.py).  Then two Euler steps of the real 50-step schedule with the one-GEMM modulation path forced (see below):
+    latents <= 3e-2, the update itself <= 2e-2.  Needs the oracle's f32 weights in memory (48 GB): skipped on hosts without it."""
     if not full_models["wide"]:
         pytest.skip("the host cannot hold the oracle's 48 GB of f32 weights (the paged variant would take ~15 minutes for this forward)")
     torch, d, orc, gm, om = (full_models[k] for k in ("torch", "d", "orc", "gm_dev", "om"))
@@ -229,8 +230,11 @@ def test_c2_dev_1024_one_forward_of_the_full_model_matches_oracle(full_models):
     img, ids = orc.pack_latents(lat)
     assert img.shape[1] == 4096
     txt_ids = np.zeros((B, T, 3), np.float32)
-    t = np.array([0.6], np.float32)
     g = np.array([3.5], np.float32)
+    # the first three timesteps of the REAL 50-step schedule of this resolution (dynamic shifting, mu from S = 4096)
+    sched = d.SchedulerConfig()
+    ts3 = [float(v) for v in sched.get_timesteps(50, sched.calculate_shift(4096))[:3]]
+    t = np.array([ts3[0]], np.float32)
     got = host(gm.forward(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(t), dev(clip), dev(g)))
     t0 = time.time()
     ref = om.forward(img, ids, t5, txt_ids, t, clip, g)
@@ -238,6 +242,32 @@ def test_c2_dev_1024_one_forward_of_the_full_model_matches_oracle(full_models):
     err = rel_l2(got, ref)
     print(f"C2 in full (FLUX.1-dev, D=3072, 19+38 blocks, S=4096 + T=512 tokens), one Flux::forward: rel-L2 {err:.3e} (oracle {t_or:.0f} s)")
     assert np.isfinite(got).all() and err <= 2e-2
+    # --- and the TRAJECTORY: two Euler steps of the 50-step schedule at full size against the oracle's, with the
+    # modulation of both steps computed as ONE GEMM over the 6.5 GB (344 D x D) matrix — the path every 50-step run takes and the one
+    # that carried the silent > 4 GiB offset wrap of round 3 — forced at 2 rows by fmi_flux_set_modulation_gemm(2); until now that
+    # path was compared at full size only with the library's own GEMV passes.  Sampler::sample, pipelines/sampling.rs:25-48;
+    # Modulation1/2, model.rs:211-300.  The oracle's first step is the forward above (img + pred * f32(dt), orc_flux_denoise's update).
+    from diffusion_rs_amd import _lib as L
+    L.check(gm.lib.fmi_flux_set_modulation_gemm(gm.h, 2))
+    try:
+        got2 = host(gm.denoise(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(clip), dev(g), ts3))
+        mod_ms = None
+        gm.set_profiling(True)
+        gm.denoise(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(clip), dev(g), ts3)
+        mod_ms = gm.phase_ms().get("modulation")
+        gm.set_profiling(False)
+    finally:
+        L.check(gm.lib.fmi_flux_set_modulation_gemm(gm.h, 1))
+    t0 = time.time()
+    ref1 = img + ref * np.float32(ts3[1] - ts3[0])
+    ref2 = om.denoise(ref1, ids, t5, txt_ids, clip, g, ts3[1:])
+    t_or2 = time.time() - t0
+    e2, moved = rel_l2(got2, ref2), rel_l2(ref2, img)
+    print(f"C2 in full, 2 Euler steps of the 50-step schedule with the one-GEMM modulation path forced: latents rel-L2 {e2:.3e} "
+          f"(the two steps moved them by {moved:.3e}; update alone: {rel_l2(got2 - img, ref2 - img):.3e}; modulation phase {mod_ms} ms; oracle {t_or2:.0f} s)")
+    assert np.isfinite(got2).all() and e2 <= 3e-2
+    # the latents barely move in 2 of 50 steps, so the bar that means something is on the UPDATE (sum of pred * dt): the per-forward one
+    assert rel_l2(got2 - img, ref2 - img) <= 2e-2
 
 
 def test_batch_of_8_at_full_size_equals_the_samples_run_alone(full_models):

@@ -192,3 +192,35 @@ def test_bench_live_traffic_declines_cleanly(monkeypatch, tmp_path):
     monkeypatch.setenv("PATH", f"{tmp_path}:{os.environ['PATH']}")
     val, note = bench.measure_traffic_live([], timeout=30)
     assert val is None and "FETCH_SIZE" in note and "failed" in note
+
+
+def test_build_id_ties_the_library_to_the_source_tree(tmp_path):
+    """fmi_build_id() = sha256 of csrc/*, include/*.h, Makefile as compiled in; _lib.tree_build_id() recomputes it from the tree (what
+    __graft_entry__.build() compares, so a stale prebuilt .so cannot pass the build check); `make print-build-id` is the third witness."""
+    import shutil
+    import subprocess
+    lib = L.load()
+    have = lib.fmi_build_id().decode()
+    assert re.fullmatch(r"[0-9a-f]{16}", have)
+    assert have == L.tree_build_id(ROOT), "libflux_mi355x.so was not built from the sources in this tree: run `make lib`"
+    assert have == subprocess.check_output(["make", "-C", ROOT, "-s", "print-build-id"]).decode().strip()
+    assert f'"build_id": "{have}"' in lib.fmi_device_info().decode() or "no device" in lib.fmi_device_info().decode()
+    # any byte of any source moves it
+    for sub in ("diffusion-rs_amd/csrc", "include"):
+        shutil.copytree(os.path.join(ROOT, sub), tmp_path / sub)
+    shutil.copy(os.path.join(ROOT, "Makefile"), tmp_path / "Makefile")
+    assert L.tree_build_id(str(tmp_path)) == have
+    with open(tmp_path / "diffusion-rs_amd" / "csrc" / "vae.hip", "a") as f:
+        f.write("// edited\n")
+    assert L.tree_build_id(str(tmp_path)) != have
+
+
+def test_bench_as_rank_hook_is_validated():
+    """bench.py --as-rank / --as-world (the hook that lets one GPU draw rank R's samples, tests/test_gpu_multi_device.py) only goes
+    together, on one GPU, with R < N: anything else stops before touching a device."""
+    import subprocess
+    import sys
+    for bad in (["--as-rank", "1"], ["--as-rank", "2", "--as-world", "2"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + bad, capture_output=True, text=True, timeout=300,
+                           env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+        assert r.returncode != 0 and "--as-rank" in r.stderr, r.stderr[-500:]
