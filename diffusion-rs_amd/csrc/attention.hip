@@ -549,6 +549,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
 #include "attention_w4.h"
 #include "attention_w16.h"
 #include "attention_w32.h"
+#include "attention_w16l.h"
 namespace fmi {
 
 static std::atomic<bool> g_att_pingpong{true};  // process-wide test hooks, like the GEMM switches (gemm_bf16.hip)
@@ -573,6 +574,14 @@ static std::atomic<bool> g_att_w32{[] {
   return e ? atoi(e) != 0 : false;
 }()};
 void set_attention_w32(bool on) { g_att_w32 = on; }
+// bf16 operands, round 4: the lock-step schedule of the 16x16x32 kernel (attention_w16l.h) in front of all of them — the default;
+// FMI_ATT_W16L=0 / set_attention_w16l(false) falls back to the selection above.  Bit-identical to attention_w16 / _w32 at rescale
+// threshold 0, equal to rounding at the default threshold.
+static std::atomic<bool> g_att_w16l{[] {
+  const char* e = getenv("FMI_ATT_W16L");
+  return e ? atoi(e) != 0 : true;
+}()};
+void set_attention_w16l(bool on) { g_att_w16l = on; }
 
 static std::atomic<unsigned long long> g_fp8_fallbacks{0};  // fp8-QK^T launches that did not get the one-wave stream
 unsigned long long attention_fp8_fallbacks() { return g_fp8_fallbacks.load(std::memory_order_relaxed); }
@@ -622,7 +631,12 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
       hipLaunchKernelGGL((attention_pp_kernel<0, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
     else
       hipLaunchKernelGGL((attention_pp_kernel<96, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
-  } else if (g_att_w32 && Lk > ATT_KV) {  // (a single KV tile has no steady state to pipeline: the 8-wave kernel serves it)
+  } else if (g_att_w16l && Lk > ATT_KV) {  // (a single KV tile has no steady state to pipeline: the 8-wave kernel serves it)
+    if (rescale_thr_x16 == 0)
+      FMI_LAUNCH_LDS((attention_w16l_kernel<0>), 8 * 16384, grid, dim3(AW16L_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+    else
+      FMI_LAUNCH_LDS((attention_w16l_kernel<96>), 8 * 16384, grid, dim3(AW16L_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+  } else if (g_att_w32 && Lk > ATT_KV) {
     if (rescale_thr_x16 == 0)
       FMI_LAUNCH_LDS((attention_w32_kernel<0>), 8 * 16384, grid, dim3(AW32_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
     else

@@ -278,6 +278,7 @@ unsigned long long attention_fp8_fallbacks();
 void set_attention_pingpong(bool on);  // 8-wave kernels: ping-pong (default) or the single-barrier one
 void set_attention_w4(bool on);        // bf16 operands: one-wave-per-SIMD kernel (default) or the 8-wave ones
 void set_attention_w16(bool on);       // bf16 operands: the 16x16x32-MFMA one-wave kernel in front of the others (default on)
+void set_attention_w16l(bool on);      // bf16 operands: the lock-step schedule of the 16x16x32 kernel, in front of all (default on)
 void set_attention_w32(bool on);       // bf16 operands: the same design on the 32x32x16 MFMA, in front of all (default off)
 // flash attention, d = 128.  q,k: (BH, L, 128) bf16; vt: (BH, 128, Lpad) bf16 with the kv axis
 // permuted inside each group of 16 (see attention.hip); out token-major (B, L, H*128) or (BH,L,128)

@@ -68,7 +68,7 @@ int fmi_init(int device_ordinal);
 /* Device / build info as a JSON string (static storage, valid until next call); includes "build_id" and the count of fp8-QK^T
  * attention launches that fell back from the one-wave stream to the 8-wave kernel ("fp8_attention_fallbacks"). */
 const char* fmi_device_info(void);
-/* Source identity of this binary: the first 16 hex digits of sha256 over diffusion-rs_amd/csrc/*, include/*.h and the Makefile
+/* Source identity of this binary: the first 16 hex digits of sha256 over every file of diffusion-rs_amd/csrc/, include/flux_mi355x.h and the Makefile
  * (sorted by path, concatenated) at build time.  __graft_entry__.build() recomputes it from the tree and rebuilds on a mismatch,
  * so a stale prebuilt .so cannot stand in for the sources next to it. */
 const char* fmi_build_id(void);
@@ -471,7 +471,10 @@ int fmi_linear_fp8(const void* x, const uint8_t* wq, const float* w_scale, const
 int fmi_sdpa_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
                   int Lk, int d, float scale, int out_token_major, void* stream);
 /* Process-wide choice of the bf16 attention kernel (test / benchmark hook):
- *   3 (default) one wave per SIMD on v_mfma_f32_16x16x32_bf16, the whole KV stream generated assembly (attention_w16.h);
+ *   5 (default) round 4's lock-step schedule of kernel 3 (attention_w16l.h: the wave's four 16-query blocks walk a KV tile together, one
+ *     K / V^T fragment read feeds four MFMAs) — the arithmetic of 3 / 4; bit-identical to them when every tile rescales, equal to
+ *     rounding otherwise (the deferred-rescale decision is taken over 64 queries instead of 32);
+ *   3 one wave per SIMD on v_mfma_f32_16x16x32_bf16, the whole KV stream generated assembly (attention_w16.h);
  *   4 the same design on v_mfma_f32_32x32x16_bf16 (attention_w32.h) — 3 and 4 are bit-identical to each other;
  *   2 round 2's one-wave kernel (attention_w4.h), 1 the 8-wave ping-pong kernel, 0 the 8-wave single-barrier kernel — these
  *   three are bit-identical to each other, and equal to 3 / 4 to rounding (3 / 4 round q * scale * log2(e) to bf16 once and

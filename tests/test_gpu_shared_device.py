@@ -66,7 +66,7 @@ def test_attention_and_gemm_reproduce_their_idle_results_while_another_process_u
     torch, L, lib = env["torch"], env["L"], env["lib"]
     g = torch.Generator(device="cuda").manual_seed(5)
     cases = []
-    for kind in (3, 4, 2, 1, 0):  # every attention kernel: the two generated round-3 streams, the round-2 one-wave kernel, the 8-wave ones
+    for kind in (5, 3, 4, 2, 1, 0):  # every attention kernel: round 4's lock-step stream, the two generated round-3 streams, the round-2 one-wave kernel, the 8-wave ones
         for (H, Lq) in ((24, 4608), (96, 1024), (512, 128), (24, 4550)):
             q, k, v = (torch.randn((1, H, Lq, 128), generator=g, device="cuda").to(torch.bfloat16) for _ in range(3))
 
@@ -157,7 +157,7 @@ def test_attention_and_gemm_reproduce_their_idle_results_while_another_process_u
         print(f"{reps} repetitions of {len(cases)} kernels next to the co-runner; launches that differ from the idle result: {bad or 'none'}")
         assert not bad
     finally:
-        L.check(lib.fmi_set_attention_kernel(3))
+        L.check(lib.fmi_set_attention_kernel(5))
 
 
 def test_flux_forward_reproduces_its_idle_result_while_another_process_uses_the_gpu(env):

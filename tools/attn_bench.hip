@@ -112,13 +112,17 @@ int main(int argc, char** argv) {
     bf16_t* o5;
     hipMalloc((void**)&o5, n * 2);
     hipMemset(o5, 0xff, n * 2);
-    double tf[5];
-    for (int pp = 0; pp < 5; ++pp) {  // single-barrier kernel, the ping-pong kernel, the one-wave-per-SIMD kernel, the 16x16x32 one-wave kernel
+    bf16_t* o6;
+    hipMalloc((void**)&o6, n * 2);
+    hipMemset(o6, 0xff, n * 2);
+    double tf[6];
+    for (int pp = 0; pp < 6; ++pp) {  // single-barrier kernel, the ping-pong kernel, the one-wave-per-SIMD kernel, the 16x16x32 one-wave kernel, its 32x32x16 twin, the lock-step schedule
       set_attention_pingpong(pp != 0);
       set_attention_w4(pp == 2);
       set_attention_w16(pp == 3);
       set_attention_w32(pp == 4);
-      bf16_t* dst = pp == 0 ? o : pp == 1 ? o2 : pp == 2 ? o3 : pp == 3 ? o4 : o5;
+      set_attention_w16l(pp == 5);
+      bf16_t* dst = pp == 0 ? o : pp == 1 ? o2 : pp == 2 ? o3 : pp == 3 ? o4 : pp == 4 ? o5 : o6;
       for (int i = 0; i < 3; ++i) launch_attention(q, k, vt, dst, s.B, s.H, s.L, s.L, Lpad, scale, 1, nullptr);
       hipDeviceSynchronize();
       hipEventRecord(e0, nullptr);
@@ -130,7 +134,8 @@ int main(int argc, char** argv) {
       ms /= iters;
       tf[pp] = 4.0 * s.B * s.H * (double)s.L * s.L * 128 / (ms * 1e-3) / 1e12;
     }
-    std::vector<uint16_t> ha(n), hb(n), hc(n), hd(n), he(n);
+    std::vector<uint16_t> ha(n), hb(n), hc(n), hd(n), he(n), hf(n);
+    hipMemcpy(hf.data(), o6, n * 2, hipMemcpyDeviceToHost);
     hipMemcpy(hd.data(), o4, n * 2, hipMemcpyDeviceToHost);
     hipMemcpy(he.data(), o5, n * 2, hipMemcpyDeviceToHost);
     hipMemcpy(ha.data(), o, n * 2, hipMemcpyDeviceToHost);
@@ -163,6 +168,31 @@ int main(int argc, char** argv) {
       printf("   one-wave vs pp: max |diff| %.4g, first at token %zu head %zu d %zu (pp %.5g, one-wave %.5g); %zu of %zu token rows differ, last %zu\n", maxd, row,
              col / 128, col % 128, tof(hb[first]), tof(hc[first]), rows_bad, (size_t)s.B * s.L, last_row);
     }
+    {  // round 4: the lock-step schedule against attention_w16 — default threshold: to rounding; threshold 0 (every tile rescales): bit for bit
+      size_t mism = 0, nan = 0;
+      double num = 0, den = 0, mx = 0;
+      for (size_t i = 0; i < n; ++i) {
+        const double a = tof(hf[i]), b = tof(hd[i]);
+        mism += hf[i] != hd[i];
+        if (!(a == a)) ++nan;
+        num += (a - b) * (a - b), den += b * b, mx = std::max(mx, std::fabs(a - b));
+      }
+      AttnOut ao{};
+      ao.p1 = o4, ao.ld1 = s.H * 128, ao.bstride1 = (int64_t)s.L * s.H * 128;
+      set_attention_w16l(false), set_attention_w32(false), set_attention_w16(true);
+      launch_attention_ex(q, k, vt, ao, s.B, s.H, s.L, s.L, Lpad, scale, 0, nullptr);
+      ao.p1 = o6;
+      set_attention_w16l(true);
+      launch_attention_ex(q, k, vt, ao, s.B, s.H, s.L, s.L, Lpad, scale, 0, nullptr);
+      hipDeviceSynchronize();
+      std::vector<uint16_t> h0(n), h1(n);
+      hipMemcpy(h0.data(), o4, n * 2, hipMemcpyDeviceToHost);
+      hipMemcpy(h1.data(), o6, n * 2, hipMemcpyDeviceToHost);
+      size_t mism0 = 0;
+      for (size_t i = 0; i < n; ++i) mism0 += h0[i] != h1[i];
+      printf("   w16l vs w16: rel-L2 %.3e, max |diff| %.4g, NaN %zu, differing elements %zu; at threshold 0: %zu differing     w16l %7.1f TF (%6.1f us)\n",
+             std::sqrt(num / std::max(den, 1e-30)), mx, nan, mism, mism0, tf[5], 4.0 * s.B * s.H * (double)s.L * s.L * 128 / tf[5] * 1e-6);
+    }
     for (int which = 0; which < 2; ++which) {  // the round-3 kernels equal the others to rounding (Q pre-scaled, row sums of the rounded P), not bit for bit
       const std::vector<uint16_t>& hx = which ? he : hd;
       double num = 0, den = 0, mx = 0;
@@ -183,6 +213,7 @@ int main(int argc, char** argv) {
     hipFree(o3);
     hipFree(o4);
     hipFree(o5);
+    hipFree(o6);
     hipFree(q); hipFree(k); hipFree(vt); hipFree(o);
   }
   fp8_section(iters);

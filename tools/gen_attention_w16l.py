@@ -1,0 +1,553 @@
+#!/usr/bin/env python
+"""Generates diffusion-rs_amd/csrc/attention_w16l_loop.inc: the whole KV stream of attention_w16l_kernel (attention_w16l.h) as ONE
+inline-asm statement with hand-assigned registers.
+
+attention_w16l is round 4's joint-attention kernel: attention_w16's arithmetic (both products on v_mfma_f32_16x16x32_bf16, scale and the
+running maximum folded into the score MFMA, exp2 in place, row sums from a ones-row MFMA, nothing crossing lanes on the common path —
+tools/gen_attention_w16.py) on a LOCK-STEP schedule: the wave's four 16-query blocks q = 0..3 go through a KV tile TOGETHER, so a K / V^T
+fragment (one ds_read_b128 per lane) feeds FOUR MFMAs instead of two — half the LDS fragment reads and counted waits per FLOP.  Round 3's
+measurements (the stream is bound by what is issued BETWEEN the MFMAs; a ds_read_b128 costs ~14 clocks of issue with four waves
+reading, a 16-clock MFMA hides ~8) made the LDS reads the largest removable item.
+
+What lock-step costs: the two half-tile-staggered query blocks of attention_w16 gave every MFMA phase an independent softmax to hide; here a
+tile's softmax sits between ITS OWN two products.  So the products of neighbouring tiles interleave —
+
+    pre   X(0)                                                            X(t) = S^T(t) = K(t) Q^T   (64 MFMAs, 16 K fragments)
+    P1    X(1)   | softmax(0) whole (first tile: forced rescale) | barrier                Y(t) = O^T += V^T(t) P^T(t), l += 1 P^T(t)  (72 MFMAs, 16 V^T fragments)
+    loop t = 0 ..:
+      Y(t)     | mask / max tree / decision (+ rare: rescale of S, M, NM) / first half of the exponentials of tile t + 1    | DMA K(t+4)
+      if t == n-1: break
+      X(t+2)   | rare: O^T, l *= alpha | second half of the exponentials and the packs to bf16 (P) of tile t + 1 | barrier | DMA V^T(t+3)
+
+— and S^T is double-buffered (tile t lives in buffer t & 1: X(t+2) overwrites the buffer of the dead tile t while tile t+1 is still being
+exponentiated), which makes the loop body two tiles long (register names are static).  P is single-buffered: Y(t) has issued its last read of
+P(t) before X(t+2)'s packs write P(t+1).  The deferred rescale is split: the decision (any s' of the wave above the threshold) and everything
+that touches S, M and NM run in Y(t)'s gaps, BEFORE X(t+2) folds the new maximum into the next scores; the multiplication of O^T and l by
+alpha waits (flag + four saved alphas) until Y(t) — which is still accumulating tile t into them — has finished: it runs at the top of
+X(t+2).  With THR = 0 (rescale on every tile) the result is bit-identical to attention_w16 / attention_w32; with the default threshold the
+three agree to rounding (this kernel takes its decision over all 64 queries of the wave, attention_w16 per 32).
+
+LDS rings (4 K tiles, 4 V^T tiles, as before) and the one barrier per tile: barrier(t) sits in the middle of X(t+2).  K(t+4) is staged in
+Y(t) into the slot of K(t) (every wave passed barrier(t-1), i.e. finished X(t)); V^T(t+3) behind barrier(t) into the slot of V^T(t-1) (every
+wave finished Y(t-1)).  At barrier(t) a wave's newest 8 pieces (V^T(t+2), K(t+4)) may be in flight — vmcnt(8) — and what the next tile of
+reads needs (K(t+3), V^T(t+1)) is older.  Two tiles of lead for either operand, as in attention_w16.
+
+Register map (pinned by the operand constraints in attention_w16l.h):
+  a[0:127]    O^T   O[q][dt]   -> a[((8b+dt)*2+c)*4 ..], q = 2b + c      a[128:191]  Q fragments QF[q][s] -> a[128+(q*4+s)*4 ..]
+  a[192:207]  OL[q]: the ones-row product (register 0 of lanes 0..15 = the row sum of query n of block q)
+  a[208:239]  fragment buffers FR[0..7] (ds_read_b128 destinations; the MFMA takes its A operand from the accumulator half)
+  v[0:63]     S^T buffer 0: S[a][q] -> v[(4a+q)*4 ..]     v[64:127]  S^T buffer 1     v[128:159]  P[kk][q] -> v[128+(4kk+q)*4 ..]
+  v[160:163]  KAD[s]  v[164:165] VAD[kk]  v[166:169] k_voff  v[170:173] v_voff  v[174:177] k_voff clamped (ragged last tile)
+  v178        lane key offset 16 (g >> 1) + 4 (g & 1)   v179 DMA offset temporary
+  v[180:195]  NM[q] (-m of the lane's query, 4 copies)   v[196:199] M[q]   v[200:203] the ones fragment   v[204:207] ALPHA[q] (pending O^T rescale)
+  v[208:255]  temporaries (clobbers)   s[80:97] loop state (clobbers)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TILE = 16384
+VT_RING = 4 * TILE
+NBUF = 8
+LOOKAHEAD = int(os.environ.get("AW16L_LOOKAHEAD", "16"))  # a fragment is read this many MFMA slots ahead of its first use (4 fragments in flight)
+X = os.environ.get("AW16L_X", "")  # timing experiments only (wrong results): novalu | noexp | nodma | nobarrier | nomfma | nowait
+
+PMAX, TA, TB, T0, T1, AL, DL = (f"v{n}" for n in range(208, 215))
+XT = [f"v{n}" for n in range(215, 221)]
+PM0, PM1 = "v221", "v222"
+PMX = [f"v{n}" for n in range(223, 256)]  # partial maxima of the tree (33 registers)
+LKEY, DMAT = "v178", "v179"
+S_KP, S_VP, S_MASKK = "s[80:81]", "s[82:83]", "s[84:85]"
+S_T, S_TILE, S_M0K, S_M0V, S_TMP, S_RESC, S_RAG, S_TMP2, S_FLAG = "s86", "s87", "s88", "s89", "s90", "s91", "s93", "s94", "s95"
+NEG_BIG = "0xf149f2ca"  # -1e30f
+
+
+def O(q, dt):
+    b, c = q >> 1, q & 1
+    lo = ((8 * b + dt) * 2 + c) * 4
+    return f"a[{lo}:{lo + 3}]"
+
+
+def Or(q, k):  # k = 0..31: register i of d block dt, k = 4 dt + i
+    b, c = q >> 1, q & 1
+    return f"a{((8 * b + (k >> 2)) * 2 + c) * 4 + (k & 3)}"
+
+
+def QF(q, s):
+    lo = 128 + (q * 4 + s) * 4
+    return f"a[{lo}:{lo + 3}]"
+
+
+def OL(q):
+    lo = 192 + q * 4
+    return f"a[{lo}:{lo + 3}]"
+
+
+def S(buf, a, q):
+    lo = 64 * buf + (4 * a + q) * 4
+    return f"v[{lo}:{lo + 3}]"
+
+
+def Sr(buf, a, q, i):
+    return f"v{64 * buf + (4 * a + q) * 4 + i}"
+
+
+def P(kk, q):
+    lo = 128 + (4 * kk + q) * 4
+    return f"v[{lo}:{lo + 3}]"
+
+
+def Pr(kk, q, d):
+    return f"v{128 + (4 * kk + q) * 4 + d}"
+
+
+def FR(n):
+    lo = 208 + 4 * (n % NBUF)
+    return f"a[{lo}:{lo + 3}]"
+
+
+def KAD(s):
+    return f"v{160 + s}"
+
+
+def VAD(kk):
+    return f"v{164 + kk}"
+
+
+def NM(q):
+    lo = 180 + 4 * q
+    return f"v[{lo}:{lo + 3}]"
+
+
+def NMr(q, i):
+    return f"v{180 + 4 * q + i}"
+
+
+def M(q):
+    return f"v{196 + q}"
+
+
+def ALPHA(q):
+    return f"v{204 + q}"
+
+
+ONESF = "v[200:203]"
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+class Phase:
+    """One phase: its MFMA slots (text with a {fr} hole + the index of the slot's fragment) and its fragments (address register,
+    immediate) in order of first use.  kind "X": S^T(buf) = K Q^T; kind "Y": O^T += V^T P^T and the ones row."""
+
+    def __init__(self, name, kind, buf=None):
+        self.name, self.kind, self.buf = name, kind, buf
+        self.mfma, self.frags = [], []
+        if kind == "X":
+            for s in range(4):          # d-step (32 of the 128 head dimensions)
+                for a in range(4):      # key block (16 keys)
+                    self.frags.append((KAD(s), (a >> 1) * 8192 + (a & 1) * 2048))
+                    for q in range(4):
+                        acc = NM(q) if s == 0 else S(buf, a, q)  # first d-step: start from -m of the lane's query (the fold)
+                        self.mfma.append((f"v_mfma_f32_16x16x32_bf16 {S(buf, a, q)}, {{fr}}, {QF(q, s)}, {acc}", 4 * s + a))
+        else:
+            for kk in range(2):         # k-step (32 keys)
+                for dt in range(8):     # d block (16 head dimensions)
+                    self.frags.append((VAD(kk), dt * 2048))
+                    for q in range(4):
+                        self.mfma.append((f"v_mfma_f32_16x16x32_bf16 {O(q, dt)}, {{fr}}, {P(kk, q)}, {O(q, dt)}", 8 * kk + dt))
+                for q in range(4):      # V^T extended by a row of ones: the row sums of the bf16-rounded P
+                    self.mfma.append((f"v_mfma_f32_16x16x32_bf16 {OL(q)}, {ONESF}, {P(kk, q)}, {OL(q)}", None))
+        self.n = len(self.mfma)
+        nf = len(self.frags)
+        self.fu = [min(i for i, (_, ff) in enumerate(self.mfma) if ff == f) for f in range(nf)]
+        self.lu = [max(i for i, (_, ff) in enumerate(self.mfma) if ff == f) for f in range(nf)]
+        assert self.fu == sorted(self.fu) and nf % NBUF == 0
+        # set by build(): valu (list of instruction lists per gap), dma ("K" | "V" | None), barrier, advance ((regs, xor mask) applied behind the last own read)
+        self.valu, self.dma, self.barrier, self.advance = [[] for _ in range(self.n)], None, False, None
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# softmax of the tile in S^T buffer `buf`, as instruction streams
+def mask_block(buf):
+    """ragged last tile: scores of keys >= Lk become -1e30 (p = 0).  The key of (a, i) in lane (g, n) is
+    32 (a >> 1) + 8 (a & 1) + i + LKEY; S_RAG = keys in the last tile (1..64)."""
+    out = [f"v_mov_b32 {T1}, {NEG_BIG}"]
+    for a in range(4):
+        for i in range(4):
+            koff = 32 * (a >> 1) + 8 * (a & 1) + i
+            out.append(f"s_sub_i32 {S_TMP2}, {S_RAG}, {koff}")          # key valid <=> LKEY + koff < rag
+            out.append(f"v_cmp_le_i32 vcc, {S_TMP2}, {LKEY}")
+            for q in range(4):
+                out.append(f"v_cndmask_b32 {Sr(buf, a, q, i)}, {Sr(buf, a, q, i)}, {T1}, vcc")
+    return out
+
+
+def max_chain(dst, regs):
+    out = [f"v_max3_f32 {dst}, {regs[0]}, {regs[1]}, {regs[2]}"]
+    k = 3
+    while k + 1 < len(regs):
+        out.append(f"v_max3_f32 {dst}, {dst}, {regs[k]}, {regs[k + 1]}")
+        k += 2
+    if k < len(regs):
+        out.append(f"v_max_f32 {dst}, {dst}, {regs[k]}")
+    return out
+
+
+def max_tree(buf):
+    """maximum over the lane's 64 scores (all four query blocks): the common path only needs "does any score of the wave exceed the
+    threshold".  A tree of independent v_max3 (a serial chain on one register costs ~13 clocks per link with one wave per SIMD),
+    key blocks in order a = 0..3 (the order the score product finishes them in).  Result in PMAX."""
+    level = [Sr(buf, a, q, i) for a in range(4) for q in range(4) for i in range(4)]
+    out, nxt = [], 0
+    while len(level) > 1:
+        new = []
+        k = 0
+        while k < len(level):
+            rest = len(level) - k
+            dst = PMAX if (len(level) <= 3) else PMX[nxt % len(PMX)]
+            if rest >= 3:
+                out.append(f"v_max3_f32 {dst}, {level[k]}, {level[k + 1]}, {level[k + 2]}")
+                k += 3
+            elif rest == 2:
+                out.append(f"v_max_f32 {dst}, {level[k]}, {level[k + 1]}")
+                k += 2
+            else:
+                new.append(level[k])
+                k += 1
+                continue
+            new.append(dst)
+            nxt += 1
+        level = new
+    assert nxt <= len(PMX) + 1, nxt  # no partial is overwritten while live (22 + 8 + 3 + 1 = 34 results, the last in PMAX)
+    assert level == [PMAX]
+    return out
+
+
+def rescale_s(buf, set_flag):
+    """Taken when some score of the wave exceeds the threshold, and always on the first tile (M = -1e30, fold = 0): per query block q
+    the new maximum m' = max(M, max s' - NM), delta = m' + NM (how far this tile's fold was off), alpha = exp2(min(-delta, 0));
+    then s' -= delta, M = m', NM = -m' — and alpha is SAVED: O^T and l still receive tile t's second product; they are multiplied at
+    the top of the next X phase (rescale_o), flagged by S_RESC."""
+    out = []
+    for b in range(2):
+        for c, pm in ((0, PM0), (1, PM1)):
+            out += max_chain(pm, [Sr(buf, a, 2 * b + c, i) for a in range(4) for i in range(4)])
+        # reduce over the four lane groups (lanes n, n + 16, n + 32, n + 48 hold the same query): after the first swap the lower half
+        # of the wave works on query block 2b and the upper half on 2b + 1; the last swap hands every lane both results
+        out += ["s_nop 1",
+                f"v_permlane32_swap_b32 {PM0}, {PM1}",
+                "s_nop 1",
+                f"v_max_f32 {TA}, {PM0}, {PM1}",
+                f"v_mov_b32 {TB}, {TA}",
+                "s_nop 1",
+                f"v_permlane16_swap_b32 {TA}, {TB}",
+                "s_nop 1",
+                f"v_max_f32 {TA}, {TA}, {TB}",
+                f"v_mov_b32 {TB}, {TA}",
+                "s_nop 1",
+                f"v_permlane32_swap_b32 {TA}, {TB}",         # TA = block 2b's maximum in every lane, TB = block 2b + 1's
+                "s_nop 1"]
+        for c, ps in ((0, TA), (1, TB)):
+            q = 2 * b + c
+            out += [f"v_sub_f32 {T0}, {ps}, {NMr(q, 0)}",            # the maximum in the unshifted domain: ps' - NM
+                    f"v_max_f32 {T0}, {M(q)}, {T0}",                  # m'
+                    f"v_add_f32 {DL}, {T0}, {NMr(q, 0)}",             # delta = m' - (the m this tile's fold used)
+                    f"v_max_f32 {AL}, {DL}, 0",
+                    f"v_sub_f32 {AL}, 0, {AL}",
+                    f"v_exp_f32 {ALPHA(q)}, {AL}",                    # alpha = exp2(-max(delta, 0)), read much later (rescale_o)
+                    f"v_mov_b32 {M(q)}, {T0}"]
+            out += [f"v_sub_f32 {NMr(q, i)}, 0, {T0}" for i in range(4)]
+            out += [f"v_sub_f32 {Sr(buf, a, q, i)}, {Sr(buf, a, q, i)}, {DL}" for a in range(4) for i in range(4)]
+    if set_flag:
+        out.append(f"s_mov_b32 {S_RESC}, 1")
+    return out
+
+
+def rescale_o():
+    """O^T[q] *= alpha[q], l[q] *= alpha[q] for the four query blocks (rare).  Placed >= 4 MFMA slots behind the last MFMA that wrote
+    them (the previous Y phase); the X phase around it does not touch these accumulators."""
+    out = []
+    for q in range(4):
+        lo = 192 + q * 4
+        out += [f"v_accvgpr_read_b32 {T1}, a{lo}", "s_nop 0", f"v_mul_f32 {T1}, {T1}, {ALPHA(q)}", "s_nop 0", f"v_accvgpr_write_b32 a{lo}, {T1}"]
+        n = len(XT)
+        out.append(f"v_accvgpr_read_b32 {XT[0]}, {Or(q, 0)}")
+        for r in range(32):  # software pipeline over the 32 accumulator registers of block q
+            if r + 1 < 32:
+                out.append(f"v_accvgpr_read_b32 {XT[(r + 1) % n]}, {Or(q, r + 1)}")
+            out.append(f"v_mul_f32 {XT[r % n]}, {XT[r % n]}, {ALPHA(q)}")
+            out.append(f"v_accvgpr_write_b32 {Or(q, r)}, {XT[r % n]}")
+    out.append(f"s_mov_b32 {S_RESC}, 0")
+    return out
+
+
+def exps(buf, a, q):
+    return [f"v_exp_f32 {Sr(buf, a, q, i)}, {Sr(buf, a, q, i)}" for i in range(4)]
+
+
+def packs(buf, a, q):
+    kk, h = a >> 1, a & 1  # P[kk][q] dwords 2h, 2h + 1
+    return [f"v_cvt_pk_bf16_f32 {Pr(kk, q, 2 * h + d)}, {Sr(buf, a, q, 2 * d)}, {Sr(buf, a, q, 2 * d + 1)}" for d in range(2)]
+
+
+def exp_pack_stream(buf, a_list, SKEW=2):
+    """p = exp2(s') in place, then per unit of 4 scores (a, q) two packs to bf16.  The packs of unit u follow the exponentials of unit
+    u + SKEW: a v_exp_f32 result must not be read within the next few VALU instructions (gfx950: stale in half of the lanes, DESIGN
+    4.4 rule 2)."""
+    units = [(a, q) for a in a_list for q in range(4)]
+    out = []
+    for u in range(len(units) + SKEW):
+        if u < len(units):
+            out += exps(buf, *units[u])
+        if u >= SKEW:
+            out += packs(buf, *units[u - SKEW])
+    return out
+
+
+def spread(plan, stream, first, last):
+    """stream instructions over gaps first..last (inclusive), as evenly as integer division allows, in order"""
+    n = last - first + 1
+    for k, ins in enumerate(stream):
+        plan[first + k * n // len(stream)].append(ins)
+
+
+def plan_y(ph, buf, uid):
+    """Y(t)'s gaps: mask (ragged last tile), max tree, decision (+ rare rescale of S / M / NM), first half of the exponentials — of tile
+    t + 1 in S^T buffer `buf`, which the X phase in front of this one completed (its last MFMAs are >= 4 slots behind gap 4)."""
+    n, plan = ph.n, ph.valu
+    skipm = f".Law16l_nomask_{uid}_%="
+    plan[4] += [f"s_cmp_eq_u32 {S_FLAG}, 0", f"s_cbranch_scc1 {skipm}"] + mask_block(buf) + [f"{skipm}:"]
+    spread(plan, max_tree(buf), 5, 19)
+    skip = f".Law16l_skip_{uid}_%="
+    plan[21] += [f"v_cmp_lt_f32 vcc, %[thr], {PMAX}", f"s_cbranch_vccz {skip}"] + rescale_s(buf, True) + [f"{skip}:"]
+    spread(plan, [i for a in (0, 1) for q in range(4) for i in exps(buf, a, q)], 22, n - 1)
+
+
+def plan_x(ph, buf, uid):
+    """X(t+2)'s gaps: the pending O^T / l rescale (rare), then for tile t + 1 (buffer `buf`): packs of key blocks 0, 1 (exponentiated in
+    the Y phase before), exponentials + packs of key blocks 2, 3.  P[kk = 0] is complete by mid-phase, P[kk = 1] by the last gap (Y(t+1)
+    reads it from its slot 36 on)."""
+    n, plan = ph.n, ph.valu
+    skip = f".Law16l_noresc_{uid}_%="
+    plan[4] += [f"s_cmp_eq_u32 {S_RESC}, 0", f"s_cbranch_scc1 {skip}"] + rescale_o() + [f"{skip}:"]
+    early = [i for a in (0, 1) for q in range(4) for i in packs(buf, a, q)]
+    late = exp_pack_stream(buf, (2, 3))
+    # the 16 early packs alternate with the first 16 instructions of the late stream: P[kk = 0] is complete after a third of the
+    # phase, and the exponentials start at once; the last pack sits a few gaps in front of the next phase
+    stream = []
+    for k, ins in enumerate(late):
+        stream.append(ins)
+        if k < len(early):
+            stream.append(early[k])
+    spread(plan, stream, 5, n - 3)
+
+
+def plan_p1(ph, uid):
+    """P1 = X(1) | all exponentials and packs of tile 0 (buffer 0).  Tile 0's maxima (the rescale block, unconditional on a first tile:
+    M = -1e30, NM = 0) were taken BETWEEN pre and P1 — X(1) folds -m into its scores, so NM must be final before its first MFMA;
+    everywhere else in the stream the rescale of tile t + 1 runs inside Y(t), where no score product is in flight."""
+    n, plan = ph.n, ph.valu
+    spread(plan, exp_pack_stream(0, (0, 1, 2, 3)), 1, n - 3)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+def emit_phase(ph, nxt, own_prefetch=False, drain=False):
+    """asm lines of one phase.  `nxt` = the phase whose first fragments are fetched behind this phase's last MFMAs (None: none).
+    Fragment f of a phase is read in the gap behind MFMA slot fu[f] - LOOKAHEAD (a negative slot: in the previous phase's tail, or in
+    front of the phase when own_prefetch)."""
+    o = [f"; ==== phase {ph.name}"]
+    n, nf = ph.n, len(ph.frags)
+    reads = [[] for _ in range(n)]
+    early = []
+    for f, (reg, imm) in enumerate(ph.frags):
+        i = ph.fu[f] - LOOKAHEAD
+        (reads[i] if i >= 0 else early).append(((0, f), FR(f), reg, imm))
+    own_last_read = max([g for g in range(n) if reads[g]], default=-1)
+    if nxt is not None:
+        for f, (reg, imm) in enumerate(nxt.frags):
+            i = n + nxt.fu[f] - LOOKAHEAD
+            if i < n:
+                assert i > own_last_read, (ph.name, "next phase's reads must follow the own ones")
+                reads[i].append(((1, f), FR(f), reg, imm))
+    if own_prefetch:
+        for (_, b_, reg, imm) in early:
+            o.append(f"ds_read_b128 {b_}, {reg} offset:{imm}")
+    order = [key for (key, _, _, _) in early]
+    issued_before_slot = [len(order)]
+    for g in range(n):
+        order += [key for (key, _, _, _) in reads[g]]
+        issued_before_slot.append(len(order))
+    last = {}
+    for k, key in enumerate(order):
+        last[key] = k
+    # ring-slot advance of the address registers: each right behind the last own read that uses it
+    adv_at = [[] for _ in range(n)]
+    if ph.advance:
+        regs, mask = ph.advance
+        for reg in regs:
+            own = [g for g in range(n) for (key, _, r_, _) in reads[g] if key[0] == 0 and r_ == reg]
+            g_last = max(own, default=0)
+            nxt_use = [g for g in range(n) for (key, _, r_, _) in reads[g] if key[0] == 1 and r_ == reg]
+            assert all(g > g_last for g in nxt_use), (ph.name, reg, g_last, nxt_use)
+            adv_at[g_last].append(f"v_xor_b32 {reg}, 0x{mask:x}, {reg}")
+    for i in range(n):
+        text, f = ph.mfma[i]
+        pre, post = [], []
+        dma = None
+        if ph.dma == "K" and i % (n // 4) == n // 8 - 1 and X != "nodma":       # 4 pieces, one per quarter
+            piece = i // (n // 4)
+            pre.append(f"s_add_i32 m0, {S_M0K}, {piece * 1024}")
+            pre.append(f"v_cndmask_b32 {DMAT}, v{166 + piece}, v{174 + piece}, {S_MASKK}")
+            dma = f"global_load_lds_dwordx4 {DMAT}, {S_KP}"
+        if ph.dma == "V" and i >= n // 2 and (i - n // 2) % (n // 8) == n // 8 - 1 and X != "nodma":   # 4 pieces in the second half, behind the barrier
+            piece = (i - n // 2) // (n // 8)
+            pre.append(f"s_add_i32 m0, {S_M0V}, {piece * 1024}")
+            dma = f"global_load_lds_dwordx4 v{170 + piece}, {S_VP}"
+        if i % 4 == 0:  # counted wait (LDS reads retire in order) for every fragment first used in slots i .. i + 3
+            need = [f2 for f2 in range(nf) if i <= ph.fu[f2] < i + 4]
+            if need:
+                younger = issued_before_slot[i] - last[(0, max(need))] - 1
+                assert 0 <= younger <= 15, (ph.name, i, younger)
+                pre.append(f"s_waitcnt lgkmcnt({younger})")
+        mf = text.format(fr=FR(f)) if f is not None else text
+        rd = [f"ds_read_b128 {b_}, {reg} offset:{imm}" for (_, b_, reg, imm) in reads[i]]
+        post += adv_at[i]
+        post += ph.valu[i]
+        if X == "nomfma":
+            mf = "s_nop 0"
+        if X == "nowait":
+            pre = [p_ for p_ in pre if not p_.startswith("s_waitcnt lgkmcnt")]
+        if X == "novalu":
+            post = [p_ for p_ in post if p_.startswith(("s_", ".Law16l", "v_xor", "v_cmp"))]
+        if X == "noexp":
+            post = [p_.replace("v_exp_f32", "v_mov_b32") for p_ in post]
+        o.append(f"; slot {i}")
+        o += pre + [mf] + rd
+        if dma:
+            o.append(dma)
+        o += post
+        if ph.barrier and i == n // 2 and X != "nobarrier":
+            # everything but this wave's newest pieces — V^T(t+2) [4] and K(t+4) [4] — has landed: K(t+3), V^T(t+1)
+            o += ["s_waitcnt vmcnt(8)", "s_barrier"]
+    if drain:
+        o += ["s_waitcnt lgkmcnt(0)", "s_nop 15", "s_nop 15", "s_nop 15"]
+    return o
+
+
+def check_rule3(seq):
+    """Linearise a sequence of phases and assert that every read refills a buffer whose previous fragment's LAST MFMA sits strictly
+    before the MFMA slot the read is issued behind (so a later MFMA has issued and the old operand has left the front of the matrix
+    pipe — DESIGN 4.4 rule 3), and that reads are issued in stream order."""
+    base, last_user, prev_rd = 0, {}, None
+    for ph in seq:
+        for f in range(len(ph.frags)):
+            rd = base + ph.fu[f] - LOOKAHEAD
+            assert prev_rd is None or rd >= prev_rd, ("stream order", ph.name, f)
+            prev_rd = rd
+            pb = f % NBUF
+            assert last_user.get(pb, -10**9) < rd, ("rule 3", ph.name, f, pb, last_user.get(pb), rd)
+            last_user[pb] = base + ph.lu[f]
+        base += ph.n
+
+
+def build():
+    K_REGS, V_REGS = [KAD(s) for s in range(4)], [VAD(k) for k in range(2)]
+    EVEN, ODD = TILE, 3 * TILE  # ring slot s -> s + 1: xor 1 << 14 out of an even slot, 3 << 14 out of an odd one
+    pre = Phase("pre: X(0) -> S0", "X", 0)
+    pre.advance = (K_REGS, EVEN)                    # K leaves slot 0
+    p1 = Phase("P1: X(1) -> S1 | softmax(0)", "X", 1)
+    p1.advance, p1.barrier = (K_REGS, ODD), True    # K leaves slot 1
+    plan_p1(p1, "p1")
+    ye = Phase("Y(t), t even | softmax 1st half of tile t+1 (S1)", "Y")
+    ye.advance, ye.dma = (V_REGS, EVEN), "K"
+    plan_y(ye, 1, "ye")
+    xe = Phase("X(t+2) -> S0, t even | softmax 2nd half of tile t+1 (S1)", "X", 0)
+    xe.advance, xe.dma, xe.barrier = (K_REGS, EVEN), "V", True   # t + 2 even
+    plan_x(xe, 1, "xe")
+    yo = Phase("Y(t), t odd | softmax 1st half of tile t+1 (S0)", "Y")
+    yo.advance, yo.dma = (V_REGS, ODD), "K"
+    plan_y(yo, 0, "yo")
+    xo = Phase("X(t+2) -> S1, t odd | softmax 2nd half of tile t+1 (S0)", "X", 1)
+    xo.advance, xo.dma, xo.barrier = (K_REGS, ODD), "V", True
+    plan_x(xo, 0, "xo")
+    return pre, p1, ye, xe, yo, xo
+
+
+def stream():
+    pre, p1, ye, xe, yo, xo = build()
+    check_rule3([pre, p1, ye, xe, yo, xo, ye, xe, yo, xo, ye])
+
+    def dma_setup():
+        """scalar state of one tile: K(min(t + 4, n - 1)) and V^T(min(t + 3, n - 1)): HBM base and ring slot of either"""
+        return [f"s_add_i32 {S_TILE}, {S_T}, 4",
+                f"s_min_i32 {S_TILE}, {S_TILE}, %[ntm1]",
+                f"s_lshl_b32 {S_TMP}, {S_TILE}, 14",
+                "s_add_u32 s80, %[kb_lo], " + S_TMP,
+                "s_addc_u32 s81, %[kb_hi], 0",
+                f"s_and_b32 {S_TMP}, {S_TILE}, 3",
+                f"s_lshl_b32 {S_M0K}, {S_TMP}, 14",
+                f"s_add_i32 {S_M0K}, {S_M0K}, %[woffk]",
+                f"s_cmp_eq_u32 {S_TILE}, %[ntm1]",
+                f"s_cselect_b64 {S_MASKK}, -1, 0",
+                f"s_add_i32 {S_TILE}, {S_T}, 3",
+                f"s_min_i32 {S_TILE}, {S_TILE}, %[ntm1]",
+                f"s_lshl_b32 {S_TMP}, {S_TILE}, 7",
+                "s_add_u32 s82, %[vb_lo], " + S_TMP,
+                "s_addc_u32 s83, %[vb_hi], 0",
+                f"s_and_b32 {S_TMP}, {S_TILE}, 3",
+                f"s_lshl_b32 {S_TMP}, {S_TMP}, 14",
+                f"s_add_i32 {S_M0V}, {S_TMP}, %[woffv]"]
+
+    def rag_flag():
+        """S_FLAG = 1 when the softmax of this Y phase (tile t + 1) works on the last tile and that tile is ragged"""
+        return [f"s_add_i32 {S_TMP}, {S_T}, 1",
+                f"s_cmp_eq_u32 {S_TMP}, %[ntm1]",
+                f"s_cselect_b32 {S_FLAG}, 1, 0",
+                f"s_cmp_lt_u32 {S_RAG}, 64",
+                f"s_cselect_b32 {S_FLAG}, {S_FLAG}, 0"]
+
+    o = [f"s_mov_b32 {S_RAG}, %[rag]", f"s_mov_b32 {S_FLAG}, 0", f"s_mov_b32 {S_RESC}, 0", f"s_mov_b32 {S_T}, 0"]
+    o += emit_phase(pre, p1, own_prefetch=True)
+    # the one un-hidden softmax piece of a workgroup: tile 0's maxima.  X(0)'s last MFMAs must have written S0 (an MFMA result needs
+    # ~40 clocks); tile 0 is never the ragged last tile (n >= 2); O^T = l = 0: no rescale_o, no flag
+    o += ["s_nop 15", "s_nop 15", "s_nop 15", "s_nop 15"] + rescale_s(0, False)
+    o += emit_phase(p1, ye)
+    o += [".Law16l_loop_%=:"]
+    for y, x in ((ye, xe), (yo, xo)):
+        o += dma_setup() + rag_flag()
+        o += emit_phase(y, x)
+        o += [f"s_cmp_eq_u32 {S_T}, %[ntm1]",
+              "s_cbranch_scc1 .Law16l_done_%="]
+        o += emit_phase(x, yo if y is ye else ye)
+        o += [f"s_add_i32 {S_T}, {S_T}, 1"]
+    o += ["s_branch .Law16l_loop_%=",
+          ".Law16l_done_%=:",
+          # Y's tail fetched fragments of an X phase that does not follow: let them land; the statement ends drained
+          "s_waitcnt lgkmcnt(0)", "s_nop 15", "s_nop 15", "s_nop 15", "s_nop 15"]
+    return o
+
+
+def main():
+    lines = stream()
+    stem = "attention_w16l_loop"
+    path = os.path.join(ROOT, "diffusion-rs_amd", "csrc", stem + ".inc")
+    if X:
+        os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+        path = os.path.join(ROOT, "build", f"{stem}_{X}.inc")
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/gen_attention_w16l.py — do not edit.  The whole KV stream of attention_w16l_kernel as one asm\n")
+        f.write("// statement (pre, P1, loop { Y(t); X(t+2) } unrolled over two tiles); register map and schedule: see the generator.\n")
+        f.write("#define FMI_AW16L_LOOP_ASM \\\n")
+        body = ['  "' + ln + '\\n\\t"' for ln in lines if not ln.startswith(";")]
+        f.write(" \\\n".join(body))
+        f.write("\n")
+    if os.environ.get("AW16L_DUMP"):
+        with open(os.environ["AW16L_DUMP"], "w") as f:
+            f.write("\n".join(lines) + "\n")
+    n_mfma = sum(1 for ln in lines if ln.startswith("v_mfma"))
+    n_other = sum(1 for ln in lines if not ln.startswith(";") and not ln.startswith("v_mfma") and not ln.endswith(":"))
+    print(f"{path}: {len(lines)} lines, {n_mfma} MFMAs, {n_other} other instructions", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
