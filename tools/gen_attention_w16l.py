@@ -51,6 +51,9 @@ VT_RING = 4 * TILE
 NBUF = 8
 LOOKAHEAD = int(os.environ.get("AW16L_LOOKAHEAD", "16"))  # a fragment is read this many MFMA slots ahead of its first use (4 fragments in flight)
 X = os.environ.get("AW16L_X", "")  # timing experiments only (wrong results): novalu | noexp | nodma | nobarrier | nomfma | nowait
+TAG = os.environ.get("AW16L_TAG", X)  # a tag (or an experiment) writes build/attention_w16l_loop_<tag>.inc instead of the committed file
+EY = int(os.environ.get("AW16L_EY", "8"))  # how many of a tile's 16 exponential units (4 scores each, key-block major) run in the Y phase; the rest in X
+TREE_END = int(os.environ.get("AW16L_TREE_END", "19"))  # last gap of the max tree in a Y phase (the decision sits two gaps behind it)
 
 PMAX, TA, TB, T0, T1, AL, DL = (f"v{n}" for n in range(208, 215))
 XT = [f"v{n}" for n in range(215, 221)]
@@ -290,11 +293,13 @@ def packs(buf, a, q):
     return [f"v_cvt_pk_bf16_f32 {Pr(kk, q, 2 * h + d)}, {Sr(buf, a, q, 2 * d)}, {Sr(buf, a, q, 2 * d + 1)}" for d in range(2)]
 
 
-def exp_pack_stream(buf, a_list, SKEW=2):
+UNITS = [(a, q) for a in range(4) for q in range(4)]  # a tile's 16 units of 4 scores, in the order the score product finishes them
+
+
+def exp_pack_stream(buf, units, SKEW=2):
     """p = exp2(s') in place, then per unit of 4 scores (a, q) two packs to bf16.  The packs of unit u follow the exponentials of unit
     u + SKEW: a v_exp_f32 result must not be read within the next few VALU instructions (gfx950: stale in half of the lanes, DESIGN
     4.4 rule 2)."""
-    units = [(a, q) for a in a_list for q in range(4)]
     out = []
     for u in range(len(units) + SKEW):
         if u < len(units):
@@ -317,10 +322,10 @@ def plan_y(ph, buf, uid):
     n, plan = ph.n, ph.valu
     skipm = f".Law16l_nomask_{uid}_%="
     plan[4] += [f"s_cmp_eq_u32 {S_FLAG}, 0", f"s_cbranch_scc1 {skipm}"] + mask_block(buf) + [f"{skipm}:"]
-    spread(plan, max_tree(buf), 5, 19)
+    spread(plan, max_tree(buf), 5, TREE_END)
     skip = f".Law16l_skip_{uid}_%="
-    plan[21] += [f"v_cmp_lt_f32 vcc, %[thr], {PMAX}", f"s_cbranch_vccz {skip}"] + rescale_s(buf, True) + [f"{skip}:"]
-    spread(plan, [i for a in (0, 1) for q in range(4) for i in exps(buf, a, q)], 22, n - 1)
+    plan[TREE_END + 2] += [f"v_cmp_lt_f32 vcc, %[thr], {PMAX}", f"s_cbranch_vccz {skip}"] + rescale_s(buf, True) + [f"{skip}:"]
+    spread(plan, [i for (a, q) in UNITS[:EY] for i in exps(buf, a, q)], TREE_END + 3, n - 1)
 
 
 def plan_x(ph, buf, uid):
@@ -330,8 +335,8 @@ def plan_x(ph, buf, uid):
     n, plan = ph.n, ph.valu
     skip = f".Law16l_noresc_{uid}_%="
     plan[4] += [f"s_cmp_eq_u32 {S_RESC}, 0", f"s_cbranch_scc1 {skip}"] + rescale_o() + [f"{skip}:"]
-    early = [i for a in (0, 1) for q in range(4) for i in packs(buf, a, q)]
-    late = exp_pack_stream(buf, (2, 3))
+    early = [i for (a, q) in UNITS[:EY] for i in packs(buf, a, q)]
+    late = exp_pack_stream(buf, UNITS[EY:])
     # the 16 early packs alternate with the first 16 instructions of the late stream: P[kk = 0] is complete after a third of the
     # phase, and the exponentials start at once; the last pack sits a few gaps in front of the next phase
     stream = []
@@ -347,7 +352,7 @@ def plan_p1(ph, uid):
     M = -1e30, NM = 0) were taken BETWEEN pre and P1 — X(1) folds -m into its scores, so NM must be final before its first MFMA;
     everywhere else in the stream the rescale of tile t + 1 runs inside Y(t), where no score product is in flight."""
     n, plan = ph.n, ph.valu
-    spread(plan, exp_pack_stream(0, (0, 1, 2, 3)), 1, n - 3)
+    spread(plan, exp_pack_stream(0, UNITS), 1, n - 3)
 
 
 # ----------------------------------------------------------------------------------------------------------------------------
@@ -531,9 +536,9 @@ def main():
     lines = stream()
     stem = "attention_w16l_loop"
     path = os.path.join(ROOT, "diffusion-rs_amd", "csrc", stem + ".inc")
-    if X:
+    if TAG:
         os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
-        path = os.path.join(ROOT, "build", f"{stem}_{X}.inc")
+        path = os.path.join(ROOT, "build", f"{stem}_{TAG}.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_attention_w16l.py — do not edit.  The whole KV stream of attention_w16l_kernel as one asm\n")
         f.write("// statement (pre, P1, loop { Y(t); X(t+2) } unrolled over two tiles); register map and schedule: see the generator.\n")
