@@ -116,6 +116,11 @@ struct fmi_flux {
   } ws;
   // profiling
   bool profiling = false;
+  // Experiment (FMI_TWO_STREAMS=1, read at create): the image and text chains of a double block between two attentions
+  // (proj -> LayerNorm -> MLP) run on two streams so that the text chain's small launches fill the partial rounds of the image chain
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool two_streams = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float phase_ms[PH_COUNT] = {0};
   int attn_thr = 96;
@@ -873,6 +878,34 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       if (sp) FMI_TRY(attention_sp(m, o, T, S, sc, s));
       else FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0, nullptr, 0, qk8 ? -m->n8_dbl[i] : ATT_NO_EXP2));
     }
+    if (m->two_streams && !fp8 && !sp && !m->profiling && !bw.proj[0].q_type && !bw.proj[1].q_type && !bw.mlp1[0].q_type && !bw.mlp1[1].q_type &&
+        !bw.mlp2[0].q_type && !bw.mlp2[1].q_type && !m->split_k) {
+      // the two chains are independent from here to the next block's joint attention: text on the side stream, image on the caller's
+      bf16_t* hid_txt = w.hid;
+      bf16_t* hid_img = w.hid + (size_t)B * T * Mh;
+      FMI_HIP_TRY(hipEventRecord(m->ev_fork, s));
+      FMI_HIP_TRY(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+      for (int st = 0; st < 2; ++st) {  // st 0 = image chain on s, 1 = text chain on the side stream
+        hipStream_t q = st ? m->side : s;
+        const int rows = st ? B * T : B * S, rpb = st ? T : S;
+        const float* mo = st ? mt : mi;
+        float* x = st ? w.x_txt : w.x_img;
+        bf16_t* xm_ = st ? xm_txt : xm_img;
+        bf16_t* hid_ = st ? hid_txt : hid_img;
+        GemmProblem p = make_problem(bw.proj[st], st ? w.attn_txt : w.attn_img, D, rows, x, D, EPI_RESID_GATE_F32);
+        with_gate(p, mo + 2 * D, rpb, nmod);
+        FMI_TRY(gemm1(m, p, bw.proj[st], q));
+        FMI_TRY(launch_layernorm_mod(x, mo + 4 * D, mo + 3 * D, nmod, rpb, xm_, rows, D, 1e-6f, q));
+        p = make_problem(bw.mlp1[st], xm_, D, rows, hid_, Mh, EPI_GELU_BF16);
+        FMI_TRY(gemm1(m, p, bw.mlp1[st], q));
+        p = make_problem(bw.mlp2[st], hid_, Mh, rows, x, D, EPI_RESID_GATE_F32);
+        with_gate(p, mo + 5 * D, rpb, nmod);
+        FMI_TRY(gemm1(m, p, bw.mlp2[st], q));
+      }
+      FMI_HIP_TRY(hipEventRecord(m->ev_join, m->side));
+      FMI_HIP_TRY(hipStreamWaitEvent(s, m->ev_join, 0));
+      continue;
+    }
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
       GemmProblem p[2];
@@ -1035,6 +1068,11 @@ extern "C" int fmi_flux_create(const fmi_flux_config* cfg, fmi_model_dtype dtype
   resolve_base_and_names(m);
   hipEventCreate(&m->ev0);
   hipEventCreate(&m->ev1);
+  if (const char* e = getenv("FMI_TWO_STREAMS"); e && atoi(e) != 0) {
+    m->two_streams = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) == hipSuccess;
+  }
   *out = m;
   return FMI_OK;
 }
@@ -1061,6 +1099,9 @@ extern "C" void fmi_flux_destroy(fmi_flux* m) {
     }
   if (m->ev0) hipEventDestroy(m->ev0);
   if (m->ev1) hipEventDestroy(m->ev1);
+  if (m->ev_fork) hipEventDestroy(m->ev_fork);
+  if (m->ev_join) hipEventDestroy(m->ev_join);
+  if (m->side) hipStreamDestroy(m->side);
   delete m;
 }
 
