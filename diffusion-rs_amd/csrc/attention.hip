@@ -618,6 +618,15 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
     }
     const bool pow2 = n2 <= 0 && n2 >= -126;
     if (!(g_att_w16 && Lk > ATT_KV && pow2)) g_fp8_fallbacks.fetch_add(1, std::memory_order_relaxed);
+    if (g_att_w16l && g_att_w16 && Lk > ATT_KV && pow2) {  // round 4: the lock-step schedule's fp8-QK^T stream
+      const float sl2 = ldexpf(1.0f, n2);
+      if (rescale_thr_x16 == 0)
+        FMI_LAUNCH_LDS((attention_w16l_kernel<0, true>), 8 * 16384, grid, dim3(AW16L_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl2);
+      else
+        FMI_LAUNCH_LDS((attention_w16l_kernel<96, true>), 8 * 16384, grid, dim3(AW16L_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl2);
+      FMI_LAUNCH_CHECK();
+      return FMI_OK;
+    }
     if (g_att_w16 && Lk > ATT_KV && pow2) {
       const float sl2 = ldexpf(1.0f, n2);
       if (rescale_thr_x16 == 0)

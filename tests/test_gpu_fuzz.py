@@ -190,6 +190,21 @@ def test_lockstep_attention_is_bit_identical_to_w16_when_every_tile_rescales(env
             e = float((outs[(96, 5)] - outs[(96, 3)]).norm() / outs[(96, 3)].norm())
             print(f"S={hw[0] * hw[1]} T={T}: threshold 0: w16l == w16 == w32 bit for bit; default threshold: w16l vs w16 rel-L2 {e:.2e}")
             assert e <= 2e-3
+        # the fp8-QK^T streams of the two schedules (the model's fp8 mode: q, k as e4m3 codes from the fused epilogue, score factor in the
+        # MFMA's block scale): the same statement.  Token counts multiples of 16 so that the fp8 attention is really taken.
+        m.quantize_fp8()
+        L.check(lib.fmi_flux_set_attention_rescale_threshold(m.h, 0))
+        for (hw, T) in (((16, 16), 64), ((64, 64), 400)):
+            img, ids, txt, txt_ids, y = flux_inputs(cfg, 1, hw, T, seed=hw[0] + 1)
+            args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(np.array([0.5], np.float32)), dev(y), dev(np.array([3.5], np.float32)))
+            o8 = {}
+            for kind in (3, 5):
+                L.check(lib.fmi_set_attention_kernel(kind))
+                o8[kind] = m.forward(*args).clone()
+            torch.cuda.synchronize()
+            nbad = int((o8[5].view(torch.int32) != o8[3].view(torch.int32)).sum())
+            print(f"fp8 mode, S={hw[0] * hw[1]} T={T}, threshold 0: lock-step fp8-QK stream vs attention_w16 QK8: {nbad} differing elements")
+            assert nbad == 0 and bool(torch.isfinite(o8[5]).all())
     finally:
         L.check(lib.fmi_set_attention_kernel(5))
         m.close()

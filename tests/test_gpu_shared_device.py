@@ -129,11 +129,16 @@ def test_attention_and_gemm_reproduce_their_idle_results_while_another_process_u
         return o
     cases.append(("sdpa fp8 QK", run_fp8_attn))
 
-    def run_fp8_attn_onewave(q8=q8, k8=k8, v=v, H=H, Lq=Lq):  # a power-of-two score factor: the one-wave generated stream (attention_w16 QK8)
+    from tests.util import pow2_attention_scale
+    sc17 = pow2_attention_scale(-17)
+
+    def run_fp8_attn_onewave(kind, q8=q8, k8=k8, v=v, H=H, Lq=Lq):  # a power-of-two score factor: the one-wave generated streams
+        L.check(lib.fmi_set_attention_kernel(kind))
         o = torch.full((1, Lq, H * 128), float("nan"), dtype=torch.bfloat16, device="cuda")
-        L.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o), 1, H, Lq, Lq, 128, 2.0 ** -17 / 1.4426950408889634, 1, None))
+        L.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o), 1, H, Lq, Lq, 128, sc17, 1, None))
         return o
-    cases.append(("sdpa fp8 QK one-wave", run_fp8_attn_onewave))
+    cases.append(("sdpa fp8 QK one-wave lock-step (attention_w16l QK8)", lambda: run_fp8_attn_onewave(5)))
+    cases.append(("sdpa fp8 QK one-wave (attention_w16 QK8)", lambda: run_fp8_attn_onewave(3)))
     try:
         idle = []
         for name, run in cases:

@@ -43,3 +43,17 @@ def flux_inputs(cfg, B, S_hw, T, seed=1234):
     ids[:, :, 2] = np.tile(np.arange(w2), h2)[None]
     txt_ids = np.zeros((B, T, 3), np.float32)
     return img, ids, txt, txt_ids, y
+
+
+def pow2_attention_scale(n):
+    """An f32 `scale` with f32(scale * f32(log2 e)) == 2^n bit for bit: what fmi_sdpa_fp8qk needs to take a one-wave stream (the score
+    factor rides in the MFMA's E8M0 block scale; a factor that is not exactly a power of two runs on the 8-wave kernel and is counted)."""
+    log2e = np.float32(1.4426950408889634)
+    target = np.float32(2.0 ** n)
+    c = np.float32(target / log2e)
+    for _ in range(8):
+        got = np.float32(c * log2e)
+        if got == target:
+            return float(c)
+        c = np.nextafter(c, np.float32(np.inf if got < target else -np.inf), dtype=np.float32)
+    raise AssertionError(f"no f32 scale with scale * log2(e) == 2^{n}")

@@ -44,17 +44,19 @@ static void fp8_section(int iters) {
     const int Lpad = (s.L + 63) / 64 * 64;
     const size_t n = (size_t)s.B * s.H * s.L * 128, nv = (size_t)s.B * s.H * 128 * Lpad;
     uint8_t *q, *k;
-    bf16_t *vt, *oa, *ob;
+    bf16_t *vt, *oa, *ob, *oc;
     hipMalloc((void**)&q, n); hipMalloc((void**)&k, n); hipMalloc((void**)&vt, nv * 2); hipMalloc((void**)&oa, n * 2); hipMalloc((void**)&ob, n * 2);
+    hipMalloc((void**)&oc, n * 2);
     fill_e4m3_kernel<<<2048, 256>>>(q, n, 11u); fill_e4m3_kernel<<<2048, 256>>>(k, n, 12u); fill_kernel<<<2048, 256>>>(vt, nv, 3u);
     hipDeviceSynchronize();
     const float scale = ldexpf(1.0f, -6) / 1.4426950408889634f;  // scale * log2(e) = 2^-6
     AttnOut out{};
     out.p1 = oa, out.ld1 = s.H * 128, out.bstride1 = (int64_t)s.L * s.H * 128;
-    double us[2];
-    for (int w = 0; w < 2; ++w) {
-      set_attention_w16(w == 1);
-      out.p1 = w ? ob : oa;
+    double us[3];
+    for (int w = 0; w < 3; ++w) {  // 8-wave fp8 kernel, round 3's one-wave stream, round 4's lock-step stream
+      set_attention_w16(w >= 1);
+      set_attention_w16l(w == 2);
+      out.p1 = w == 0 ? oa : w == 1 ? ob : oc;
       for (int i = 0; i < 3; ++i) launch_attention_ex((const bf16_t*)q, (const bf16_t*)k, vt, out, s.B, s.H, s.L, s.L, Lpad, scale, 96, nullptr, 1);
       hipDeviceSynchronize();
       hipEventRecord(e0, nullptr);
@@ -65,9 +67,12 @@ static void fp8_section(int iters) {
       hipEventElapsedTime(&ms, e0, e1);
       us[w] = ms / iters * 1e3;
     }
-    std::vector<uint16_t> ha(n), hb(n);
+    std::vector<uint16_t> ha(n), hb(n), hc(n);
     hipMemcpy(ha.data(), oa, n * 2, hipMemcpyDeviceToHost);
     hipMemcpy(hb.data(), ob, n * 2, hipMemcpyDeviceToHost);
+    hipMemcpy(hc.data(), oc, n * 2, hipMemcpyDeviceToHost);
+    size_t mis_l = 0, nan_l = 0;
+    for (size_t i = 0; i < n; ++i) mis_l += hb[i] != hc[i], nan_l += ((hc[i] & 0x7f80) == 0x7f80 && (hc[i] & 0x7f));
     auto tof = [](uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return (double)f; };
     double num = 0, den = 0, mx = 0;
     size_t nan = 0;
@@ -76,11 +81,12 @@ static void fp8_section(int iters) {
       if (!(a == a)) ++nan;
       num += (a - b) * (a - b), den += b * b, mx = std::max(mx, std::fabs(a - b));
     }
-    printf("fp8 QK^T  B=%d H=%d L=%d   8-wave %6.1f us   one-wave (w16 QK8) %6.1f us   rel-L2 %.3e  max |diff| %.4g  NaN %zu%s\n", s.B, s.H, s.L, us[0], us[1],
-           std::sqrt(num / std::max(den, 1e-30)), mx, nan, hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
-    hipFree(q); hipFree(k); hipFree(vt); hipFree(oa); hipFree(ob);
+    printf("fp8 QK^T  B=%d H=%d L=%d   8-wave %6.1f us   one-wave (w16 QK8) %6.1f us   rel-L2 %.3e  max |diff| %.4g  NaN %zu   lock-step (w16l QK8) %6.1f us  differing from w16 QK8: %zu, NaN %zu%s\n", s.B, s.H, s.L, us[0], us[1],
+           std::sqrt(num / std::max(den, 1e-30)), mx, nan, us[2], mis_l, nan_l, hipGetLastError() == hipSuccess ? "" : "  (HIP ERROR)");
+    hipFree(q); hipFree(k); hipFree(vt); hipFree(oa); hipFree(ob); hipFree(oc);
   }
   set_attention_w16(true);
+  set_attention_w16l(true);
 }
 
 int main(int argc, char** argv) {

@@ -49,10 +49,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TILE = 16384
 VT_RING = 4 * TILE
 NBUF = 8
+NBUFK = 4         # fp8 mode: the 32-byte K fragments have their own pool of four 8-register buffers, a[160:191]
+MODE = os.environ.get("AW16L_MODE", "bf16")  # "bf16" | "fp8qk": Q and K as OCP e4m3 (the model's fp8 mode), P and V^T stay bf16 -> attention_w16lf8_loop.inc
+FP8 = MODE == "fp8qk"
+TILE_K = 8192 if FP8 else TILE  # bytes of a K tile (64 keys x 128 d) in HBM and in LDS
 LOOKAHEAD = int(os.environ.get("AW16L_LOOKAHEAD", "16"))  # a fragment is read this many MFMA slots ahead of its first use (4 fragments in flight)
 X = os.environ.get("AW16L_X", "")  # timing experiments only (wrong results): novalu | noexp | nodma | nobarrier | nomfma | nowait
 TAG = os.environ.get("AW16L_TAG", X)  # a tag (or an experiment) writes build/attention_w16l_loop_<tag>.inc instead of the committed file
 EY = int(os.environ.get("AW16L_EY", "8"))  # how many of a tile's 16 exponential units (4 scores each, key-block major) run in the Y phase; the rest in X
+F8_EX = int(os.environ.get("AW16L_F8_EX", "4"))  # fp8 mode: how many of the 16 exponential units (from the last) run in the X phase instead of Y
 TREE_END = int(os.environ.get("AW16L_TREE_END", "19"))  # last gap of the max tree in a Y phase (the decision sits two gaps behind it)
 
 PMAX, TA, TB, T0, T1, AL, DL = (f"v{n}" for n in range(208, 215))
@@ -104,9 +109,22 @@ def Pr(kk, q, d):
     return f"v{128 + (4 * kk + q) * 4 + d}"
 
 
-def FR(n):
+def FR(n, pool="V", half=None):
+    """fragment buffer n of a pool: "V" = a[208:239] (8 x 4 registers: every bf16 fragment); "K8" = a[160:191] (4 x 8 registers: the fp8
+    mode's 32-byte K fragments; half = 0 / 1 selects the 16 bytes one ds_read_b128 fills)"""
+    if pool == "K8":
+        lo = 160 + 8 * (n % NBUFK)
+        return f"a[{lo}:{lo + 7}]" if half is None else f"a[{lo + 4 * half}:{lo + 4 * half + 3}]"
     lo = 208 + 4 * (n % NBUF)
     return f"a[{lo}:{lo + 3}]"
+
+
+def QF8(q):
+    lo = 128 + 8 * q
+    return f"a[{lo}:{lo + 7}]"
+
+
+SCA, SCB = "v162", "v163"  # fp8 mode (KAD[2], KAD[3] are unused there): E8M0 block scales of the score product, 2^-n on the K side, 1 on the Q side
 
 
 def KAD(s):
@@ -145,17 +163,25 @@ class Phase:
     def __init__(self, name, kind, buf=None):
         self.name, self.kind, self.buf = name, kind, buf
         self.mfma, self.frags = [], []
-        if kind == "X":
+        if kind == "X" and FP8:
+            # one v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 score tile: the whole head dimension in one instruction, whose E8M0 block
+            # scales carry the score factor 2^-n; fragment a = the key block's 32 bytes per lane (two reads: KAD[0], KAD[1] = KAD[0] ^ 16)
+            for a in range(4):
+                imm = (a >> 1) * 4096 + (a & 1) * 1024
+                self.frags.append([(KAD(0), imm), (KAD(1), imm)])
+                for q in range(4):
+                    self.mfma.append((f"v_mfma_scale_f32_16x16x128_f8f6f4 {S(buf, a, q)}, {{fr}}, {QF8(q)}, {NM(q)}, {SCA}, {SCB}", a))
+        elif kind == "X":
             for s in range(4):          # d-step (32 of the 128 head dimensions)
                 for a in range(4):      # key block (16 keys)
-                    self.frags.append((KAD(s), (a >> 1) * 8192 + (a & 1) * 2048))
+                    self.frags.append([(KAD(s), (a >> 1) * 8192 + (a & 1) * 2048)])
                     for q in range(4):
                         acc = NM(q) if s == 0 else S(buf, a, q)  # first d-step: start from -m of the lane's query (the fold)
                         self.mfma.append((f"v_mfma_f32_16x16x32_bf16 {S(buf, a, q)}, {{fr}}, {QF(q, s)}, {acc}", 4 * s + a))
         else:
             for kk in range(2):         # k-step (32 keys)
                 for dt in range(8):     # d block (16 head dimensions)
-                    self.frags.append((VAD(kk), dt * 2048))
+                    self.frags.append([(VAD(kk), dt * 2048)])
                     for q in range(4):
                         self.mfma.append((f"v_mfma_f32_16x16x32_bf16 {O(q, dt)}, {{fr}}, {P(kk, q)}, {O(q, dt)}", 8 * kk + dt))
                 for q in range(4):      # V^T extended by a row of ones: the row sums of the bf16-rounded P
@@ -164,7 +190,8 @@ class Phase:
         nf = len(self.frags)
         self.fu = [min(i for i, (_, ff) in enumerate(self.mfma) if ff == f) for f in range(nf)]
         self.lu = [max(i for i, (_, ff) in enumerate(self.mfma) if ff == f) for f in range(nf)]
-        assert self.fu == sorted(self.fu) and nf % NBUF == 0
+        self.pool = "K8" if (kind == "X" and FP8) else "V"
+        assert self.fu == sorted(self.fu) and nf % (NBUFK if self.pool == "K8" else NBUF) == 0
         # set by build(): valu (list of instruction lists per gap), dma ("K" | "V" | None), barrier, advance ((regs, xor mask) applied behind the last own read)
         self.valu, self.dma, self.barrier, self.advance = [[] for _ in range(self.n)], None, False, None
 
@@ -347,6 +374,41 @@ def plan_x(ph, buf, uid):
     spread(plan, stream, 5, n - 3)
 
 
+def plan_y_f8(ph, buf, uid):
+    """fp8 mode: an X phase is 16 double-length MFMAs — a quarter of the gaps of the bf16 one — so the softmax lives in the Y phases.
+    Y(t): [packs of key blocks 2, 3 of tile t (the OTHER buffer) -> P[kk = 1], which this phase reads from slot 36 on], then tile t + 1
+    (buffer `buf`): mask, max tree, decision (+ rare rescale of S / M / NM), ALL 64 exponentials.  X(t+2) keeps the packs of key blocks 0, 1."""
+    n, plan = ph.n, ph.valu
+    spread(plan, [i for (a, q) in UNITS[8:] for i in packs(buf ^ 1, a, q)], 0, 28)
+    skipm = f".Law16l_nomask_{uid}_%="
+    plan[4] += [f"s_cmp_eq_u32 {S_FLAG}, 0", f"s_cbranch_scc1 {skipm}"] + mask_block(buf) + [f"{skipm}:"]
+    spread(plan, max_tree(buf), 5, TREE_END)
+    skip = f".Law16l_skip_{uid}_%="
+    plan[TREE_END + 2] += [f"v_cmp_lt_f32 vcc, %[thr], {PMAX}", f"s_cbranch_vccz {skip}"] + rescale_s(buf, True) + [f"{skip}:"]
+    spread(plan, [i for (a, q) in UNITS[:16 - F8_EX] for i in exps(buf, a, q)], TREE_END + 3, n - 1)
+
+
+def plan_x_f8(ph, buf, uid):
+    """fp8 mode, X(t+2)'s 16 gaps: the pending O^T / l rescale (rare; gap 2 is 64+ clocks behind Y(t)'s last MFMA), then the packs of key
+    blocks 0, 1 of tile t + 1 (buffer `buf`, exponentiated in Y(t)) -> P[kk = 0], complete three gaps in front of Y(t+1)."""
+    n, plan = ph.n, ph.valu
+    skip = f".Law16l_noresc_{uid}_%="
+    plan[2] += [f"s_cmp_eq_u32 {S_RESC}, 0", f"s_cbranch_scc1 {skip}"] + rescale_o() + [f"{skip}:"]
+    late_exps = [i for (a, q) in UNITS[16 - F8_EX:] for i in exps(buf, a, q)]  # (their packs are Y(t+1)'s first job: far enough behind)
+    pk = [i for (a, q) in UNITS[:8] for i in packs(buf, a, q)]
+    stream = []
+    for k in range(max(len(late_exps), len(pk))):
+        stream += late_exps[k:k + 1] + pk[k:k + 1]
+    spread(plan, stream, 3, n - 3)
+
+
+def plan_p1_f8(ph, uid):
+    """fp8 mode, P1 = X(1) | all exponentials of tile 0 (buffer 0) and the packs of its key blocks 0, 1; the packs of key blocks 2, 3
+    are Y(0)'s first job, as in the steady state (a one-time crowd: 80 instructions in 14 gaps)."""
+    n, plan = ph.n, ph.valu
+    spread(plan, [i for (a, q) in UNITS for i in exps(0, a, q)] + [i for (a, q) in UNITS[:8] for i in packs(0, a, q)], 1, n - 3)
+
+
 def plan_p1(ph, uid):
     """P1 = X(1) | all exponentials and packs of tile 0 (buffer 0).  Tile 0's maxima (the rescale block, unconditional on a first tile:
     M = -1e30, NM = 0) were taken BETWEEN pre and P1 — X(1) folds -m into its scores, so NM must be final before its first MFMA;
@@ -364,16 +426,21 @@ def emit_phase(ph, nxt, own_prefetch=False, drain=False):
     n, nf = ph.n, len(ph.frags)
     reads = [[] for _ in range(n)]
     early = []
-    for f, (reg, imm) in enumerate(ph.frags):
+    def dest(p_, f, k):
+        return FR(f, p_.pool, k if p_.pool == "K8" else None)
+
+    for f, fr in enumerate(ph.frags):
         i = ph.fu[f] - LOOKAHEAD
-        (reads[i] if i >= 0 else early).append(((0, f), FR(f), reg, imm))
+        for k, (reg, imm) in enumerate(fr):
+            (reads[i] if i >= 0 else early).append(((0, f), dest(ph, f, k), reg, imm))
     own_last_read = max([g for g in range(n) if reads[g]], default=-1)
     if nxt is not None:
-        for f, (reg, imm) in enumerate(nxt.frags):
+        for f, fr in enumerate(nxt.frags):
             i = n + nxt.fu[f] - LOOKAHEAD
             if i < n:
                 assert i > own_last_read, (ph.name, "next phase's reads must follow the own ones")
-                reads[i].append(((1, f), FR(f), reg, imm))
+                for k, (reg, imm) in enumerate(fr):
+                    reads[i].append(((1, f), dest(nxt, f, k), reg, imm))
     if own_prefetch:
         for (_, b_, reg, imm) in early:
             o.append(f"ds_read_b128 {b_}, {reg} offset:{imm}")
@@ -399,7 +466,7 @@ def emit_phase(ph, nxt, own_prefetch=False, drain=False):
         text, f = ph.mfma[i]
         pre, post = [], []
         dma = None
-        if ph.dma == "K" and i % (n // 4) == n // 8 - 1 and X != "nodma":       # 4 pieces, one per quarter
+        if ph.dma == "K" and i % (n // 4) == n // 8 - 1 and i // (n // 4) < (2 if FP8 else 4) and X != "nodma":  # 4 pieces (fp8: 2), one per quarter
             piece = i // (n // 4)
             pre.append(f"s_add_i32 m0, {S_M0K}, {piece * 1024}")
             pre.append(f"v_cndmask_b32 {DMAT}, v{166 + piece}, v{174 + piece}, {S_MASKK}")
@@ -414,7 +481,7 @@ def emit_phase(ph, nxt, own_prefetch=False, drain=False):
                 younger = issued_before_slot[i] - last[(0, max(need))] - 1
                 assert 0 <= younger <= 15, (ph.name, i, younger)
                 pre.append(f"s_waitcnt lgkmcnt({younger})")
-        mf = text.format(fr=FR(f)) if f is not None else text
+        mf = text.format(fr=FR(f, ph.pool)) if f is not None else text
         rd = [f"ds_read_b128 {b_}, {reg} offset:{imm}" for (_, b_, reg, imm) in reads[i]]
         post += adv_at[i]
         post += ph.valu[i]
@@ -427,16 +494,31 @@ def emit_phase(ph, nxt, own_prefetch=False, drain=False):
         if X == "noexp":
             post = [p_.replace("v_exp_f32", "v_mov_b32") for p_ in post]
         o.append(f"; slot {i}")
+        if ph.barrier and FP8 and i == 0 and X != "nobarrier":
+            # fp8 mode: an X phase is 16 slots long and the NEXT Y phase's first V^T fragments are read from its slot 0 on (look-ahead 16) —
+            # the barrier that publishes V^T(t+1) must stand in front of them (in the bf16 stream those reads start at slot 48, behind
+            # the mid-phase barrier).  Same accounting: the newest V^T(t+2) [4] + K(t+4) [2] pieces may fly.
+            o += ["s_waitcnt vmcnt(6)", "s_barrier"]
         o += pre + [mf] + rd
         if dma:
             o.append(dma)
         o += post
-        if ph.barrier and i == n // 2 and X != "nobarrier":
-            # everything but this wave's newest pieces — V^T(t+2) [4] and K(t+4) [4] — has landed: K(t+3), V^T(t+1)
+        if ph.barrier and not FP8 and i == n // 2 and X != "nobarrier":
+            # everything but this wave's newest pieces — V^T(t+2) [4] and K(t+4) [4; 2 in fp8 mode] — has landed: K(t+3), V^T(t+1)
             o += ["s_waitcnt vmcnt(8)", "s_barrier"]
     if drain:
         o += ["s_waitcnt lgkmcnt(0)", "s_nop 15", "s_nop 15", "s_nop 15"]
     return o
+
+
+def early_reads(ph):
+    """the reads of ph's fragments that precede its slot 0 (what the previous phase's tail, or an own prefetch, issues), in order"""
+    out = []
+    for f, fr in enumerate(ph.frags):
+        if ph.fu[f] - LOOKAHEAD < 0:
+            for k, (reg, imm) in enumerate(fr):
+                out.append(f"ds_read_b128 {FR(f, ph.pool, k if ph.pool == 'K8' else None)}, {reg} offset:{imm}")
+    return out
 
 
 def check_rule3(seq):
@@ -449,48 +531,55 @@ def check_rule3(seq):
             rd = base + ph.fu[f] - LOOKAHEAD
             assert prev_rd is None or rd >= prev_rd, ("stream order", ph.name, f)
             prev_rd = rd
-            pb = f % NBUF
+            pb = (ph.pool, f % (NBUFK if ph.pool == "K8" else NBUF))
             assert last_user.get(pb, -10**9) < rd, ("rule 3", ph.name, f, pb, last_user.get(pb), rd)
             last_user[pb] = base + ph.lu[f]
         base += ph.n
 
 
 def build():
-    K_REGS, V_REGS = [KAD(s) for s in range(4)], [VAD(k) for k in range(2)]
-    EVEN, ODD = TILE, 3 * TILE  # ring slot s -> s + 1: xor 1 << 14 out of an even slot, 3 << 14 out of an odd one
+    K_REGS, V_REGS = [KAD(s) for s in range(2 if FP8 else 4)], [VAD(k) for k in range(2)]
+    EVEN, ODD = TILE, 3 * TILE  # ring slot s -> s + 1: xor one slot size out of an even slot, three out of an odd one
+    KEVEN, KODD = TILE_K, 3 * TILE_K
+    py, px, pp1 = (plan_y_f8, plan_x_f8, plan_p1_f8) if FP8 else (plan_y, plan_x, plan_p1)
     pre = Phase("pre: X(0) -> S0", "X", 0)
-    pre.advance = (K_REGS, EVEN)                    # K leaves slot 0
+    pre.advance = (K_REGS, KEVEN)                    # K leaves slot 0
     p1 = Phase("P1: X(1) -> S1 | softmax(0)", "X", 1)
-    p1.advance, p1.barrier = (K_REGS, ODD), True    # K leaves slot 1
-    plan_p1(p1, "p1")
+    p1.advance, p1.barrier = (K_REGS, KODD), True    # K leaves slot 1
+    pp1(p1, "p1")
     ye = Phase("Y(t), t even | softmax 1st half of tile t+1 (S1)", "Y")
     ye.advance, ye.dma = (V_REGS, EVEN), "K"
-    plan_y(ye, 1, "ye")
+    py(ye, 1, "ye")
     xe = Phase("X(t+2) -> S0, t even | softmax 2nd half of tile t+1 (S1)", "X", 0)
-    xe.advance, xe.dma, xe.barrier = (K_REGS, EVEN), "V", True   # t + 2 even
-    plan_x(xe, 1, "xe")
+    xe.advance, xe.dma, xe.barrier = (K_REGS, KEVEN), "V", True   # t + 2 even
+    px(xe, 1, "xe")
     yo = Phase("Y(t), t odd | softmax 1st half of tile t+1 (S0)", "Y")
     yo.advance, yo.dma = (V_REGS, ODD), "K"
-    plan_y(yo, 0, "yo")
+    py(yo, 0, "yo")
     xo = Phase("X(t+2) -> S1, t odd | softmax 2nd half of tile t+1 (S0)", "X", 1)
-    xo.advance, xo.dma, xo.barrier = (K_REGS, ODD), "V", True
-    plan_x(xo, 0, "xo")
+    xo.advance, xo.dma, xo.barrier = (K_REGS, KODD), "V", True
+    px(xo, 0, "xo")
     return pre, p1, ye, xe, yo, xo
 
 
 def stream():
     pre, p1, ye, xe, yo, xo = build()
-    check_rule3([pre, p1, ye, xe, yo, xo, ye, xe, yo, xo, ye])
+    if FP8:  # pre and P1 are 16 MFMAs each, as long as the look-ahead and back to back on the same four K buffers: each fetches its own
+        check_rule3([pre])  # fragments and ends drained, and Y(0)'s first fragments are fetched in front of the loop label
+        check_rule3([p1])
+        check_rule3([ye, xe, yo, xo, ye, xe, yo, xo, ye])
+    else:
+        check_rule3([pre, p1, ye, xe, yo, xo, ye, xe, yo, xo, ye])
 
     def dma_setup():
         """scalar state of one tile: K(min(t + 4, n - 1)) and V^T(min(t + 3, n - 1)): HBM base and ring slot of either"""
         return [f"s_add_i32 {S_TILE}, {S_T}, 4",
                 f"s_min_i32 {S_TILE}, {S_TILE}, %[ntm1]",
-                f"s_lshl_b32 {S_TMP}, {S_TILE}, 14",
+                f"s_lshl_b32 {S_TMP}, {S_TILE}, {13 if FP8 else 14}",   # log2 of a K tile's bytes, in HBM and in LDS
                 "s_add_u32 s80, %[kb_lo], " + S_TMP,
                 "s_addc_u32 s81, %[kb_hi], 0",
                 f"s_and_b32 {S_TMP}, {S_TILE}, 3",
-                f"s_lshl_b32 {S_M0K}, {S_TMP}, 14",
+                f"s_lshl_b32 {S_M0K}, {S_TMP}, {13 if FP8 else 14}",
                 f"s_add_i32 {S_M0K}, {S_M0K}, %[woffk]",
                 f"s_cmp_eq_u32 {S_TILE}, %[ntm1]",
                 f"s_cselect_b64 {S_MASKK}, -1, 0",
@@ -512,11 +601,14 @@ def stream():
                 f"s_cselect_b32 {S_FLAG}, {S_FLAG}, 0"]
 
     o = [f"s_mov_b32 {S_RAG}, %[rag]", f"s_mov_b32 {S_FLAG}, 0", f"s_mov_b32 {S_RESC}, 0", f"s_mov_b32 {S_T}, 0"]
-    o += emit_phase(pre, p1, own_prefetch=True)
+    o += emit_phase(pre, None if FP8 else p1, own_prefetch=True, drain=FP8)
     # the one un-hidden softmax piece of a workgroup: tile 0's maxima.  X(0)'s last MFMAs must have written S0 (an MFMA result needs
     # ~40 clocks); tile 0 is never the ragged last tile (n >= 2); O^T = l = 0: no rescale_o, no flag
     o += ["s_nop 15", "s_nop 15", "s_nop 15", "s_nop 15"] + rescale_s(0, False)
-    o += emit_phase(p1, ye)
+    if FP8:
+        o += emit_phase(p1, None, own_prefetch=True, drain=True) + early_reads(ye)
+    else:
+        o += emit_phase(p1, ye)
     o += [".Law16l_loop_%=:"]
     for y, x in ((ye, xe), (yo, xo)):
         o += dma_setup() + rag_flag()
@@ -534,7 +626,7 @@ def stream():
 
 def main():
     lines = stream()
-    stem = "attention_w16l_loop"
+    stem = "attention_w16lf8_loop" if FP8 else "attention_w16l_loop"
     path = os.path.join(ROOT, "diffusion-rs_amd", "csrc", stem + ".inc")
     if TAG:
         os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
@@ -542,7 +634,7 @@ def main():
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_attention_w16l.py — do not edit.  The whole KV stream of attention_w16l_kernel as one asm\n")
         f.write("// statement (pre, P1, loop { Y(t); X(t+2) } unrolled over two tiles); register map and schedule: see the generator.\n")
-        f.write("#define FMI_AW16L_LOOP_ASM \\\n")
+        f.write(f"#define FMI_AW16L{'F8' if FP8 else ''}_LOOP_ASM \\\n")
         body = ['  "' + ln + '\\n\\t"' for ln in lines if not ln.startswith(";")]
         f.write(" \\\n".join(body))
         f.write("\n")
