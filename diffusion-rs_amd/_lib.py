@@ -121,6 +121,7 @@ def load():
     lib.fmi_comm_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     lib.fmi_comm_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     lib.fmi_flux_set_attention_rescale_threshold.argtypes = [C.c_void_p, C.c_int]
+    lib.fmi_flux_set_attention_kernel.argtypes = [C.c_void_p, C.c_int]
     lib.fmi_flux_forward.argtypes = [C.c_void_p, C.POINTER(FluxInputs), C.c_void_p, C.c_void_p]
     for enc in ("t5", "clip"):
         getattr(lib, f"fmi_{enc}_set_tensor").argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
@@ -196,7 +197,7 @@ def check(rc):
 # every symbol include/flux_mi355x.h declares (tests/test_host_logic.py::test_library_exports_every_header_symbol checks they are all exported)
 EXPORTED = [
     "fmi_last_error", "fmi_abi_version", "fmi_init", "fmi_device_info", "fmi_build_id", "fmi_flux_default_config", "fmi_flux_create", "fmi_flux_destroy",
-    "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_set_linear_int8", "fmi_flux_set_quant_dense_cache", "fmi_flux_set_sequence_parallel", "fmi_flux_set_split_k", "fmi_set_bnb4_onewave_min_rows", "fmi_flux_set_attention_rescale_threshold", "fmi_flux_state_buffer_count", "fmi_flux_state_export", "fmi_flux_state_adopt", "fmi_flux_state_buffer", "fmi_flux_set_modulation_gemm", "fmi_flux_quantize_fp8", "fmi_flux_set_fp8_attention", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
+    "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_set_linear_int8", "fmi_flux_set_quant_dense_cache", "fmi_flux_set_sequence_parallel", "fmi_flux_set_split_k", "fmi_set_bnb4_onewave_min_rows", "fmi_flux_set_attention_rescale_threshold", "fmi_flux_set_attention_kernel", "fmi_flux_state_buffer_count", "fmi_flux_state_export", "fmi_flux_state_adopt", "fmi_flux_state_buffer", "fmi_flux_set_modulation_gemm", "fmi_flux_quantize_fp8", "fmi_flux_set_fp8_attention", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
     "fmi_flux_forward", "fmi_flux_denoise", "fmi_flux_set_profiling", "fmi_flux_set_fused_qkv_relayout", "fmi_flux_phase_count", "fmi_flux_phase_name", "fmi_flux_phase_ms",
     "fmi_vae_default_config", "fmi_vae_create", "fmi_vae_destroy", "fmi_vae_set_tensor", "fmi_vae_missing_count", "fmi_vae_missing_name",
     "fmi_vae_scale_factor", "fmi_vae_shift_factor", "fmi_vae_decode", "fmi_vae_encode", "fmi_vae_mid_attention",

@@ -587,7 +587,12 @@ static std::atomic<unsigned long long> g_fp8_fallbacks{0};  // fp8-QK^T launches
 unsigned long long attention_fp8_fallbacks() { return g_fp8_fallbacks.load(std::memory_order_relaxed); }
 
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
-                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8, float* lse, int k_hstride, int score_exp2) {  // (k_hstride: see the lse branch)
+                        int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8, float* lse, int k_hstride, int score_exp2,
+                        int kind) {  // (k_hstride: see the lse branch)
+  // which kernel: the caller's choice (a model handle's fmi_flux_set_attention_kernel, kind 0..5) or, kind < 0, the process-wide switches
+  const bool g_att_w16l = kind >= 0 ? kind == 5 : (bool)fmi::g_att_w16l, g_att_w32 = kind >= 0 ? kind == 4 : (bool)fmi::g_att_w32,
+             g_att_w16 = kind >= 0 ? kind >= 3 : (bool)fmi::g_att_w16, g_att_w4 = kind >= 0 ? kind >= 2 : (bool)fmi::g_att_w4,
+             g_att_pingpong = kind >= 0 ? kind >= 1 : (bool)fmi::g_att_pingpong;
   if (Lq <= 0 || Lk <= 0) return fail(FMI_ERR_INVALID, "attention: empty sequence");
   if (Lkpad % ATT_KV != 0 || Lkpad < Lk) return fail(FMI_ERR_INVALID, "attention: Lkpad must be a multiple of 64 and >= Lk");
   dim3 grid(cdiv(Lq, ATT_QBLK) * B * H);

@@ -269,7 +269,8 @@ struct AttnOut {
 constexpr int ATT_NO_EXP2 = 1 << 30;
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
                         int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8 = 0, float* lse = nullptr, int nsplit = 0,
-                        int score_exp2 = ATT_NO_EXP2);
+                        int score_exp2 = ATT_NO_EXP2, int kind = -1);
+// kind: 0..5 = this kernel (fmi_set_attention_kernel's numbering: a model handle's own choice, fmi_flux_set_attention_kernel), -1 = the process-wide switches
 // score_exp2 (fp8 QK^T only): the caller KNOWS that scale * log2(e) == 2^score_exp2 exactly and says so as an integer (the model's fp8
 // mode constructs its q scale that way) -> the one-wave stream, which carries the factor in the MFMA's E8M0 block scale.  ATT_NO_EXP2 =
 // unknown: the launcher recognises an exact power of two itself, anything else runs on the 8-wave kernel and is COUNTED

@@ -124,6 +124,7 @@ struct fmi_flux {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float phase_ms[PH_COUNT] = {0};
   int attn_thr = 96;
+  int attn_kind = -1;  // fmi_flux_set_attention_kernel: 0..5 = this handle's attention kernel, -1 = follow the process-wide switch
   // 4-bit weights, large-M regime: per-layer streaming dequant into a reusable bf16 scratch
   // all denoise steps' modulation vectors (n_steps*B, n_mod) and vec (n_steps*B, D), see fmi_flux_denoise
   float *mod_steps = nullptr, *vec_steps = nullptr;
@@ -689,10 +690,10 @@ int attention_sp(fmi_flux* m, const AttnOut& out, int Tl, int Sl, float scale, h
     const size_t part = (size_t)L * Hr * 128;
     AttnOut parts = o;
     parts.p1 = m->sp_O + part;  // slices 1 .. S of the buffer; slice 0 receives the merged result
-    FMI_TRY(launch_attention_ex(m->sp_Qf, m->sp_Kf, m->sp_Vtf, parts, 1, Hr, L, L, Lp, scale, m->attn_thr, s, 0, m->sp_lse, S));
+    FMI_TRY(launch_attention_ex(m->sp_Qf, m->sp_Kf, m->sp_Vtf, parts, 1, Hr, L, L, Lp, scale, m->attn_thr, s, 0, m->sp_lse, S, ATT_NO_EXP2, m->attn_kind));
     FMI_TRY(launch_sp_merge_splits(m->sp_O + part, m->sp_lse, S, m->sp_O, Hr, L, s));
   } else {
-    FMI_TRY(launch_attention_ex(m->sp_Qf, m->sp_Kf, m->sp_Vtf, o, 1, Hr, L, L, Lp, scale, m->attn_thr, s, 0));
+    FMI_TRY(launch_attention_ex(m->sp_Qf, m->sp_Kf, m->sp_Vtf, o, 1, Hr, L, L, Lp, scale, m->attn_thr, s, 0, nullptr, 0, ATT_NO_EXP2, m->attn_kind));
   }
   FMI_TRY(launch_sp_pack_o(m->sp_O, m->sp_send, H, Tl, Sl, N, s));
   if (m->sp_a2a(m->sp_user, m->sp_send, m->sp_recv, sp_o_bytes_per_peer(Hr, Ll), s) != 0)
@@ -876,7 +877,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       o.p1 = w.attn_img, o.ld1 = D, o.bstride1 = (int64_t)S * D;
       const float sc = qk8 ? att_scale / (m->q8_dbl[i] * m->k8_dbl[i]) : att_scale;
       if (sp) FMI_TRY(attention_sp(m, o, T, S, sc, s));
-      else FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0, nullptr, 0, qk8 ? -m->n8_dbl[i] : ATT_NO_EXP2));
+      else FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0, nullptr, 0, qk8 ? -m->n8_dbl[i] : ATT_NO_EXP2, m->attn_kind));
     }
     if (m->two_streams && !fp8 && !sp && !m->profiling && !bw.proj[0].q_type && !bw.proj[1].q_type && !bw.mlp1[0].q_type && !bw.mlp1[1].q_type &&
         !bw.mlp2[0].q_type && !bw.mlp2[1].q_type && !m->split_k) {
@@ -996,7 +997,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       o.p1 = w.big + 2 * D, o.ld1 = ldbig, o.bstride1 = (int64_t)L * ldbig;
       const float sc = qk8 ? att_scale / (m->q8_sgl[i] * m->k8_sgl[i]) : att_scale;
       if (sp) FMI_TRY(attention_sp(m, o, T, S, sc, s));
-      else FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0, nullptr, 0, qk8 ? -m->n8_sgl[i] : ATT_NO_EXP2));
+      else FMI_TRY(launch_attention_ex(w.Qh, w.Kh, w.Vt, o, B, H, L, L, w.Lpad, sc, m->attn_thr, s, qk8 ? 1 : 0, nullptr, 0, qk8 ? -m->n8_sgl[i] : ATT_NO_EXP2, m->attn_kind));
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
@@ -1418,6 +1419,13 @@ extern "C" int fmi_flux_phase_ms(fmi_flux* m, float* ms_out) {
 extern "C" int fmi_flux_set_fused_qkv_relayout(fmi_flux* m, int enable) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
   m->fuse_qkv_relayout = enable != 0;
+  return FMI_OK;
+}
+// This handle's attention kernel (fmi_set_attention_kernel's numbering), -1 = follow the process-wide switch (the default)
+extern "C" int fmi_flux_set_attention_kernel(fmi_flux* m, int kind) {
+  if (!m) return fail(FMI_ERR_INVALID, "null handle");
+  if (kind < -1 || kind > 5) return fail(FMI_ERR_INVALID, "flux_set_attention_kernel: kind must be -1 .. 5");
+  m->attn_kind = kind;
   return FMI_OK;
 }
 // fmi_flux_denoise's modulation precompute: 1 (default) one MFMA GEMM over all steps (when they are more than 4 rows), 0 f32 GEMV passes of 4 rows,

@@ -184,7 +184,7 @@ int fmi_comm_stats(const fmi_comm*, unsigned long long* calls, unsigned long lon
 int fmi_comm_all_to_all(void* comm, const void* send, void* recv, size_t bytes_per_peer, void* stream);
 int fmi_comm_broadcast(fmi_comm*, void* buf, size_t bytes, int root, void* stream);
 int fmi_comm_gather(fmi_comm*, const void* send, void* recv, size_t bytes, int root, void* stream);
-/* PROCESS-WIDE test / ablation hooks — fmi_set_bnb4_onewave_min_rows, fmi_set_attention_kernel (below) and the environment
+/* PROCESS-WIDE test / ablation hooks — fmi_set_bnb4_onewave_min_rows, fmi_set_attention_kernel (below; a model handle can override it for itself: fmi_flux_set_attention_kernel) and the environment
  * variables FMI_GEMM_W4 / FMI_ATT_W4 (read once at load) and FMI_GEMM_BAND=<n> (read at the first GEMM launch: pins the band height of the
  * GEMM tile order, a bijection of the tiles whatever its value) — are shared by every handle and thread of the process: they pick between
  * kernels that produce identical bits (the attention kernels: identical within a family, equal to rounding across, see
@@ -196,6 +196,10 @@ int fmi_set_bnb4_onewave_min_rows(int rows);
  * any other value = the default (rescale only when the running maximum grew by more than 6.0 in log2 units; the kernels are
  * instantiated for these two settings only). */
 int fmi_flux_set_attention_rescale_threshold(fmi_flux*, int thr_x16);
+/* PER HANDLE: the attention kernel this model uses, in fmi_set_attention_kernel's numbering (0 .. 5; see there), or -1 (default) = follow
+ * the process-wide switch.  Two handles of one process can run different kernels; the op-level fmi_sdpa_* entry points have no handle and
+ * keep following the process-wide switch. */
+int fmi_flux_set_attention_kernel(fmi_flux*, int kind);
 /* The weights as flat device buffers — the unit of the multi-GPU broadcast (north star: "RCCL broadcast of
  * weights").  Rank 0 loads a checkpoint, fmi_flux_state_export() fills a small host blob saying which
  * arenas exist and how every fused matrix is stored (pass blob_host = NULL to query *len); the other ranks

@@ -190,6 +190,20 @@ def test_lockstep_attention_is_bit_identical_to_w16_when_every_tile_rescales(env
             e = float((outs[(96, 5)] - outs[(96, 3)]).norm() / outs[(96, 3)].norm())
             print(f"S={hw[0] * hw[1]} T={T}: threshold 0: w16l == w16 == w32 bit for bit; default threshold: w16l vs w16 rel-L2 {e:.2e}")
             assert e <= 2e-3
+        # the kernel choice is also available PER HANDLE (fmi_flux_set_attention_kernel; VERDICT r3 hygiene 13): with the process-wide switch on
+        # the default, a handle told to use round 2's kernel gives round 2's bits, and follows the process again after -1
+        L.check(lib.fmi_flux_set_attention_rescale_threshold(m.h, 96))
+        L.check(lib.fmi_set_attention_kernel(2))
+        ref2 = m.forward(*args).clone()
+        L.check(lib.fmi_set_attention_kernel(5))
+        ref5 = m.forward(*args).clone()
+        L.check(lib.fmi_flux_set_attention_kernel(m.h, 2))
+        own2 = m.forward(*args).clone()
+        L.check(lib.fmi_flux_set_attention_kernel(m.h, -1))
+        back5 = m.forward(*args).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(own2, ref2) and torch.equal(back5, ref5) and not torch.equal(ref2, ref5)
+        assert lib.fmi_flux_set_attention_kernel(m.h, 6) < 0
         # the fp8-QK^T streams of the two schedules (the model's fp8 mode: q, k as e4m3 codes from the fused epilogue, score factor in the
         # MFMA's block scale): the same statement.  Token counts multiples of 16 so that the fp8 attention is really taken.
         m.quantize_fp8()
