@@ -532,11 +532,15 @@ def main():
                 for line in open("/proc/meminfo"):
                     if line.startswith("MemAvailable:"):
                         avail = int(line.split()[1]) / 2**20
-                lim = open("/sys/fs/cgroup/memory.max").read().strip()
-                if lim != "max":
-                    avail = min(avail, int(lim) / 2**30)
             except OSError:
                 pass
+            for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):  # cgroup v2, v1
+                try:
+                    lim = open(path).read().strip()
+                    if lim != "max":
+                        avail = min(avail, int(lim) / 2**30)
+                except (OSError, ValueError):
+                    pass
             return avail
 
         Dh = D_HID

@@ -32,12 +32,13 @@ def _host_memory_gib():
                 avail = int(line.split()[1]) / 2**20
     except OSError:
         pass
-    try:
-        lim = open("/sys/fs/cgroup/memory.max").read().strip()
-        if lim != "max":
-            avail = min(avail, int(lim) / 2**30)
-    except OSError:
-        pass
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):  # cgroup v2, v1
+        try:
+            lim = open(path).read().strip()
+            if lim != "max":
+                avail = min(avail, int(lim) / 2**30)
+        except (OSError, ValueError):
+            pass
     return avail
 
 
