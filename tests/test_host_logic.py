@@ -224,3 +224,26 @@ def test_bench_as_rank_hook_is_validated():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + bad, capture_output=True, text=True, timeout=300,
                            env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
         assert r.returncode != 0 and "--as-rank" in r.stderr, r.stderr[-500:]
+
+
+def test_committed_attention_streams_are_what_their_generators_emit(tmp_path):
+    """The six generated instruction streams under csrc/ (`*_loop.inc`: the hand-scheduled KV loops of the attention kernels) are committed
+    files; each must be byte for byte what its generator in tools/ emits — a stream edited by hand, or a generator changed without
+    regenerating, would otherwise ship unnoticed (the generators also assert their own invariants — rule 3, read order, wait counts — while
+    they run).  The generators write relative to their own location, so they run from a scratch copy of tools/."""
+    import shutil
+    import subprocess
+    import sys
+    (tmp_path / "tools").mkdir()
+    (tmp_path / "diffusion-rs_amd" / "csrc").mkdir(parents=True)
+    jobs = [("gen_attention_w4_loop.py", {}, "attention_w4_loop.inc"), ("gen_attention_w16.py", {}, "attention_w16_loop.inc"),
+            ("gen_attention_w16.py", {"AW16_MODE": "fp8qk"}, "attention_w16f8_loop.inc"), ("gen_attention_w32.py", {}, "attention_w32_loop.inc"),
+            ("gen_attention_w16l.py", {}, "attention_w16l_loop.inc"), ("gen_attention_w16l.py", {"AW16L_MODE": "fp8qk"}, "attention_w16lf8_loop.inc")]
+    for gen, env, out in jobs:
+        shutil.copy(os.path.join(ROOT, "tools", gen), tmp_path / "tools" / gen)
+        clean = {k: v for k, v in os.environ.items() if not k.startswith(("AW16", "AW32", "AW4"))}
+        r = subprocess.run([sys.executable, str(tmp_path / "tools" / gen)], env=dict(clean, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (gen, r.stderr[-1000:])
+        made = (tmp_path / "diffusion-rs_amd" / "csrc" / out).read_bytes()
+        have = open(os.path.join(ROOT, "diffusion-rs_amd", "csrc", out), "rb").read()
+        assert made == have, f"{out} differs from what tools/{gen} {env or ''} emits: regenerate it (make) or revert the edit"
