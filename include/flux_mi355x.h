@@ -34,7 +34,9 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
 #pragma GCC visibility push(default)
 
-#define FMI_ABI_VERSION 3
+/* 4 (round 4): + fmi_build_id, fmi_comm_probe, fmi_flux_set_attention_kernel; fmi_flux_set_modulation_gemm accepts 2; fmi_set_attention_kernel accepts 5.
+ * Additions only: a host bound against version 3 keeps working. */
+#define FMI_ABI_VERSION 4
 
 typedef enum fmi_status {
   FMI_OK = 0,

@@ -27,7 +27,7 @@ def test_library_exports_every_header_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert set(L.EXPORTED) == declared
-    assert lib.fmi_abi_version() == 3
+    assert lib.fmi_abi_version() == 4
 
 
 def test_no_cpu_fallback():
