@@ -30,7 +30,9 @@ build/build_id.h: FORCE
 	@echo '#define FMI_BUILD_ID "$(BUILD_ID)"' > $@.tmp
 	@cmp -s $@.tmp $@ || cp $@.tmp $@
 	@rm -f $@.tmp
-build/capi.o: build/build_id.h
+# EVERY object depends on the id: it changes with any byte of any source, so a changed tree is rebuilt as a whole and the id that capi.o
+# carries is the id of all the code that is linked (an object newer than an edited source can no longer ride along under a fresh id)
+$(OBJS): build/build_id.h
 FORCE:
 
 $(LIB): $(OBJS)
