@@ -271,6 +271,34 @@ def test_c2_dev_1024_forward_and_two_step_trajectory_of_the_full_model_match_ora
     assert rel_l2(got2 - img, ref2 - img) <= 2e-2
 
 
+def test_c5_shape_1280x720_bf16_forward_of_the_full_model_matches_oracle(full_models):
+    """BASELINE configs[4]'s SHAPE in bf16 at full size: 1280 x 720 -> latent 90 x 160 -> S = 45 * 80 = 3600 image tokens + T = 512 text tokens = 4112 — the
+    ragged case of every launch: 4112 = 16 x 256 + 16 (a 17th query block of 16 rows), = 64 x 64 + 16 (a last KV tile of 16 keys, masked inside
+    the attention stream), GEMM row tiles of 16 ragged rows.  One `Flux::forward` of FLUX.1-dev (19 + 38 blocks) against the f32 oracle, rel-L2 <= 2e-2
+    (model.rs:790-833).  Round 4: the first full-size check of the lock-step attention's ragged paths inside the model."""
+    if not full_models["wide"]:
+        pytest.skip("the host cannot hold the oracle's 48 GB of f32 weights")
+    torch, d, orc, gm, om = (full_models[k] for k in ("torch", "d", "orc", "gm_dev", "om"))
+    cfg = dict(d.FLUX_DEV)
+    B, T = 1, 512
+    rng = np.random.default_rng(85)
+    lat = rng.standard_normal((B, 16, 90, 160)).astype(np.float32)
+    t5 = bf16_round(rng.standard_normal((B, T, cfg["joint_attention_dim"])).astype(np.float32))
+    clip = rng.standard_normal((B, cfg["pooled_projection_dim"])).astype(np.float32)
+    img, ids = orc.pack_latents(lat)
+    assert img.shape[1] == 3600
+    txt_ids = np.zeros((B, T, 3), np.float32)
+    sched = d.SchedulerConfig()
+    t = np.array([float(sched.get_timesteps(50, sched.calculate_shift(3600))[10])], np.float32)
+    g = np.array([3.5], np.float32)
+    got = host(gm.forward(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(t), dev(clip), dev(g)))
+    t0 = time.time()
+    ref = om.forward(img, ids, t5, txt_ids, t, clip, g)
+    err = rel_l2(got, ref)
+    print(f"C5 shape in bf16 (FLUX.1-dev in full, S=3600 + T=512 = 4112 tokens), one Flux::forward: rel-L2 {err:.3e} (oracle {time.time() - t0:.0f} s)")
+    assert np.isfinite(got).all() and err <= 2e-2
+
+
 def test_batch_of_8_at_full_size_equals_the_samples_run_alone(full_models):
     """`Pipeline.MAX_BATCH` = 8 at the headline shape: FLUX.1-dev in full, 8 samples x (4096 + 512) tokens in ONE denoise call (36 864
     rows per launch, a 1.6 GB fused-projection buffer, 8 x 3 = 24 rows in the modulation precompute) — every row of every kernel is
