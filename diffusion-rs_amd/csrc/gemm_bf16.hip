@@ -677,25 +677,48 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   const int a_row_off = (wm * 128 + (lane & 15)) * 128;
   const int w_row_off = (wn * 32 * NJ + (lane & 15)) * 128;
 
-  // CONV: this lane stages rows chunk*8 + (lane>>3), chunk = wave*4 + i; precompute their pixels
-  int cv_y[4], cv_x[4];
-  int64_t cv_base[4];
+  // CONV: this lane stages rows chunk*8 + (lane>>3), chunk = wave*4 + i; precompute their pixels.
+  // cv_up > 0: nearest-2x upsample folded in; cv_up < 0: the VAE encoder's Downsample (stride 2,
+  // one zero column / row on the right / bottom only): input pixel = 2*out + tap, no centring
+  int cv_y[4], cv_x[4], cv_pix[4];
+  const int cv_sh = MODE == 2 && P.cv_up > 0 ? P.cv_up : 0;        // shift of the (virtually upsampled) input coordinates
+  const int cv_half = MODE == 2 && P.cv_up >= 0 ? P.cv_ks >> 1 : 0;
+  const int cv_ow = P.cv_w << cv_sh, cv_oh = P.cv_h << cv_sh;        // bounds of the (virtually upsampled) input
+  const uint32_t cv_cin2 = (uint32_t)P.cv_cin * 2;                  // bytes per pixel
   if (MODE == 2) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int m = m0 + (wave * 4 + i) * 8 + (lane >> 3);
       m = m > P.M - 1 ? P.M - 1 : m;
-      // cv_up > 0: nearest-2x upsample folded in; cv_up < 0: the VAE encoder's Downsample (stride 2,
-      // one zero column / row on the right / bottom only): input pixel = 2*out + tap, no centring
       const bool down = P.cv_up < 0;
-      const int up = down ? 0 : P.cv_up;
-      const int ow = down ? P.cv_w >> 1 : P.cv_w << up, oh = down ? P.cv_h >> 1 : P.cv_h << up;
+      const int ow = down ? P.cv_w >> 1 : cv_ow, oh = down ? P.cv_h >> 1 : cv_oh;
       const int x = m % ow, y = (m / ow) % oh, b = m / (ow * oh);
       cv_x[i] = down ? 2 * x : x;
       cv_y[i] = down ? 2 * y : y;
-      cv_base[i] = (int64_t)b * P.cv_h * P.cv_w;
+      cv_pix[i] = b * P.cv_h * P.cv_w;  // pixels, not elements: < 2^31 at any batch the pipeline runs
     }
   }
+  // the 16-byte slot of a row this lane stages: (lane & 7) ^ ((row >> 1) & 7), row = (wave * 4 + i) * 8 + (lane >> 3) -> depends on i & 1 only
+  const int cv_slot[2] = {((lane & 7) ^ ((lane >> 4) & 7)) << 4, ((lane & 7) ^ ((4 + (lane >> 4)) & 7)) << 4};
+  // source of piece i of the K tile (tap offset dy, dx; 64-channel slice at c0): one v_mad_u64_u32 per row, the zero line for padding taps
+  auto conv_src = [&](int i, int dy, int dx, int c0) -> const char* {
+    const int yy = cv_y[i] + dy, xx = cv_x[i] + dx;
+    const bool in = (unsigned)yy < (unsigned)cv_oh && (unsigned)xx < (unsigned)cv_ow;
+    const uint32_t pix = (uint32_t)(cv_pix[i] + (yy >> cv_sh) * P.cv_w + (xx >> cv_sh));
+    const char* src = reinterpret_cast<const char*>(P.A) + ((uint64_t)pix * cv_cin2 + (uint32_t)(c0 * 2 + cv_slot[i & 1]));
+    const char* zero = reinterpret_cast<const char*>(P.cv_zero) + cv_slot[i & 1];  // zero padding (conv2d pad = k/2)
+    return in ? src : zero;
+  };
+  // uniform walk over (tap, slice), kept one K tile AHEAD of the tile being multiplied (the DMA pieces of tile kt + 1 are issued among
+  // the MFMAs of tile kt, as in the dense kernel)
+  int cvn_c0 = 0, cvn_dy = -cv_half, cvn_dx = -cv_half;
+  auto conv_advance = [&]() {
+    cvn_c0 += 64;
+    if (cvn_c0 == P.cv_cin) {
+      cvn_c0 = 0;
+      if (++cvn_dx == P.cv_ks - cv_half) cvn_dx = -cv_half, ++cvn_dy;
+    }
+  };
   // per-lane DMA source pointers, hoisted out of the K loop: this lane stages tile rows
   // chunk*8 + (lane>>3) (1-KiB chunk = 8 rows), 16-B slot (lane&7) ^ ((row>>1)&7) of each row
   constexpr int CPWN = BN / 64;
@@ -717,31 +740,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
       w_src[i] = P.W + (int64_t)g * P.ldw + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
     }
   }
-  auto stage_a = [&](int kt, char* dst) {
-    if (MODE == 2) {
-      const int cpt = P.cv_cin >> 6;  // 64-channel slices per tap
-      const int tap = kt / cpt, c0 = (kt - tap * cpt) << 6;
-      const int up = P.cv_up < 0 ? 0 : P.cv_up;
-      const int half = P.cv_up < 0 ? 0 : P.cv_ks >> 1;
-      const int dy = tap / P.cv_ks - half, dx = tap % P.cv_ks - half;
-      const int ow = P.cv_w << up, oh = P.cv_h << up;  // bounds of the (virtually upsampled) input
-      const int cs = lane & 7;
+  auto stage_a = [&](int kt, char* dst) {  // (CONV: tile 0 only — the walk's state is tile 0's)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int chunk = wave * 4 + i;
-        const int row = chunk * 8 + (lane >> 3);
-        const int src_slot = cs ^ ((row >> 1) & 7);
-        const int yy = cv_y[i] + dy, xx = cv_x[i] + dx;
-        const bf16_t* src;
-        if (yy >= 0 && yy < oh && xx >= 0 && xx < ow)
-          src = P.A + (cv_base[i] + (int64_t)(yy >> up) * P.cv_w + (xx >> up)) * P.cv_cin + c0 + src_slot * 8;
-        else
-          src = P.cv_zero + src_slot * 8;  // zero padding (conv2d pad = k/2)
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + chunk * 1024), 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      if (MODE == 2)
+        __builtin_amdgcn_global_load_lds((glb_void*)conv_src(i, cvn_dy, cvn_dx, cvn_c0), (lds_void*)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+      else
         __builtin_amdgcn_global_load_lds((glb_void*)(a_src[i] + kt * BK), (lds_void*)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
     }
   };
@@ -760,7 +764,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
 
   // One 1-KiB piece (8 rows) of tile `kt` into buffer `buf`: pieces 0..3 are A, the rest W.
   auto dma_piece = [&](int kt, int d, int buf) {
-    if (d < 4)
+    if (d < 4 && MODE == 2)
+      __builtin_amdgcn_global_load_lds((glb_void*)conv_src(d, cvn_dy, cvn_dx, cvn_c0), (lds_void*)(bufA(buf) + (wave * 4 + d) * 1024), 16, 0, 0);
+    else if (d < 4)
       __builtin_amdgcn_global_load_lds((glb_void*)(a_src[d] + kt * BK), (lds_void*)(bufA(buf) + (wave * 4 + d) * 1024), 16, 0, 0);
     else
       __builtin_amdgcn_global_load_lds((glb_void*)(w_src[d - 4] + kt * BK), (lds_void*)(bufW(buf) + (wave * CPWN + d - 4) * 1024), 16, 0, 0);
@@ -769,11 +775,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   // first two k-steps of tile kt (an LDS-DMA costs ~60 cycles among MFMAs but 100-185 in a burst,
   // and a burst leaves the matrix pipe of the SIMD idle because both of its waves burst together);
   // the last two k-steps give the pieces time to land before the next barrier.
-  constexpr bool INTERLEAVE = (MODE == 0);
+  constexpr bool INTERLEAVE = (MODE == 0 || MODE == 2);
   auto ktile = [&](int kt, auto more_tag) {
     constexpr bool MORE = decltype(more_tag)::value;
     const int cur = kt & 1;
     dma_barrier();  // tile kt landed for every wave; everyone finished reading buf[cur^1]
+    if (MODE == 2 && MORE) conv_advance();
     if (MORE && !INTERLEAVE) {
       stage_a(kt + 1, bufA(cur ^ 1));
       stage_w(kt + 1, bufW(cur ^ 1));
@@ -1400,7 +1407,14 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   const bool fp8 = probs[0].fp8 != 0;
   int max_n = 0;
   for (int i = 0; i < nprob; ++i) max_n = std::max(max_n, probs[i].N);
-  const int bn = max_n <= 128 ? 128 : 256;
+  int bn = max_n <= 128 ? 128 : 256;
+  if (conv && bn == 256) {
+    // a convolution whose 256 x 256 tiles leave a quarter of the CUs or more without one (the decoder's 512 -> 512 layers on 128 x 128
+    // pixels: 128 tiles) runs on 256 x 128 tiles instead
+    int64_t tiles = 0;
+    for (int i = 0; i < nprob; ++i) tiles += (int64_t)cdiv(probs[i].M, BM) * cdiv(probs[i].N, 256);
+    if (tiles <= 192) bn = 128;
+  }
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem& p = probs[i];
     if (p.M <= 0 || p.N <= 0) return fail(FMI_ERR_INVALID, "launch_gemm: empty problem");
