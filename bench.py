@@ -173,8 +173,9 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--txt-tokens", type=int, default=512)
-    ap.add_argument("--quant", choices=["none", "nf4", "fp8"], default="none",
-                    help="nf4: block linears stored bitsandbytes-nf4, fused dequant-GEMM (config C3); fp8: block linears on the e4m3 MFMA path (config C5)")
+    ap.add_argument("--quant", choices=["none", "nf4", "fp8", "int8"], default="none",
+                    help="nf4: block linears stored bitsandbytes-nf4, fused dequant-GEMM (config C3); fp8: block linears on the e4m3 MFMA path (config C5); "
+                         "int8: the int8 MFMA on the default linear mask (all but the double blocks' MLP), bf16 attention")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU per image step (C5: 2)")
     ap.add_argument("--sequence-parallel", action="store_true",
                     help="N > 1: all ranks denoise ONE image together (token shards, two all-to-alls per block; strong scaling) instead of one image each")
@@ -269,13 +270,15 @@ def main():
     bcast = fdist.broadcast_state(flux, dev) if world > 1 else None
     if args.quant == "fp8":
         flux.quantize_fp8()
+    if args.quant == "int8":
+        flux.quantize_int8()
     synth.fill_vae_random_device(vae, seed=1, device=dev)
     torch.cuda.synchronize()
     load_s = time.time() - t_load
     # single-image sequence parallelism: the ranks work on the SAME image, each on 1/N of its tokens
     spg = None
     if args.sequence_parallel and world > 1:
-        if args.quant == "fp8" or args.batch != 1:
+        if args.quant in ("fp8", "int8") or args.batch != 1:
             raise SystemExit("--sequence-parallel runs one bf16 / nf4 image at a time (batch 1)")
         spg = fdist.SequenceParallel(dev)
         spg.attach(flux)
@@ -410,7 +413,9 @@ def main():
         extra["avg_power_w_rank0"] = round((e_end - e_start) / 1e6 / elapsed, 1)
     KDESC = {"none": "gemm_pp_kernel + gemm_w4_kernel (bf16 MFMA GEMM: the 152 block-linear launches of a step)",
              "nf4": "gemm_w4q_kernel (fused nf4 dequant-GEMM on the packed weights: the 152 block-linear launches of a step; dense-equivalent FLOPs)",
-             "fp8": "gemm_pp_kernel<fp8> (e4m3 MFMA GEMM, all block linears)"}
+             "fp8": "gemm_pp_kernel<fp8> (e4m3 MFMA GEMM, all block linears)",
+             "int8": "gemm_pp_kernel<int8> (v_mfma_i32_32x32x32_i8: double q|k|v + attention out, single linear1 + linear2) + gemm_pp_kernel / gemm_w4_kernel (bf16: the double "
+                     "blocks' MLP); one average over both kinds of launch, priced against the int8 peak"}
     PEAK_NOTE = "2500 = dense bf16 MFMA peak at 2.4 GHz; a register-only MFMA loop (tools/mfma_peak.hip) sustains 2020-2160 on this part (power cap, ~1.95 GHz)"
     if rank == 0 and not args.no_profile_pass and spg is None:  # (the profiled pass is a single-device pass)
         traffic = tnote = None
@@ -431,7 +436,7 @@ def main():
                              + (f" ({live_note})" if live_note else ""))
                 except Exception:
                     pass
-        roof, ex, img = wl.profile(flux, KDESC[args.quant], 5000.0 if args.quant == "fp8" else 2500.0, traffic, tnote)
+        roof, ex, img = wl.profile(flux, KDESC[args.quant], 5000.0 if args.quant in ("fp8", "int8") else 2500.0, traffic, tnote)
         roof["peak_note"] = PEAK_NOTE
         extra.update(ex)
         # VAE decode timing
@@ -469,7 +474,7 @@ def main():
             torch.cuda.synchronize()
             el = time.perf_counter() - t1
             traffic = tnote = None
-            mode = "nf4" if name.startswith("nf4") else "fp8"
+            mode = "nf4" if name.startswith("nf4") else "int8" if name.startswith("int8") else "fp8"
             if (wk.H, wk.W, wk.B) == (1024, 1024, 1):  # the PMC passes are taken at the headline shape
                 try:
                     with open(os.path.join(ROOT, "profiles", f"pmc_summary_{mode}.json")) as f:
@@ -506,6 +511,15 @@ def main():
         # for this policy and the same bits — DESIGN 4.5 states the per-call policy as final, the leg was dropped in round 3)
         fq.close()
         del fq
+        # int8 mode (round 4): its own handle (bf16 weights + int8 codes of the masked linears), default mask = all but the double blocks' MLP
+        fi = d.FluxModel(d.FLUX_DEV, local_rank)
+        fill_flux(fi, "none")
+        fi.quantize_int8()
+        leg(fi, wl, "int8_1024", KDESC["int8"], 5000.0,
+            "int8 block linears (symmetric per-channel weight / per-token activation scales, exact int32 accumulate) for double q|k|v + attention out and single "
+            "linear1 + linear2; the double blocks' MLP, the attention and everything else bf16; f32 residual stream")
+        fi.close()
+        del fi
         flux.quantize_fp8()  # last: the headline model itself switches to the fp8 path
         fp8_dtype = "fp8 e4m3 block linears (per-channel weight / per-token activation scales, f32 accumulate), fp8 QK^T, f32 residual stream"
         leg(flux, wl, "fp8_1024", KDESC["fp8"], 5000.0, fp8_dtype)  # the headline workload (1024x1024, batch 1) in fp8 mode
@@ -680,9 +694,10 @@ def main():
             "metric": "images/sec, FLUX.1-dev 1024x1024 50-step" if (H, W, NS) == (1024, 1024, 50) else f"images/sec, FLUX.1-dev {W}x{H} {NS}-step",
             "value": total_images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "strong" if spg is not None else "weak", "vs_baseline": None, "dtype": {"none": "bf16", "nf4": "bf16 MFMA on nf4 weights (fused dequant-GEMM, packed weights only)",
-                                                                                                                 "fp8": "fp8 e4m3 block linears (per-channel weight / per-token activation scales, f32 accumulate), bf16 attention, f32 residual stream"}[args.quant],
+                                                                                                                 "fp8": "fp8 e4m3 block linears (per-channel weight / per-token activation scales, f32 accumulate), bf16 attention, f32 residual stream",
+                                                                                                                 "int8": "int8 block linears on the default mask (per-channel / per-token scales, exact int32 accumulate), the rest bf16, f32 residual stream"}[args.quant],
             "data": "synthetic (random-init FLUX.1-dev + FLUX VAE weights, N(0,1) embeddings, Philox latents)",
-            "config": {"workload": f"FLUX.1-dev {'fp8' if args.quant == 'fp8' else 'bf16'} {W}x{H} {NS}-step, batch={B} per GPU, S={S} img + T={T} txt tokens, step = one image "
+            "config": {"workload": f"FLUX.1-dev {args.quant if args.quant in ('fp8', 'int8') else 'bf16'} {W}x{H} {NS}-step, batch={B} per GPU, S={S} img + T={T} txt tokens, step = one image "
                                    "(50x Flux::forward + Euler, unpack, VAE decode, u8)",
                        "global_batch": B if spg is not None else world * B,
                        "parallelism": (f"sequence-parallel x{world} (one image on all ranks{', split-K latency mode' if args.split_k else ''})" if spg is not None

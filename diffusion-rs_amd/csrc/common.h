@@ -239,7 +239,7 @@ struct GemmProblem {
   // value * qk_k8 (static scales chosen so that sqrt(128) * max|norm weight| maps to 448), rows of 128 B in the same
   // head-major order; qk_qh / qk_kh then point to byte buffers.  v is unchanged (bf16).
   float qk_q8, qk_k8;
-  // fp8 operands (optional, fp8 != 0; dense 256-wide N tiles only): A and W point to OCP e4m3 bytes,
+  // 8-bit operands (optional, fp8 != 0: 1 = OCP e4m3, 2 = int8; dense 256-wide N tiles only): A and W point to bytes,
   // K / lda / ldw count elements (= bytes, K % 128 == 0), and the f32 accumulator is multiplied by
   // a_scale[m] * w_scale[n] (per-token / per-output-channel dequantisation) before the epilogue.
   int fp8;
@@ -315,16 +315,17 @@ int launch_layernorm_mod2(const float* x, const float* scale, const float* shift
                           hipStream_t stream);
 int launch_layernorm_mod_fp8_2(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch, uint8_t* out,
                                float* out_scale, int rows, const float* x2, const float* scale2, const float* shift2, int rows_per_batch2, uint8_t* out2,
-                               float* out_scale2, int rows2, int D, float eps, hipStream_t stream);
+                               float* out_scale2, int rows2, int D, float eps, hipStream_t stream, int kind = 1);
 int launch_layernorm_mod(const float* x, const float* scale, const float* shift, int mod_bstride,
                          int rows_per_batch, bf16_t* out, int rows, int D, float eps, hipStream_t stream);
 // y(M,N) f32 (+)= act_in(x(M,K) f32) W(N,K)^T bf16 + bias bf16 ; M <= 8
 // fp8 path (fp8.hip).  Row-wise dynamic quantisation: scale[r] = max(absmax(x[r,:]), 1e-30) / 448,
 // out[r,k] = e4m3_rne(x[r,k] * (448 / max(absmax, 1e-30))); x bf16 with row stride ld, out (rows, K) dense.
-int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* out, float* scale, hipStream_t stream);
+// kind 2: the int8 form (scale = absmax / 127, codes = clamp(rint(x * 127 / absmax), -127, 127)) — fp8.hip's header
+int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* out, float* scale, hipStream_t stream, int kind = 1);
 // launch_layernorm_mod with the row quantisation fused (values quantised from f32, not via bf16)
 int launch_layernorm_mod_fp8(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch,
-                             uint8_t* out, float* out_scale, int rows, int D, float eps, hipStream_t stream);
+                             uint8_t* out, float* out_scale, int rows, int D, float eps, hipStream_t stream, int kind = 1);
 int launch_gemv(const float* x, const bf16_t* W, const bf16_t* bias, float* y, int M, int N, int K,
                 int silu_in, int accumulate, hipStream_t stream);
 // bf16 out = w_i8 * SCB[row] / 127 (dequant.cu:205-214) on `stream`

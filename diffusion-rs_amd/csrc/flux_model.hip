@@ -156,8 +156,11 @@ struct fmi_flux {
   bool split_k = false;
   float* splitk_scratch = nullptr;
   size_t splitk_floats = 0;
-  // fp8 mode (fmi_flux_quantize_fp8)
+  // 8-bit modes (fmi_flux_quantize_fp8 / fmi_flux_quantize_int8): fp8 = some block linears hold an 8-bit form (Dense::w8) and the workspace
+  // has the code buffers; q8_kind says which (1 OCP e4m3, 2 int8 — GemmProblem::fp8), q8_mask which linears (FMI_Q8_* bits of the header)
   bool fp8 = false;
+  int q8_kind = 0;
+  unsigned q8_mask = 0;
   char* fp8_arena = nullptr;
   size_t fp8_bytes = 0;
   // fp8 attention operands (QK^T on the fp8 MFMA): static scales per block, 448 / (sqrt(128) * max|norm weight|) — a
@@ -460,7 +463,7 @@ GemmProblem make_problem_fp8(const fmi_flux* m, const Dense& d, int row0, int Mr
   p.lda = d.K, p.ldw = d.K, p.ldo = ldo;
   p.epi = epi;
   p.alpha = 1.0f;
-  p.fp8 = 1;
+  p.fp8 = m->q8_kind;
   p.a_scale = m->ws.a8s + row0;
   p.w_scale = d.w8_scale;
   return p;
@@ -796,6 +799,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
   const int64_t pe_bs = in->ids_per_sample ? (int64_t)L * 128 : 0;
   const float att_scale = 1.0f / sqrtf(128.0f);
   const bool fp8 = m->fp8;
+  const int qk = m->q8_kind;  // 1 e4m3, 2 int8
   // sequence parallel: S, T (and the ids) are this rank's shard; only the attention sees the other ranks (attention_sp)
   const bool sp = m->sp_world > 1 && m->sp_a2a;
   if (sp && (B != 1 || fp8)) return fail(FMI_ERR_UNSUPPORTED, "flux: sequence parallelism runs one image (B = 1) in bf16 mode");
@@ -833,11 +837,13 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     bf16_t* xm_txt = w.xm;
     bf16_t* xm_img = w.xm + (size_t)B * T * D;
     bool fused_img = false, fused_txt = false, qk8 = false;
+    // which of the block's linears run on 8-bit operands (all of them in fp8 mode; the int8 mode's mask leaves some in bf16)
+    const bool q_qkv = fp8 && bw.qkv[0].w8, q_out = fp8 && bw.proj[0].w8, q_m1 = fp8 && bw.mlp1[0].w8, q_m2 = fp8 && bw.mlp2[0].w8;
     {
       PhaseTimer pt(m, s, PH_LN);
-      if (fp8) {
+      if (q_qkv) {
         FMI_TRY(launch_layernorm_mod_fp8_2(w.x_img, mi + D, mi, nmod, S, w.a8 + (size_t)BT * D, w.a8s + BT, B * S, w.x_txt, mt + D, mt, T, w.a8, w.a8s,
-                                           B * T, D, 1e-6f, s));
+                                           B * T, D, 1e-6f, s, qk));
       } else {
         FMI_TRY(launch_layernorm_mod2(w.x_img, mi + D, mi, nmod, S, xm_img, B * S, w.x_txt, mt + D, mt, T, xm_txt, B * T, D, 1e-6f, s));
       }
@@ -845,13 +851,13 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     {
       PhaseTimer pt(m, s, PH_GEMM_QKV);
       GemmProblem p[2];
-      p[0] = fp8 ? make_problem_fp8(m, bw.qkv[0], BT, B * S, w.qkv_img, 3 * D, EPI_STORE_BF16)
-                 : make_problem(bw.qkv[0], xm_img, D, B * S, w.qkv_img, 3 * D, EPI_STORE_BF16);
-      p[1] = fp8 ? make_problem_fp8(m, bw.qkv[1], 0, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16)
-                 : make_problem(bw.qkv[1], xm_txt, D, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16);
+      p[0] = q_qkv ? make_problem_fp8(m, bw.qkv[0], BT, B * S, w.qkv_img, 3 * D, EPI_STORE_BF16)
+                   : make_problem(bw.qkv[0], xm_img, D, B * S, w.qkv_img, 3 * D, EPI_STORE_BF16);
+      p[1] = q_qkv ? make_problem_fp8(m, bw.qkv[1], 0, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16)
+                   : make_problem(bw.qkv[1], xm_txt, D, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16);
       // joint order [txt, img] (model.rs:540-542): txt tokens at positions [0,T), img at [T,T+S)
       // fp8 attention operands only when BOTH streams take the fused epilogue (the stand-alone kernels write bf16)
-      qk8 = fp8 && m->fp8_attn && can_fuse_relayout(m, B * S, S, T) && can_fuse_relayout(m, B * T, T, 0);
+      qk8 = q_qkv && qk == 1 && m->fp8_attn && can_fuse_relayout(m, B * S, S, T) && can_fuse_relayout(m, B * T, T, 0);
       const float q8 = qk8 ? m->q8_dbl[i] : 0.f, k8 = qk8 ? m->k8_dbl[i] : 0.f;
       fused_img = with_qkv_relayout(m, p[0], bw.nq[0], bw.nk[0], pe_bs, S, T, L, q8, k8);
       fused_txt = with_qkv_relayout(m, p[1], bw.nq[1], bw.nk[1], pe_bs, T, 0, L, q8, k8);
@@ -910,24 +916,24 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
       GemmProblem p[2];
-      if (fp8) {
-        FMI_TRY(launch_quantize_rows_fp8(w.attn_img, D, B * S, D, w.a8 + (size_t)BT * D, w.a8s + BT, s));
-        FMI_TRY(launch_quantize_rows_fp8(w.attn_txt, D, B * T, D, w.a8, w.a8s, s));
+      if (q_out) {
+        FMI_TRY(launch_quantize_rows_fp8(w.attn_img, D, B * S, D, w.a8 + (size_t)BT * D, w.a8s + BT, s, qk));
+        FMI_TRY(launch_quantize_rows_fp8(w.attn_txt, D, B * T, D, w.a8, w.a8s, s, qk));
       }
-      p[0] = fp8 ? make_problem_fp8(m, bw.proj[0], BT, B * S, w.x_img, D, EPI_RESID_GATE_F32)
-                 : make_problem(bw.proj[0], w.attn_img, D, B * S, w.x_img, D, EPI_RESID_GATE_F32);
+      p[0] = q_out ? make_problem_fp8(m, bw.proj[0], BT, B * S, w.x_img, D, EPI_RESID_GATE_F32)
+                   : make_problem(bw.proj[0], w.attn_img, D, B * S, w.x_img, D, EPI_RESID_GATE_F32);
       with_gate(p[0], mi + 2 * D, S, nmod);
-      p[1] = fp8 ? make_problem_fp8(m, bw.proj[1], 0, B * T, w.x_txt, D, EPI_RESID_GATE_F32)
-                 : make_problem(bw.proj[1], w.attn_txt, D, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
+      p[1] = q_out ? make_problem_fp8(m, bw.proj[1], 0, B * T, w.x_txt, D, EPI_RESID_GATE_F32)
+                   : make_problem(bw.proj[1], w.attn_txt, D, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
       with_gate(p[1], mt + 2 * D, T, nmod);
       Dense* dn[2] = {&bw.proj[0], &bw.proj[1]};
       FMI_TRY(gemm2(m, p, dn, 2, s));
     }
     {
       PhaseTimer pt(m, s, PH_LN);
-      if (fp8) {
+      if (q_m1) {
         FMI_TRY(launch_layernorm_mod_fp8_2(w.x_img, mi + 4 * D, mi + 3 * D, nmod, S, w.a8 + (size_t)BT * D, w.a8s + BT, B * S, w.x_txt, mt + 4 * D,
-                                           mt + 3 * D, T, w.a8, w.a8s, B * T, D, 1e-6f, s));
+                                           mt + 3 * D, T, w.a8, w.a8s, B * T, D, 1e-6f, s, qk));
       } else {
         FMI_TRY(launch_layernorm_mod2(w.x_img, mi + 4 * D, mi + 3 * D, nmod, S, xm_img, B * S, w.x_txt, mt + 4 * D, mt + 3 * D, T, xm_txt, B * T, D,
                                       1e-6f, s));
@@ -938,18 +944,18 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       bf16_t* hid_txt = w.hid;
       bf16_t* hid_img = w.hid + (size_t)B * T * Mh;
       GemmProblem p[2];
-      p[0] = fp8 ? make_problem_fp8(m, bw.mlp1[0], BT, B * S, hid_img, Mh, EPI_GELU_BF16) : make_problem(bw.mlp1[0], xm_img, D, B * S, hid_img, Mh, EPI_GELU_BF16);
-      p[1] = fp8 ? make_problem_fp8(m, bw.mlp1[1], 0, B * T, hid_txt, Mh, EPI_GELU_BF16) : make_problem(bw.mlp1[1], xm_txt, D, B * T, hid_txt, Mh, EPI_GELU_BF16);
+      p[0] = q_m1 ? make_problem_fp8(m, bw.mlp1[0], BT, B * S, hid_img, Mh, EPI_GELU_BF16) : make_problem(bw.mlp1[0], xm_img, D, B * S, hid_img, Mh, EPI_GELU_BF16);
+      p[1] = q_m1 ? make_problem_fp8(m, bw.mlp1[1], 0, B * T, hid_txt, Mh, EPI_GELU_BF16) : make_problem(bw.mlp1[1], xm_txt, D, B * T, hid_txt, Mh, EPI_GELU_BF16);
       Dense* dn1[2] = {&bw.mlp1[0], &bw.mlp1[1]};
       FMI_TRY(gemm2(m, p, dn1, 2, s));
-      if (fp8) {  // hid is (B*L, M) with the txt rows first, like a8
-        FMI_TRY(launch_quantize_rows_fp8(w.hid, Mh, B * L, Mh, w.a8, w.a8s, s));
+      if (q_m2) {  // hid is (B*L, M) with the txt rows first, like a8
+        FMI_TRY(launch_quantize_rows_fp8(w.hid, Mh, B * L, Mh, w.a8, w.a8s, s, qk));
       }
-      p[0] = fp8 ? make_problem_fp8(m, bw.mlp2[0], BT, B * S, w.x_img, D, EPI_RESID_GATE_F32)
-                 : make_problem(bw.mlp2[0], hid_img, Mh, B * S, w.x_img, D, EPI_RESID_GATE_F32);
+      p[0] = q_m2 ? make_problem_fp8(m, bw.mlp2[0], BT, B * S, w.x_img, D, EPI_RESID_GATE_F32)
+                  : make_problem(bw.mlp2[0], hid_img, Mh, B * S, w.x_img, D, EPI_RESID_GATE_F32);
       with_gate(p[0], mi + 5 * D, S, nmod);
-      p[1] = fp8 ? make_problem_fp8(m, bw.mlp2[1], 0, B * T, w.x_txt, D, EPI_RESID_GATE_F32)
-                 : make_problem(bw.mlp2[1], hid_txt, Mh, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
+      p[1] = q_m2 ? make_problem_fp8(m, bw.mlp2[1], 0, B * T, w.x_txt, D, EPI_RESID_GATE_F32)
+                  : make_problem(bw.mlp2[1], hid_txt, Mh, B * T, w.x_txt, D, EPI_RESID_GATE_F32);
       with_gate(p[1], mt + 5 * D, T, nmod);
       Dense* dn2[2] = {&bw.mlp2[0], &bw.mlp2[1]};
       FMI_TRY(gemm2(m, p, dn2, 2, s));
@@ -966,19 +972,20 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     auto& bw = m->sgl[i];
     const float* mo = mod + bw.mod_off;  // shift, scale, gate
     bool fused = false;
-    const bool qk8 = fp8 && m->fp8_attn && can_fuse_relayout(m, B * L, L, 0);
+    const bool q_w1 = fp8 && bw.w1.w8, q_w2 = fp8 && bw.w2.w8;
+    const bool qk8 = q_w1 && qk == 1 && m->fp8_attn && can_fuse_relayout(m, B * L, L, 0);
     {
       PhaseTimer pt(m, s, PH_LN);
-      if (fp8)
-        FMI_TRY(launch_layernorm_mod_fp8(w.x, mo + D, mo, nmod, L, w.a8, w.a8s, B * L, D, 1e-6f, s));
+      if (q_w1)
+        FMI_TRY(launch_layernorm_mod_fp8(w.x, mo + D, mo, nmod, L, w.a8, w.a8s, B * L, D, 1e-6f, s, qk));
       else
         FMI_TRY(launch_layernorm_mod(w.x, mo + D, mo, nmod, L, w.xm, B * L, D, 1e-6f, s));
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_QKV);
       // [q|k|v|gelu(proj_mlp)] in one GEMM; the concat of model.rs:660 is never materialised
-      GemmProblem p = fp8 ? make_problem_fp8(m, bw.w1, 0, B * L, w.big, ldbig, EPI_GELU_FROM_COL)
-                          : make_problem(bw.w1, w.xm, D, B * L, w.big, ldbig, EPI_GELU_FROM_COL);
+      GemmProblem p = q_w1 ? make_problem_fp8(m, bw.w1, 0, B * L, w.big, ldbig, EPI_GELU_FROM_COL)
+                           : make_problem(bw.w1, w.xm, D, B * L, w.big, ldbig, EPI_GELU_FROM_COL);
       p.gelu_from = 3 * D;
       fused = with_qkv_relayout(m, p, bw.nq, bw.nk, pe_bs, L, 0, L, qk8 ? m->q8_sgl[i] : 0.f, qk8 ? m->k8_sgl[i] : 0.f);
       FMI_TRY(gemm1(m, p, bw.w1, s));
@@ -1001,9 +1008,9 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
-      if (fp8) FMI_TRY(launch_quantize_rows_fp8(w.big + 2 * D, ldbig, B * L, D + Mh, w.a8, w.a8s, s));
-      GemmProblem p = fp8 ? make_problem_fp8(m, bw.w2, 0, B * L, w.x, D, EPI_RESID_GATE_F32)
-                          : make_problem(bw.w2, w.big + 2 * D, ldbig, B * L, w.x, D, EPI_RESID_GATE_F32);
+      if (q_w2) FMI_TRY(launch_quantize_rows_fp8(w.big + 2 * D, ldbig, B * L, D + Mh, w.a8, w.a8s, s, qk));
+      GemmProblem p = q_w2 ? make_problem_fp8(m, bw.w2, 0, B * L, w.x, D, EPI_RESID_GATE_F32)
+                           : make_problem(bw.w2, w.big + 2 * D, ldbig, B * L, w.x, D, EPI_RESID_GATE_F32);
       with_gate(p, mo + 2 * D, L, nmod);
       FMI_TRY(gemm1(m, p, bw.w2, s));
     }
@@ -1458,18 +1465,27 @@ extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int mode) {
   m->dense_ready.clear();
   return FMI_OK;
 }
-// fp8 mode: quantise every block Linear once (bf16 arena -> e4m3 + per-output-channel scale); see the header.
-extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) {
+// 8-bit modes: quantise the block Linears of `mask` once (bf16 arena -> e4m3 / int8 codes + per-output-channel scale); see the header.
+static int quantize_8bit(fmi_flux* m, int kind, unsigned mask, void* stream) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
   FMI_TRY(use_device(m));
   FMI_TRY(check_ready(m));
-  if (m->fp8) return FMI_OK;
+  if (m->fp8) {
+    if (m->q8_kind == kind && m->q8_mask == mask) return FMI_OK;
+    return fail(FMI_ERR_STATE, "quantize: the model already holds another 8-bit form (create a new one)");
+  }
+  if (!(mask & 0x3f) || (mask & ~0x3fu)) return fail(FMI_ERR_INVALID, "quantize: the linear mask must name at least one of the six block linears (bits 0..5)");
   std::vector<Dense*> lin;
   for (auto& b : m->dbl)
-    for (int s = 0; s < 2; ++s)
-      for (Dense* d : {&b.qkv[s], &b.proj[s], &b.mlp1[s], &b.mlp2[s]}) lin.push_back(d);
-  for (auto& b : m->sgl)
-    for (Dense* d : {&b.w1, &b.w2}) lin.push_back(d);
+    for (int s = 0; s < 2; ++s) {
+      Dense* ds[4] = {&b.qkv[s], &b.proj[s], &b.mlp1[s], &b.mlp2[s]};
+      for (int k = 0; k < 4; ++k)
+        if (mask >> k & 1) lin.push_back(ds[k]);
+    }
+  for (auto& b : m->sgl) {
+    if (mask >> 4 & 1) lin.push_back(&b.w1);
+    if (mask >> 5 & 1) lin.push_back(&b.w2);
+  }
   size_t bytes = 0;
   for (Dense* d : lin) {
     if (d->q_type || !d->w) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: model holds bitsandbytes-quantised linears; load a bf16 checkpoint");
@@ -1486,7 +1502,7 @@ extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) {
     off += align_up((size_t)d->N * d->K, 256);
     d->w8_scale = reinterpret_cast<float*>(m->fp8_arena + off);
     off += align_up((size_t)d->N * 4, 256);
-    FMI_TRY(launch_quantize_rows_fp8(d->w, d->K, d->N, d->K, d->w8, d->w8_scale, s));
+    FMI_TRY(launch_quantize_rows_fp8(d->w, d->K, d->N, d->K, d->w8, d->w8_scale, s, kind));
   }
   FMI_HIP_TRY(hipStreamSynchronize(s));
   {  // static e4m3 scales of the attention operands from the QkNorm weights (see fmi_flux::fp8_attn)
@@ -1543,8 +1559,13 @@ extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) {
     m->ws.bytes = 0;
   }
   m->fp8 = true;
+  m->q8_kind = kind;
+  m->q8_mask = mask;
   return FMI_OK;
 }
+extern "C" int fmi_flux_quantize_fp8(fmi_flux* m, void* stream) { return quantize_8bit(m, 1, 0x3f, stream); }
+// int8 mode (round 4): the same per-row recipe on int8 codes (fp8.hip's header) for the linears of `linear_mask`; the others stay bf16.
+extern "C" int fmi_flux_quantize_int8(fmi_flux* m, unsigned linear_mask, void* stream) { return quantize_8bit(m, 2, linear_mask, stream); }
 // fp8 mode only: 1 (default) = q and k leave the fused relayout epilogue as e4m3 and QK^T runs on the fp8 MFMA whenever
 // both streams of a block take that epilogue (token counts multiples of 16); 0 = bf16 attention operands
 extern "C" int fmi_flux_set_fp8_attention(fmi_flux* m, int enable) {

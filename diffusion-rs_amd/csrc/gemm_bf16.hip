@@ -847,8 +847,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
 // which they do: both tiles have the same LDS layout and are read with the same offsets.
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
-template <bool FP8, int ACT>
+typedef __attribute__((ext_vector_type(16))) int i32x16_t;
+template <int Q8, int ACT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatch batch) {
+  constexpr bool FP8 = Q8 != 0;  // 8-bit operands: 1 = OCP e4m3, 2 = int8 (GemmProblem::fp8)
+  constexpr bool I8 = Q8 == 2;
   constexpr int NJ = 2, BN = 256;
   constexpr int ES = FP8 ? 1 : 2;  // operand element size
   constexpr int A_RING = 0, W_RING = 2 * A_TILE_BYTES, TILE = A_TILE_BYTES;  // 2 x 32 KiB + 3 x 32 KiB
@@ -876,9 +879,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
   // fp8: v_mfma_f32_32x32x64_f8f6f4, accumulators acc[4][NJ] of 32 x 32 (Acc32).  bf16: v_mfma_f32_16x16x32_bf16, accumulators
   // acc16[8][2 NJ] of 16 x 16 (Acc16) — on this power-capped part the 16 x 16 x 32 form sustains 14 % more than 32 x 32 x 16
   // (tools/mfma_peak); same LDS image, the fragment of a 16-row block is rows lane & 15 at k slot 4 s + (lane >> 4).
+  // int8: v_mfma_i32_32x32x32_i8, two per 32-byte fragment pair (each 16-byte fragment is one instruction's 32-k operand), accumulators
+  // acci of the same shape and lane layout as acc; the sums are exact integers, converted once behind the K loop.
   f32x16 acc[FP8 ? 4 : 1][NJ];
+  i32x16_t acci[I8 ? 4 : 1][NJ];
   f32x4 acc16[FP8 ? 1 : 8][2 * NJ];
-  if constexpr (FP8) {
+  if constexpr (I8) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acci[i][j][r] = 0;
+  } else if constexpr (FP8) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1011,7 +1024,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
     }
     slot_barrier();
     // ---- COMPUTE(t): the matrix pipe only
-    if constexpr (FP8) {
+    if constexpr (I8) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            acci[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_shufflevector(wq[s][j], wq[s][j], 0, 1, 2, 3),
+                                                               __builtin_shufflevector(xq[s][i], xq[s][i], 0, 1, 2, 3), acci[i][j], 0, 0, 0);
+            acci[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_shufflevector(wq[s][j], wq[s][j], 4, 5, 6, 7),
+                                                               __builtin_shufflevector(xq[s][i], xq[s][i], 4, 5, 6, 7), acci[i][j], 0, 0, 0);
+          }
+    } else if constexpr (FP8) {
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1036,6 +1061,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
   for (int t = nmain; t < nk; ++t) ktile(t, std::false_type{});
   if (g == 0) slot_barrier();  // group 0 finished one slot early
 
+  if constexpr (I8) {  // the exact integer sums as f32 (v_cvt_f32_i32: round to nearest even beyond 2^24, as the oracle's (float) cast)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = (float)acci[i][j][r];
+  }
   if constexpr (FP8) {  // dequantise: per-token scale of the row, per-channel scale of the 4 consecutive columns
     float sa[4];
 #pragma unroll
@@ -1418,7 +1451,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   for (int i = 0; i < nprob; ++i) {
     const GemmProblem& p = probs[i];
     if (p.M <= 0 || p.N <= 0) return fail(FMI_ERR_INVALID, "launch_gemm: empty problem");
-    if ((p.fp8 != 0) != fp8) return fail(FMI_ERR_INVALID, "launch_gemm: cannot mix fp8 and bf16 problems in one group");
+    if (p.fp8 != probs[0].fp8 || p.fp8 < 0 || p.fp8 > 2) return fail(FMI_ERR_INVALID, "launch_gemm: cannot mix e4m3 / int8 / bf16 problems in one group");
     if (fp8 && (p.q_type || p.cv_ks || bn != 256 || p.K % 128 || p.lda % 16 || p.ldw % 16 || !p.a_scale || !p.w_scale))
       return fail(FMI_ERR_INVALID, "launch_gemm: fp8 needs dense operands, N > 128, K / lda / ldw multiples of 128 / 16 / 16 and both scale vectors");
     if (p.K <= 0 || p.K % BK != 0) return fail(FMI_ERR_INVALID, "launch_gemm: K must be a positive multiple of 64, got " + std::to_string(p.K));
@@ -1476,8 +1509,10 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
     else if (act == 2) hipLaunchKernelGGL((KERNEL<FP8FLAG, 2>), grid, dim3(THREADS), 0, stream, b); \
     else hipLaunchKernelGGL((KERNEL<FP8FLAG, 3>), grid, dim3(THREADS), 0, stream, b);               \
   } while (0)
-  if (fp8)
-    FMI_ACT_LAUNCH(gemm_pp_kernel, true, GEMM_THREADS);
+  if (fp8 && probs[0].fp8 == 2)
+    FMI_ACT_LAUNCH(gemm_pp_kernel, 2, GEMM_THREADS);
+  else if (fp8)
+    FMI_ACT_LAUNCH(gemm_pp_kernel, 1, GEMM_THREADS);
   else if (conv)
     FMI_GEMM_LAUNCH(2);
   else if (quant && bn == 256 && w4q_ok) {
@@ -1493,7 +1528,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
   else if (bn == 256 && g_w4 && w4_pays)
     FMI_ACT_LAUNCH(gemm_w4_kernel, false, W4_THREADS);
   else if (bn == 256 && g_pingpong)
-    FMI_ACT_LAUNCH(gemm_pp_kernel, false, GEMM_THREADS);
+    FMI_ACT_LAUNCH(gemm_pp_kernel, 0, GEMM_THREADS);
   else
     FMI_GEMM_LAUNCH(0);
 #undef FMI_GEMM_LAUNCH

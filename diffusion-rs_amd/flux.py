@@ -16,6 +16,10 @@ import torch
 
 from . import _lib as L
 
+# fmi_flux_quantize_int8's linear mask (include/flux_mi355x.h: FMI_Q8_*)
+Q8_DOUBLE_QKV, Q8_DOUBLE_OUT, Q8_DOUBLE_MLP_IN, Q8_DOUBLE_MLP_OUT, Q8_SINGLE_LINEAR1, Q8_SINGLE_LINEAR2 = 1, 2, 4, 8, 16, 32
+INT8_DEFAULT_MASK = Q8_DOUBLE_QKV | Q8_DOUBLE_OUT | Q8_SINGLE_LINEAR1 | Q8_SINGLE_LINEAR2  # FMI_INT8_DEFAULT_MASK
+
 FLUX_DEV = dict(in_channels=64, pooled_projection_dim=768, joint_attention_dim=4096, num_attention_heads=24, num_layers=19,
                 num_single_layers=38, guidance_embeds=True, axes_dim=[16, 56, 56], theta=10000)
 FLUX_SCHNELL = dict(FLUX_DEV, guidance_embeds=False)
@@ -133,6 +137,12 @@ class FluxModel:
         """Switch the DiT block linears to the fp8 (OCP e4m3) MFMA path: weights quantised once per output
         channel from the loaded bf16 values, activations per token on the fly (BASELINE configs[4])."""
         L.check(self.lib.fmi_flux_quantize_fp8(self.h, stream))
+
+    def quantize_int8(self, mask: int = None, stream=None):
+        """Switch the DiT block linears named by `mask` (Q8_* bits; default INT8_DEFAULT_MASK) to the int8 MFMA path: symmetric per-row
+        int8 codes (weights once per output channel, activations per token on the fly), exact int32 accumulation; the other block
+        linears, the attention and everything else stay on the bf16 path."""
+        L.check(self.lib.fmi_flux_quantize_int8(self.h, INT8_DEFAULT_MASK if mask is None else int(mask), stream))
 
     def missing(self) -> List[str]:
         n = self.lib.fmi_flux_missing_count(self.h)

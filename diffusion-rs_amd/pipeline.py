@@ -42,6 +42,7 @@ class ModelDType(enum.Enum):  # diffusion_rs_py/src/lib.rs:37-44
     F16 = 2
     F32 = 3
     F8E4M3 = 4  # extension (not in the reference): DiT block linears on the e4m3 MFMA, DESIGN.md §4.3
+    I8 = 5      # extension: the int8 MFMA on the linears of flux.INT8_DEFAULT_MASK (all but the double blocks' MLP), DESIGN.md §4.3c
 
 
 class Offloading(enum.Enum):  # lib.rs:13-17.  Accepted and ignored: 288 GB of HBM hold everything.
@@ -187,6 +188,8 @@ class Pipeline:
                 self.load_stats["broadcast"] = {"bytes": 0, "messages": 0, "seconds": 0.0, "fallback": f"every rank loaded the DiT itself ({e})"}
         if dtype == ModelDType.F8E4M3:
             self.flux.quantize_fp8()
+        elif dtype == ModelDType.I8:
+            self.flux.quantize_int8()
 
     # Pipeline::load (pipelines/mod.rs:120-236) for a local diffusers directory or a DDUF file:
     # model_index.json -> FluxPipeline only; scheduler / transformer / vae components, plus text_encoder (CLIP),

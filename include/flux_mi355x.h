@@ -227,6 +227,25 @@ int fmi_flux_set_modulation_gemm(fmi_flux*, int enable);
  * (AdaLN-modulate) or by one row pass (attention output, GELU(MLP)).  Attention, the residual stream,
  * modulation, embedders and the final layer stay bf16/f32.  Not combinable with bnb-quantised linears. */
 int fmi_flux_quantize_fp8(fmi_flux*, void* stream);
+/* int8 inference mode (round 4; this library's own recipe like the fp8 one, restated in oracle/flux_oracle.cpp: orc_quantize_rows_i8 and
+ * lin_blk mode 5).  The same per-row scheme on symmetric int8 codes — scale = absmax / 127 per output channel (weights, once) and per
+ * token (activations, by the producing AdaLN-modulate kernel or one row pass), codes = clamp(rint(x * 127 / absmax), -127, 127) — and
+ * the GEMMs on v_mfma_i32_32x32x32_i8: the sum over k is an exact int32, converted once and multiplied by scale_a[m] * scale_w[n].
+ * Why it exists: an e4m3 operand carries 2.65e-2 rms relative noise whatever the scale granularity (3-bit mantissa), an int8 one
+ * 8.5e-3 (uniform steps over a Gaussian row), at the same matrix-pipe rate; with the default mask the full model stays within the
+ * tolerance stated for 8-bit modes where the e4m3 mode is a factor three outside it.
+ * `linear_mask` says WHICH block linears are quantised (the others keep their bf16 GEMM): FMI_INT8_DEFAULT_MASK = all but the double
+ * blocks' MLP, the two linears that carry most of the error per millisecond saved (DESIGN.md 4.3c's table).  Attention, residual
+ * stream, modulation, embedders and final layer stay bf16 / f32.  Call once after all tensors are set; not combinable with
+ * bnb-quantised linears or with fmi_flux_quantize_fp8 (FMI_ERR_STATE). */
+#define FMI_Q8_DOUBLE_QKV 1u      /* double blocks: q|k|v of both streams */
+#define FMI_Q8_DOUBLE_OUT 2u      /* double blocks: attention output projections */
+#define FMI_Q8_DOUBLE_MLP_IN 4u   /* double blocks: MLP linear 1 (+ GELU) */
+#define FMI_Q8_DOUBLE_MLP_OUT 8u  /* double blocks: MLP linear 2 */
+#define FMI_Q8_SINGLE_LINEAR1 16u /* single blocks: q|k|v|proj_mlp */
+#define FMI_Q8_SINGLE_LINEAR2 32u /* single blocks: proj_out over cat(attention, gelu(mlp)) */
+#define FMI_INT8_DEFAULT_MASK (FMI_Q8_DOUBLE_QKV | FMI_Q8_DOUBLE_OUT | FMI_Q8_SINGLE_LINEAR1 | FMI_Q8_SINGLE_LINEAR2)
+int fmi_flux_quantize_int8(fmi_flux*, unsigned linear_mask, void* stream);
 /* fp8 mode, attention operands: 1 (default) = q and k leave the fused QKV epilogue as e4m3 with static per-block
  * scales 448 / (sqrt(128) * max|QkNorm weight|) (no element of a normalised, rotated head vector can exceed them) and
  * QK^T runs on the fp8 MFMA; P and V stay bf16.  Applies when both streams of a block take the fused epilogue (token
@@ -472,6 +491,12 @@ int fmi_quantize_rows_fp8(const void* x, int rows, int K, uint8_t* out, float* s
  * N > 128, K % 128 == 0. */
 int fmi_linear_fp8(const void* x, const uint8_t* wq, const float* w_scale, const void* bias, void* y, int M, int N,
                    int K, fmi_epilogue epi, void* stream);
+/* The int8 forms of the two (fmi_flux_quantize_int8's recipe; oracle: orc_quantize_rows_i8 / orc_linear_i8): scale[r] =
+ * max(absmax, 1e-30) / 127, out[r,k] = clamp(rint(x[r,k] * (127 / max(absmax, 1e-30))), -127, 127); y = epi(float(xq · Wq^T as an exact
+ * int32) * (xs[m] * ws[n]) + bias) on v_mfma_i32_32x32x32_i8.  Same shape rules. */
+int fmi_quantize_rows_i8(const void* x, int rows, int K, int8_t* out, float* scale, void* stream);
+int fmi_linear_i8(const void* x, const int8_t* wq, const float* w_scale, const void* bias, void* y, int M, int N,
+                  int K, fmi_epilogue epi, void* stream);
 /* softmax(q k^T * scale) v, q,k,v,o (B,H,L,d) bf16, d == 128, non-causal; o is written
  * token-major (B,L,H*d) when `out_token_major`, else (B,H,L,d).
  * == backend::ops::sdpa fallback (ops.rs:247-262) without materialising the scores. */

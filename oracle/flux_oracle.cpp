@@ -608,6 +608,45 @@ extern "C" void orc_quantize_rows_fp8(const float* x, int rows, int K, uint8_t* 
     for (int k = 0; k < K; ++k) out[(int64_t)r * K + k] = orc_f32_to_e4m3(xr[k] * inv);
   }
 }
+// The int8 form of the same recipe (no reference counterpart; csrc/fp8.hip's header states it for the HIP path): symmetric, one scale per
+// row, scale = max(absmax, 1e-30) / 127, code = clamp(rint(x * (127 / max(absmax, 1e-30))), -127, 127) with round-half-to-even.
+extern "C" void orc_quantize_rows_i8(const float* x, int rows, int K, int8_t* out, float* scale) {
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r) {
+    const float* xr = x + (int64_t)r * K;
+    float am = 0.f;
+    for (int k = 0; k < K; ++k) am = fmaxf(am, fabsf(xr[k]));
+    am = fmaxf(am, 1e-30f);
+    const float inv = 127.0f / am;
+    scale[r] = am / 127.0f;
+    for (int k = 0; k < K; ++k) out[(int64_t)r * K + k] = (int8_t)fminf(fmaxf(nearbyintf(xr[k] * inv), -127.0f), 127.0f);
+  }
+}
+// y[m,n] = float(sum_k qx[m,k] qw[n,k]) * (sx[m] * sw[n]) + b[n], the sum an EXACT integer (as the int8 MFMA's int32 accumulator):
+// the f32 GEMM runs over slices of 1024 k, inside which every partial sum is an integer below 2^24 (1024 * 127^2) and therefore exact
+// in any order, and the slices are added in double.  qx / qw hold the codes as floats.
+static void gemm_i8_exact(const float* qx, const float* sx, const float* qw, const float* sw, const float* bias, int M, int N, int K, float* y) {
+  std::vector<double> acc((size_t)M * N, 0.0);
+  std::vector<float> part((size_t)M * N);
+  for (int k0 = 0; k0 < K; k0 += 1024) {
+    const int kc = std::min(1024, K - k0);
+    gemm_nt(qx + k0, K, qw + k0, K, nullptr, M, N, kc, part.data(), N, 1.0f);
+#pragma omp parallel for
+    for (int64_t i = 0; i < (int64_t)M * N; ++i) acc[i] += (double)part[i];
+  }
+#pragma omp parallel for
+  for (int r = 0; r < M; ++r)
+    for (int n = 0; n < N; ++n) y[(int64_t)r * N + n] = (float)(int32_t)acc[(int64_t)r * N + n] * (sx[r] * sw[n]) + (bias ? bias[n] : 0.f);
+}
+extern "C" void orc_linear_i8(const float* x, const float* w, const float* bias, int M, int N, int K, float* y) {
+  std::vector<int8_t> xc((size_t)M * K), wc((size_t)N * K);
+  std::vector<float> xs(M), ws(N), xq((size_t)M * K), wq((size_t)N * K);
+  orc_quantize_rows_i8(x, M, K, xc.data(), xs.data());
+  orc_quantize_rows_i8(w, N, K, wc.data(), ws.data());
+  for (size_t i = 0; i < xc.size(); ++i) xq[i] = (float)xc[i];
+  for (size_t i = 0; i < wc.size(); ++i) wq[i] = (float)wc[i];
+  gemm_i8_exact(xq.data(), xs.data(), wq.data(), ws.data(), bias, M, N, K, y);
+}
 
 // ---------------------------------------------------------------------------------------
 // FLUX model — diffusion_rs_core/src/models/flux/model.rs
@@ -619,6 +658,9 @@ struct Fp8Weight {
 struct orc_flux {
   int fp8 = 0;  // block linears on the fp8 recipe above
   int fp8_attn = 0;  // q, k of the attention quantised to e4m3 with static scales (see attention())
+  // which block linears take the 8-bit recipe (the others stay f32 / lin_fwd): bit 0 double q|k|v, 1 double attention out, 2 double MLP in,
+  // 3 double MLP out, 4 single linear1 (q, k, v, proj_mlp), 5 single linear2 (proj_out).  orc_flux_set_q8_mask; default all.
+  int q8_mask = 0x3f;
   std::map<const float*, Fp8Weight> fp8_w;
   int in_channels, pooled_dim, joint_dim, heads, n_double, n_single, guidance;
   int axes[3], theta;
@@ -710,6 +752,7 @@ extern "C" void orc_flux_set_fp8(orc_flux* m, int on) {
   m->fp8 = on;
 }
 extern "C" void orc_flux_set_fp8_attention(orc_flux* m, int on) { m->fp8_attn = on; }
+extern "C" void orc_flux_set_q8_mask(orc_flux* m, int mask) { m->q8_mask = mask; }
 extern "C" int orc_flux_set_tensor(orc_flux* m, const char* name, const float* data, int64_t numel) {
   m->t[name] = std::vector<float>(data, data + numel);
   m->t16.erase(name);
@@ -745,13 +788,13 @@ Lin get_lin(const orc_flux* m, const std::string& p, int in, int out, bool bias 
 void lin_fwd(const Lin& l, const float* x, int rows, float* y) { gemm_nt(x, l.in, l.w, l.in, l.b, rows, l.out, l.in, y, l.out, 1.0f); }
 // A DiT block Linear: lin_fwd, or the fp8 recipe when orc_flux_set_fp8 is on:
 // y[m,n] = (sum_k qx[m,k] qw[n,k]) * (sx[m] * sw[n]) + b[n]
-// orc_flux_set_fp8 modes.  1 is THE recipe (what the HIP path implements).  2..6 exist for the noise study of
+// orc_flux_set_fp8 modes.  1 is THE fp8 recipe and 5 THE int8 recipe (what the HIP path implements).  2, 3, 4, 6 exist for the noise study of
 // tools/fp8_noise_study.py only (DESIGN 4.3 "the e4m3 noise floor"): they answer "would another scaling granularity or
 // keeping one operand exact bring the mode inside the bf16 tolerance?" with the same f32 GEMM behind each quantiser.
 //   1  e4m3, one scale per row (token / output channel), both operands
 //   2  e4m3, one power-of-two (E8M0) scale per 32 consecutive k (the MX block format of v_mfma_scale_*), both operands
 //   3  as 1, weights only (activations exact)      4  as 1, activations only (weights exact)
-//   5  int8, absmax / 127 per row, both operands   6  as 2, activations only
+//   5  int8, absmax / 127 per row, both operands (exact integer accumulation)   6  as 2, activations only
 static void study_quantise(const float* x, int rows, int K, int kind, float* out) {
   // kind 0: copy, 1: e4m3 per row, 2: e4m3 per 32-block with a power-of-two scale that never clips, 5: int8 per row
 #pragma omp parallel for
@@ -786,8 +829,25 @@ static void study_quantise(const float* x, int rows, int K, int kind, float* out
     }
   }
 }
-void lin_blk(orc_flux* m, const Lin& l, const float* x, int rows, float* y) {
-  if (!m->fp8) return lin_fwd(l, x, rows, y);
+enum { LIN_DBL_QKV = 0, LIN_DBL_OUT = 1, LIN_DBL_MLP1 = 2, LIN_DBL_MLP2 = 3, LIN_SGL_1 = 4, LIN_SGL_2 = 5 };
+void lin_blk(orc_flux* m, const Lin& l, const float* x, int rows, float* y, int which) {
+  if (!m->fp8 || !((m->q8_mask >> which) & 1)) return lin_fwd(l, x, rows, y);
+  if (m->fp8 == 5) {  // THE int8 recipe (what fmi_flux_quantize_int8 implements): exact integer sums, see gemm_i8_exact
+    Fp8Weight& fw = m->fp8_w[l.w];
+    if (fw.q.empty()) {
+      std::vector<int8_t> codes((size_t)l.out * l.in);
+      fw.s.resize(l.out);
+      orc_quantize_rows_i8(l.w, l.out, l.in, codes.data(), fw.s.data());
+      fw.q.resize(codes.size());
+      for (size_t i = 0; i < codes.size(); ++i) fw.q[i] = (float)codes[i];
+    }
+    std::vector<int8_t> xc((size_t)rows * l.in);
+    std::vector<float> xs(rows), xq((size_t)rows * l.in);
+    orc_quantize_rows_i8(x, rows, l.in, xc.data(), xs.data());
+    for (size_t i = 0; i < xc.size(); ++i) xq[i] = (float)xc[i];
+    gemm_i8_exact(xq.data(), xs.data(), fw.q.data(), fw.s.data(), l.b, rows, l.out, l.in, y);
+    return;
+  }
   if (m->fp8 != 1) {  // study modes: dequantised operands through the plain f32 GEMM
     static const int wk[7] = {0, 1, 2, 1, 0, 5, 0}, ak[7] = {0, 1, 2, 0, 1, 5, 2};
     const int mode = std::min(std::max(m->fp8, 2), 6);
@@ -857,20 +917,20 @@ void attention(const float* q, const float* k, const float* v, const float* pe, 
     for (int h = 0; h < H; ++h) memcpy(out_tok + ((int64_t)l * H + h) * d, o.data() + ((int64_t)h * L + l) * d, sizeof(float) * d);
 }
 // SelfAttention::qkv, model.rs:399-427: three linears, head split, QkNorm on q and k.
-bool qkv(orc_flux* m, const std::string& p, const char* qn, const char* kn, const char* vn, const char* nq, const char* nk, const float* x, int rows, int row_off, int Ltot, float* Q, float* K, float* V) {
+bool qkv(orc_flux* m, const std::string& p, const char* qn, const char* kn, const char* vn, const char* nq, const char* nk, const float* x, int rows, int row_off, int Ltot, float* Q, float* K, float* V, int which) {
   const int D = m->D, H = m->heads, d = D / H;
   Lin lq = get_lin(m, p + qn, D, D), lk = get_lin(m, p + kn, D, D), lv = get_lin(m, p + vn, D, D);
   const float* wq = m->get(p + nq + ".weight", d);
   const float* wk = m->get(p + nk + ".weight", d);
   if (!lq.ok() || !lk.ok() || !lv.ok() || !wq || !wk) return false;
   std::vector<float> tmp((size_t)rows * D), tmp2((size_t)rows * D);
-  lin_blk(m, lq, x, rows, tmp.data());
+  lin_blk(m, lq, x, rows, tmp.data(), which);
   orc_rms_norm_slow(tmp.data(), wq, 1e-6f, rows * H, d, tmp2.data());
   to_heads(tmp2.data(), rows, H, d, Q, row_off, Ltot);
-  lin_blk(m, lk, x, rows, tmp.data());
+  lin_blk(m, lk, x, rows, tmp.data(), which);
   orc_rms_norm_slow(tmp.data(), wk, 1e-6f, rows * H, d, tmp2.data());
   to_heads(tmp2.data(), rows, H, d, K, row_off, Ltot);
-  lin_blk(m, lv, x, rows, tmp.data());
+  lin_blk(m, lv, x, rows, tmp.data(), which);
   to_heads(tmp.data(), rows, H, d, V, row_off, Ltot);
   return true;
 }
@@ -923,9 +983,9 @@ static int double_block_one(orc_flux* m, int idx, float* img, float* txt, const 
   std::vector<float> xm((size_t)S * D), tm((size_t)T * D);
   // chunks: shift=0, scale=1, gate=2 | shift=3, scale=4, gate=5  (model.rs:288-297)
   ln_mod(img, imod.data() + 0 * D, imod.data() + 1 * D, S, D, xm.data());
-  if (!qkv(m, p + "attn.", "to_q", "to_k", "to_v", "norm_q", "norm_k", xm.data(), S, T, L, Q.data(), K.data(), V.data())) return -1;
+  if (!qkv(m, p + "attn.", "to_q", "to_k", "to_v", "norm_q", "norm_k", xm.data(), S, T, L, Q.data(), K.data(), V.data(), LIN_DBL_QKV)) return -1;
   ln_mod(txt, tmod.data() + 0 * D, tmod.data() + 1 * D, T, D, tm.data());
-  if (!qkv(m, p + "attn.", "add_q_proj", "add_k_proj", "add_v_proj", "norm_added_q", "norm_added_k", tm.data(), T, 0, L, Q.data(), K.data(), V.data())) return -1;
+  if (!qkv(m, p + "attn.", "add_q_proj", "add_k_proj", "add_v_proj", "norm_added_q", "norm_added_k", tm.data(), T, 0, L, Q.data(), K.data(), V.data(), LIN_DBL_QKV)) return -1;
   // cat([txt, img], seq) is realised by the row offsets above (model.rs:540-542)
   std::vector<float> attn((size_t)L * D);
   float q8 = 0.f, k8 = 0.f;
@@ -942,22 +1002,22 @@ static int double_block_one(orc_flux* m, int idx, float* img, float* txt, const 
   if (!ip.ok() || !tp.ok() || !i1.ok() || !i2.ok() || !t1.ok() || !t2.ok()) return -1;
   {
     std::vector<float> y((size_t)S * D), h((size_t)S * M);
-    lin_blk(m, ip, img_attn, S, y.data());
+    lin_blk(m, ip, img_attn, S, y.data(), LIN_DBL_OUT);
     add_gated(img, imod.data() + 2 * D, y.data(), S, D);  // model.rs:548
     ln_mod(img, imod.data() + 3 * D, imod.data() + 4 * D, S, D, xm.data());
-    lin_blk(m, i1, xm.data(), S, h.data());
+    lin_blk(m, i1, xm.data(), S, h.data(), LIN_DBL_MLP1);
     orc_gelu(h.data(), (int64_t)S * M, h.data());
-    lin_blk(m, i2, h.data(), S, y.data());
+    lin_blk(m, i2, h.data(), S, y.data(), LIN_DBL_MLP2);
     add_gated(img, imod.data() + 5 * D, y.data(), S, D);  // model.rs:549-554
   }
   {
     std::vector<float> y((size_t)T * D), h((size_t)T * M);
-    lin_blk(m, tp, txt_attn, T, y.data());
+    lin_blk(m, tp, txt_attn, T, y.data(), LIN_DBL_OUT);
     add_gated(txt, tmod.data() + 2 * D, y.data(), T, D);  // model.rs:556
     ln_mod(txt, tmod.data() + 3 * D, tmod.data() + 4 * D, T, D, tm.data());
-    lin_blk(m, t1, tm.data(), T, h.data());
+    lin_blk(m, t1, tm.data(), T, h.data(), LIN_DBL_MLP1);
     orc_gelu(h.data(), (int64_t)T * M, h.data());
-    lin_blk(m, t2, h.data(), T, y.data());
+    lin_blk(m, t2, h.data(), T, y.data(), LIN_DBL_MLP2);
     add_gated(txt, tmod.data() + 5 * D, y.data(), T, D);  // model.rs:557-562
   }
   return 0;
@@ -972,11 +1032,11 @@ static int single_block_one(orc_flux* m, int idx, float* x, const float* vec, co
   std::vector<float> xm((size_t)L * D);
   ln_mod(x, mod.data() + 0 * D, mod.data() + 1 * D, L, D, xm.data());
   std::vector<float> Q((size_t)H * L * d), K((size_t)H * L * d), V((size_t)H * L * d);
-  if (!qkv(m, p + "attn.", "to_q", "to_k", "to_v", "norm_q", "norm_k", xm.data(), L, 0, L, Q.data(), K.data(), V.data())) return -1;
+  if (!qkv(m, p + "attn.", "to_q", "to_k", "to_v", "norm_q", "norm_k", xm.data(), L, 0, L, Q.data(), K.data(), V.data(), LIN_SGL_1)) return -1;
   Lin pm = get_lin(m, p + "proj_mlp", D, M), l2 = get_lin(m, p + "proj_out", D + M, D);
   if (!pm.ok() || !l2.ok()) return -1;
   std::vector<float> cat((size_t)L * (D + M)), mlp((size_t)L * M), attn((size_t)L * D);
-  lin_blk(m, pm, xm.data(), L, mlp.data());
+  lin_blk(m, pm, xm.data(), L, mlp.data(), LIN_SGL_1);
   float q8 = 0.f, k8 = 0.f;
   if (m->fp8 && m->fp8_attn) {
     k8 = fp8_attn_scale(m, p + "attn.norm_k", "", d);
@@ -990,7 +1050,7 @@ static int single_block_one(orc_flux* m, int idx, float* x, const float* vec, co
     memcpy(cat.data() + (size_t)l * (D + M) + D, mlp.data() + (size_t)l * M, sizeof(float) * M);
   }
   std::vector<float> y((size_t)L * D);
-  lin_blk(m, l2, cat.data(), L, y.data());
+  lin_blk(m, l2, cat.data(), L, y.data(), LIN_SGL_2);
   add_gated(x, mod.data() + 2 * D, y.data(), L, D);  // xs + mod_.gate(&output)  (model.rs:661)
   return 0;
 }

@@ -52,6 +52,12 @@ def lib():
         _lib.orc_flux_set_fp8.restype = None
         _lib.orc_flux_set_fp8_attention.argtypes = [C.c_void_p, C.c_int]
         _lib.orc_flux_set_fp8_attention.restype = None
+        _lib.orc_flux_set_q8_mask.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_flux_set_q8_mask.restype = None
+        _lib.orc_quantize_rows_i8.argtypes = [f32p, C.c_int, C.c_int, C.c_void_p, f32p]
+        _lib.orc_quantize_rows_i8.restype = None
+        _lib.orc_linear_i8.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p]
+        _lib.orc_linear_i8.restype = None
     return _lib
 
 
@@ -264,6 +270,30 @@ def linear_fp8(x, w, b=None):
     return y + (0 if b is None else np.asarray(b, np.float32)[None, :])
 
 
+def quantize_rows_i8(x):
+    """int8 recipe (no reference counterpart; flux_oracle.cpp: orc_quantize_rows_i8): per-row symmetric codes + f32 scale."""
+    x, xp = _f(x)
+    rows, K = x.shape
+    out = np.empty((rows, K), np.int8)
+    scale = np.empty(rows, np.float32)
+    lib().orc_quantize_rows_i8(xp, rows, K, out.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(f32p))
+    return out, scale
+
+
+def linear_i8(x, w, b=None):
+    """y = float(q(x) q(w)^T as an exact integer) * (sx * sw) + b, both operands on the row-wise int8 recipe (orc_linear_i8)."""
+    x, xp = _f(x)
+    w, wp = _f(w)
+    M, K = x.shape
+    N = w.shape[0]
+    y = np.empty((M, N), np.float32)
+    bp = None
+    if b is not None:
+        b, bp = _f(b)
+    lib().orc_linear_i8(xp, wp, bp, M, N, K, y.ctypes.data_as(f32p))
+    return y
+
+
 def quantize_blockwise_4bit(w, blocksize, quant_type):
     w, wp = _f(w)
     n = w.size
@@ -415,6 +445,18 @@ class Flux:
         quantisers of tools/fp8_noise_study.py (flux_oracle.cpp: lin_blk), never what the library is compared with."""
         lib().orc_flux_set_fp8(self.h, int(study_mode) if (on and study_mode) else int(bool(on)))
         lib().orc_flux_set_fp8_attention(self.h, int(bool(on and attention)))
+
+    def set_int8(self, on=True, mask=0x33):
+        """Block linears of `mask` on the int8 recipe (lin_blk mode 5: exact integer sums; parity unpinned, no reference counterpart),
+        the others in f32.  0x33 = the library's default mask (all but the double blocks' MLP)."""
+        lib().orc_flux_set_fp8(self.h, 5 if on else 0)
+        lib().orc_flux_set_fp8_attention(self.h, 0)
+        lib().orc_flux_set_q8_mask(self.h, int(mask) if on else 0x3f)
+
+    def set_q8_mask(self, mask=0x3f):
+        """Which block linears take the 8-bit recipe while set_fp8 is on (the others stay f32): bit 0 double q|k|v, 1 double attention
+        out, 2 double MLP in, 3 double MLP out, 4 single linear1 (q, k, v, proj_mlp), 5 single linear2."""
+        lib().orc_flux_set_q8_mask(self.h, int(mask))
 
     def forward(self, img, img_ids, txt, txt_ids, timesteps, y, guidance=None):
         img, a = _f(img)

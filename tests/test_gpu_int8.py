@@ -1,0 +1,239 @@
+"""int8 mode (fmi_flux_quantize_int8, round 4) through the C-ABI vs the oracle's restatement of the same recipe.
+
+Like the fp8 mode this recipe is the library's own (the reference has no 8-bit MFMA path), restated in
+oracle/flux_oracle.cpp (orc_quantize_rows_i8, orc_linear_i8, lin_blk mode 5).  Why it exists: tools/fp8_noise_study.py — an e4m3
+operand is 2.65e-2 rms from its value whatever the scale granularity, a per-row int8 one 8.5e-3, at the same matrix-pipe rate.
+
+Bars: quantisation bit-exact (codes and scales); the int8 MFMA's k map pinned by an EXACT integer GEMM (unit scales, sums below 256:
+every output is an integer that bf16 holds); int8 GEMM vs the oracle on the same codes rel-L2 <= 2e-3 (bf16 output rounding only —
+the sums are exact integers on both sides); model evaluation vs the int8 oracle <= 1e-2 (the bf16 path's bar), vs the f32 oracle
+<= 2e-2 on the small synthetic model; latents after the Euler loop <= 3e-2.  The full-size bar (<= 3e-2 from f32 with the default
+mask, FLUX.1-dev in full) is tests/test_gpu_production_shapes.py's.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import SMALL_FLUX, bf16_round, dev, flux_inputs, host, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import diffusion_rs_amd as d
+    from diffusion_rs_amd import _lib as L
+    from oracle import oracle as orc
+    return dict(torch=torch, d=d, L=L, lib=L.load(), orc=orc)
+
+
+def gpu_quantize(env, x_bf16):
+    torch, L, lib = env["torch"], env["L"], env["lib"]
+    rows, K = x_bf16.shape
+    q = torch.empty(rows, K, dtype=torch.int8, device="cuda")
+    s = torch.empty(rows, dtype=torch.float32, device="cuda")
+    L.check(lib.fmi_quantize_rows_i8(_p(x_bf16), rows, K, _p(q), _p(s), None))
+    torch.cuda.synchronize()
+    return q, s
+
+
+@pytest.mark.parametrize("rows,K", [(1, 8), (5, 136), (33, 3072), (7, 15360), (300, 256), (2, 16384)])
+def test_quantize_rows_i8_bit_exact(env, rows, K):
+    torch, orc = env["torch"], env["orc"]
+    rng = np.random.default_rng(rows * 131 + K)
+    x = rng.standard_normal((rows, K)).astype(np.float32) * (10.0 ** rng.uniform(-3, 3, (rows, 1))).astype(np.float32)
+    if rows > 2:
+        x[1] = 0            # an all-zero token: scale 1e-30 / 127, codes 0
+        x[2, ::3] *= 1e-4   # values far below the row maximum round to 0
+    if rows > 4:            # exact ties of the rounding: x * (127 / absmax) = n + 0.5 -> round half to even
+        x[4, :] = 0
+        x[4, 0] = 127.0
+        x[4, 1:8] = [0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 126.5]
+    x = bf16_round(x)
+    q, s = gpu_quantize(env, dev(x, torch.bfloat16))
+    rq, rs = orc.quantize_rows_i8(x)
+    np.testing.assert_array_equal(s.cpu().numpy(), rs)
+    np.testing.assert_array_equal(q.cpu().numpy(), rq)
+    assert int(np.abs(rq.astype(np.int32)).max()) <= 127
+    if rows > 4:
+        assert rq[4, :8].tolist() == [127, 0, 2, 2, 0, -2, -2, 126]
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 256, 128), (300, 384, 1280), (257, 1024, 15360), (4608, 512, 3072)])
+def test_int8_gemm_is_an_exact_integer_gemm(env, M, N, K):
+    """Unit scales (every row of x and of w holds one +-127 at a position where the other operand is 0) and sums below 256: the output is
+    the integer sum over k itself, exactly, in bf16.  Any error in which k a (lane, byte) of the MFMA operands carries — A and W must
+    agree — or in the tile / K-tile walk shows as a wrong integer."""
+    torch, L, lib = env["torch"], env["L"], env["lib"]
+    rng = np.random.default_rng(M + N + K)
+    x = np.zeros((M, K), np.float32)
+    w = rng.integers(-1, 2, (N, K)).astype(np.float32) * rng.integers(1, 4, (N, K)).astype(np.float32)  # dense, values in -3..3
+    for r in range(M):  # up to 80 non-zeros of +-1 per row of x: |sum| <= 240
+        idx = rng.choice(np.arange(2, K), size=min(80, K - 2), replace=False)
+        x[r, idx] = rng.choice([-1.0, 1.0], size=idx.size)
+    x[:, 0], x[:, 1] = 127.0, 0.0
+    w[:, 0], w[:, 1] = 0.0, 127.0 * rng.choice([-1.0, 1.0], size=N)
+    xd, wd = dev(x, torch.bfloat16), dev(w, torch.bfloat16)
+    wq, ws = gpu_quantize(env, wd)
+    assert torch.equal(ws, torch.ones_like(ws)) and torch.equal(wq.float().cpu(), torch.from_numpy(w))
+    y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.fmi_linear_i8(_p(xd), _p(wq), _p(ws), None, _p(y), M, N, K, 0, None))
+    torch.cuda.synchronize()
+    ref = x.astype(np.float64) @ w.astype(np.float64).T
+    assert np.abs(ref).max() <= 256
+    np.testing.assert_array_equal(host(y).astype(np.float64), ref)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(64, 256, 128, 0), (300, 384, 256, 0), (257, 1024, 1280, 1), (1000, 260, 384, 0), (16, 3072, 1024, 0), (130, 512, 15360, 0)])
+def test_linear_i8_matches_oracle(env, M, N, K, epi):
+    torch, L, lib, orc = env["torch"], env["L"], env["lib"], env["orc"]
+    rng = np.random.default_rng(M + N + K)
+    x = bf16_round(rng.standard_normal((M, K)).astype(np.float32) * (1 + 10 * (rng.random((M, 1)) < 0.1)).astype(np.float32))
+    w = bf16_round((rng.standard_normal((N, K)) * 0.05).astype(np.float32))
+    b = bf16_round(rng.standard_normal(N).astype(np.float32))
+    xd, wd, bd = dev(x, torch.bfloat16), dev(w, torch.bfloat16), dev(b, torch.bfloat16)
+    wq, ws = gpu_quantize(env, wd)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.fmi_linear_i8(_p(xd), _p(wq), _p(ws), _p(bd), _p(y), M, N, K, epi, None))
+    torch.cuda.synchronize()
+    ref = orc.linear_i8(x, w, b)
+    f32 = orc.linear(x, w, b)
+    if epi == 1:
+        ref, f32 = orc.gelu(ref), orc.gelu(f32)
+    err, noise = rel_l2(host(y), ref), rel_l2(ref, f32)
+    # beyond the norm: element by element the two differ by bf16 rounding of the same f32 value (+ one ulp of f32 where the GPU contracts
+    # the scale and bias into a fused multiply-add)
+    close = np.abs(host(y) - ref) <= np.abs(ref) * 2.0 ** -8 + 1e-6 * np.abs(ref).max() if epi == 0 else None
+    print(f"linear_i8 {M}x{N}x{K} epi={epi}: rel-L2 vs int8 oracle {err:.2e}; int8 recipe vs f32 linear {noise:.2e}")
+    assert err <= 2e-3
+    assert close is None or bool(close.all())
+    assert noise <= 2.5e-2  # (the e4m3 recipe on the same operands: 3.7e-2 and up)
+
+
+def test_linear_i8_rejects_bad_shapes(env):
+    torch, lib = env["torch"], env["lib"]
+    x = torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda")
+    q = torch.zeros(256, 256, dtype=torch.int8, device="cuda")
+    s = torch.ones(256, dtype=torch.float32, device="cuda")
+    y = torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda")
+    assert lib.fmi_linear_i8(_p(x), _p(q), _p(s), None, _p(y), 64, 128, 256, 0, None) < 0   # N <= 128: no 8-bit tile shape
+    assert lib.fmi_linear_i8(_p(x), _p(q), _p(s), None, _p(y), 64, 256, 192, 0, None) < 0   # K % 128
+    assert lib.fmi_linear_i8(_p(x), _p(q), None, None, _p(y), 64, 256, 256, 0, None) < 0
+    assert lib.fmi_linear_i8(_p(x), _p(q), _p(s), None, _p(y), 0, 256, 256, 0, None) == 0
+    assert lib.fmi_quantize_rows_i8(_p(x), 4, 12, _p(q), _p(s), None) < 0                    # K % 8
+
+
+MASKS = [0x33, 0x3f, 0x15, 0x0c]  # the default, every block linear, the LayerNorm-fed ones, the double blocks' MLP alone
+
+
+@pytest.fixture(scope="module")
+def models(env):
+    d, orc = env["d"], env["orc"]
+    sd = d.synth.flux_state_dict_numpy(SMALL_FLUX, seed=0)
+    out = dict(sd=sd)
+    for mask in MASKS:
+        g = d.FluxModel(SMALL_FLUX)
+        g.load_state_dict(sd)
+        g.quantize_int8(mask)
+        out[mask] = g
+    out["gb"] = d.FluxModel(SMALL_FLUX)
+    out["gb"].load_state_dict(sd)
+    out["o8"] = orc.Flux(SMALL_FLUX)
+    out["o8"].load(sd)
+    out["of"] = orc.Flux(SMALL_FLUX)
+    out["of"].load(sd)
+    return out
+
+
+@pytest.mark.parametrize("mask", MASKS)
+@pytest.mark.parametrize("B,S_hw,T", [(1, (8, 12), 40), (2, (6, 6), 64), (1, (16, 16), 77), (2, (8, 16), 48)])
+def test_flux_forward_int8_matches_int8_oracle(env, models, B, S_hw, T, mask):
+    torch = env["torch"]
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, B, S_hw, T)
+    t = np.linspace(0.9, 0.4, B).astype(np.float32)
+    g = np.full(B, 3.5, np.float32)
+    args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
+    got = host(models[mask].forward(*args))
+    models["o8"].set_int8(True, mask)
+    ref8 = models["o8"].forward(img, ids, txt, txt_ids, t, y, g)
+    models["o8"].set_int8(False)
+    ref = models["of"].forward(img, ids, txt, txt_ids, t, y, g)
+    gotb = host(models["gb"].forward(*args))
+    assert np.isfinite(got).all()
+    e8, ef, eb = rel_l2(got, ref8), rel_l2(got, ref), rel_l2(gotb, ref)
+    print(f"int8 forward mask 0x{mask:02x} B={B} S={S_hw} T={T}: vs int8 oracle {e8:.3e}; vs f32 oracle {ef:.3e} (bf16 path: {eb:.3e}); oracle int8 vs f32 {rel_l2(ref8, ref):.3e}")
+    assert e8 <= 1e-2   # the bf16 path's bar against its oracle
+    assert ef <= 2e-2
+    assert not np.array_equal(got, gotb)  # the mode is on
+
+
+def test_flux_denoise_int8(env, models):
+    torch, d = env["torch"], env["d"]
+    B, S_hw, T, steps = 1, (8, 8), 32, 4
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, B, S_hw, T, seed=7)
+    g = np.full(B, 3.5, np.float32)
+    sched = d.SchedulerConfig()
+    ts = sched.get_timesteps(steps, sched.calculate_shift(S_hw[0] * S_hw[1]))
+    models["o8"].set_int8(True, 0x33)
+    ref8 = models["o8"].denoise(img, ids, txt, txt_ids, y, g, ts)
+    models["o8"].set_int8(False)
+    args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(y), dev(g), ts)
+    got = host(models[0x33].denoise(*args))
+    again = host(models[0x33].denoise(*args))
+    np.testing.assert_array_equal(got, again)   # deterministic
+    err = rel_l2(got, ref8)
+    print(f"int8 denoise {steps} steps: rel-L2 vs int8 oracle {err:.3e}")
+    assert err <= 3e-2
+
+
+def test_int8_mode_guards(env, models):
+    d = env["d"]
+    sd = models["sd"]
+    m = d.FluxModel(SMALL_FLUX)
+    with pytest.raises(d.FmiError):
+        m.quantize_int8()             # tensors missing
+    m.load_state_dict(sd)
+    with pytest.raises(d.FmiError):
+        m.quantize_int8(0)            # no linear named
+    with pytest.raises(d.FmiError):
+        m.quantize_int8(0x40)         # a bit that names nothing
+    m.quantize_int8()
+    m.quantize_int8(d.flux.INT8_DEFAULT_MASK)   # idempotent for the same mask
+    with pytest.raises(d.FmiError):
+        m.quantize_int8(0x3f)         # another mask: the codes are already chosen
+    with pytest.raises(d.FmiError):
+        m.quantize_fp8()              # one 8-bit form per handle
+    name = "transformer_blocks.0.attn.to_q.weight"
+    with pytest.raises(d.FmiError):
+        m.set_tensor(name, sd[name])  # weights are frozen once quantised
+    m.close()
+    m = d.FluxModel(SMALL_FLUX)
+    m.load_state_dict(sd)
+    m.quantize_fp8()
+    with pytest.raises(d.FmiError):
+        m.quantize_int8()
+    m.close()
+
+
+def test_pipeline_int8_end_to_end(env):
+    """ModelDType.I8 through the Pipeline: prompts -> u8 images, deterministic, close to the bf16 pipeline's."""
+    torch, d = env["torch"], env["d"]
+    from tests.util import SMALL_VAE
+    cfg = dict(SMALL_FLUX)
+    params = d.DiffusionGenerationParams(height=128, width=128, num_steps=3, guidance_scale=3.5)
+    p8 = d.Pipeline.load(d.ModelSource.Synthetic("dev", seed=4, flux_cfg=cfg, vae_cfg=SMALL_VAE), dtype=d.ModelDType.I8)
+    pb = d.Pipeline.load(d.ModelSource.Synthetic("dev", seed=4, flux_cfg=cfg, vae_cfg=SMALL_VAE))
+    a = p8.generate_tensor(["a red fox"], params, seed=9).cpu().numpy()
+    again = p8.generate_tensor(["a red fox"], params, seed=9).cpu().numpy()
+    b = pb.generate_tensor(["a red fox"], params, seed=9).cpu().numpy()
+    np.testing.assert_array_equal(a, again)
+    assert a.dtype == np.uint8 and a.shape == b.shape
+    diff = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    print(f"int8 pipeline vs bf16 pipeline: max |du8| {int(diff.max())}, mean {float(diff.mean()):.3f}, differing {float((diff > 0).mean()):.3f}")
+    assert float((diff <= 8).mean()) >= 0.99

@@ -243,6 +243,7 @@ def test_c2_dev_1024_forward_and_two_step_trajectory_of_the_full_model_match_ora
     err = rel_l2(got, ref)
     print(f"C2 in full (FLUX.1-dev, D=3072, 19+38 blocks, S=4096 + T=512 tokens), one Flux::forward: rel-L2 {err:.3e} (oracle {t_or:.0f} s)")
     assert np.isfinite(got).all() and err <= 2e-2
+    full_models["c2"] = (img, ids, t5, txt_ids, t, clip, g, ref)  # the int8 test below measures its mode on this very forward
     # --- and the TRAJECTORY: two Euler steps of the 50-step schedule at full size against the oracle's, with the
     # modulation of both steps computed as ONE GEMM over the 6.5 GB (344 D x D) matrix — the path every 50-step run takes and the one
     # that carried the silent > 4 GiB offset wrap of round 3 — forced at 2 rows by fmi_flux_set_modulation_gemm(2); until now that
@@ -391,6 +392,68 @@ def test_c3_nf4_full_model_forward_matches_oracle_on_dequantised_weights(full_mo
     print(f"C3 with the full model ({nq} nf4 Linears, {resident:.1f} GiB resident), one Flux::forward at S=1024 + T=256: rel-L2 {err:.3e} (oracle {time.time() - t0:.0f} s)")
     assert np.isfinite(got).all() and err <= 2e-2
     del oq
+
+
+def test_c2_int8_full_model_forward_is_within_the_8_bit_tolerance(full_models):
+    """The int8 mode (fmi_flux_quantize_int8, default mask: every block linear but the double blocks' MLP; round 4) with the FULL model at the
+    HEADLINE size — FLUX.1-dev, 19 + 38 blocks, S = 4096 + T = 512 tokens, one `Flux::forward` — against the f32 oracle: rel-L2 <= 3e-2, the bar
+    VERDICT r3 set for an 8-bit mode (the e4m3 mode on the same weights: 1.0e-1; the bf16 path: 4.6e-3).  Then, at 384 + 128 tokens (where the
+    oracle's second pass is affordable: it quantises 12e9 weights), against the oracle's restatement of the same recipe with the same mask:
+    closer to it than the recipe is to f32.  The recipe is this library's own (parity unpinned by the reference).  A third GPU handle: the dev
+    handle must stay bf16 for the fp8 test that runs last."""
+    if not full_models["wide"]:
+        pytest.skip("the host cannot hold the oracle's 48 GB of f32 weights (+ 48 GB of int8 codes as floats)")
+    torch, d, orc, om = (full_models[k] for k in ("torch", "d", "orc", "om"))
+    cfg = dict(d.FLUX_DEV)
+    t0 = time.time()
+    g8 = d.FluxModel(cfg)
+    for name, shape in d.synth.flux_tensor_shapes(d.FLUX_DEV).items():
+        g8.set_tensor(name, _seeded_weight(torch, name, shape, d))
+    g8.assert_complete()
+    g8.quantize_int8()
+    t_load = time.time() - t0
+    try:
+        if "c2" in full_models:
+            img, ids, t5, txt_ids, t, clip, g, ref = full_models["c2"]
+        else:  # run alone: the headline forward of the oracle (80 s)
+            rng = np.random.default_rng(79)
+            lat = rng.standard_normal((1, 16, 128, 128)).astype(np.float32)
+            t5 = bf16_round(rng.standard_normal((1, 512, cfg["joint_attention_dim"])).astype(np.float32))
+            clip = rng.standard_normal((1, cfg["pooled_projection_dim"])).astype(np.float32)
+            img, ids = orc.pack_latents(lat)
+            txt_ids = np.zeros((1, 512, 3), np.float32)
+            g = np.array([3.5], np.float32)
+            sched = d.SchedulerConfig()
+            t = np.array([float(sched.get_timesteps(50, sched.calculate_shift(4096))[0])], np.float32)
+            ref = om.forward(img, ids, t5, txt_ids, t, clip, g)
+        got = host(g8.forward(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(t), dev(clip), dev(g)))
+        err = rel_l2(got, ref)
+        print(f"C2 in full in int8 mode (default mask 0x{d.flux.INT8_DEFAULT_MASK:02x}), one Flux::forward at S=4096 + T=512: rel-L2 vs the f32 oracle {err:.3e} "
+              f"(third handle loaded and quantised in {t_load:.0f} s)")
+        assert np.isfinite(got).all() and err <= 3e-2
+        # --- the GPU implements the STATED recipe: the oracle with the same mask, at a token count its weight quantisation dominates
+        rng = np.random.default_rng(83)
+        lat = rng.standard_normal((1, 16, 32, 48)).astype(np.float32)  # 16 x 24 = 384 tokens
+        t5s = bf16_round(rng.standard_normal((1, 128, cfg["joint_attention_dim"])).astype(np.float32))
+        clips = rng.standard_normal((1, cfg["pooled_projection_dim"])).astype(np.float32)
+        imgs, idss = orc.pack_latents(lat)
+        txts = np.zeros((1, 128, 3), np.float32)
+        ts, gs = np.array([0.6], np.float32), np.array([3.5], np.float32)
+        t0 = time.time()
+        reff = om.forward(imgs, idss, t5s, txts, ts, clips, gs)
+        om.set_int8(True, d.flux.INT8_DEFAULT_MASK)
+        try:
+            ref8 = om.forward(imgs, idss, t5s, txts, ts, clips, gs)
+        finally:
+            om.set_int8(False)
+        got8 = host(g8.forward(dev(imgs), dev(idss), dev(t5s, torch.bfloat16), dev(txts), dev(ts), dev(clips), dev(gs)))
+        e8, ef, noise = rel_l2(got8, ref8), rel_l2(got8, reff), rel_l2(ref8, reff)
+        print(f"the same at S=384 + T=128: vs the int8 oracle {e8:.3e}, vs the f32 oracle {ef:.3e} (recipe noise {noise:.3e}; oracle {time.time() - t0:.0f} s)")
+        # (the codes are chaotic in the inputs — bf16 intermediates move activations across rounding boundaries — so, as for the fp8 mode, the bar against
+        # the recipe's oracle is the recipe's own noise: measured 2.1e-2 against 2.2e-2)
+        assert np.isfinite(got8).all() and ef <= 3e-2 and e8 <= 1.25 * noise
+    finally:
+        g8.close()
 
 
 def test_c5_fp8_full_model_forward_against_the_fp8_recipe(full_models):

@@ -93,7 +93,7 @@ def test_api_mirror_objects():
     with pytest.raises(ValueError):
         d.ModelSource.DdufFile("a.dduf").override_transformer_model_id("x")
     assert [m.name for m in d.ModelDType][:4] == ["Auto", "BF16", "F16", "F32"]  # the reference's four (lib.rs:37-44) ...
-    assert [m.name for m in d.ModelDType][4:] == ["F8E4M3"]                      # ... plus this build's fp8 extension
+    assert [m.name for m in d.ModelDType][4:] == ["F8E4M3", "I8"]                # ... plus this build's two 8-bit extensions
     assert d.Offloading.Full.name == "Full"
 
 

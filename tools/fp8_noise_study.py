@@ -91,6 +91,24 @@ def model_table(n_double, n_single, S_hw, T):
         out = om.forward(img, ids, txt, txt_ids, t, y, g)
         print(f"  mode {mode}  {name:48s} {rel_l2(out, ref):.3e}", flush=True)
     om.set_fp8(False)
+    return om, (img, ids, txt, txt_ids, t, y, g), ref
+
+
+MASK_BITS = ["double q|k|v", "double attention out", "double MLP in", "double MLP out", "single linear1", "single linear2"]
+
+
+def mask_table(om, inputs, ref, masks, mode=5):
+    """The int8 recipe (mode 5) on a SUBSET of the block linears (orc_flux_set_q8_mask): which linears carry the error?"""
+    img, ids, txt, txt_ids, t, y, g = inputs
+    om.set_fp8(True, study_mode=mode)
+    print(f"int8 per row (W and A) on a subset of the block linears; rel-L2 vs f32:")
+    for mask in masks:
+        om.set_q8_mask(mask)
+        out = om.forward(img, ids, txt, txt_ids, t, y, g)
+        names = ", ".join(n for i, n in enumerate(MASK_BITS) if mask >> i & 1)
+        print(f"  mask 0x{mask:02x}  {rel_l2(out, ref):.3e}   {names}", flush=True)
+    om.set_q8_mask(0x3f)
+    om.set_fp8(False)
 
 
 if __name__ == "__main__":
@@ -100,8 +118,15 @@ if __name__ == "__main__":
     ap.add_argument("--tokens", default="12x16")
     ap.add_argument("--txt", type=int, default=64)
     ap.add_argument("--skip-model", action="store_true")
+    ap.add_argument("--masks", default="", help="comma-separated hex masks of block linears for the int8 subset table, e.g. 3f,15,2a")
+    ap.add_argument("--only-masks", action="store_true")
     a = ap.parse_args()
-    one_gemm_table()
+    if not a.only_masks:
+        one_gemm_table()
     if not a.skip_model:
         h, w = (int(v) for v in a.tokens.split("x"))
-        model_table(a.double, a.single, (h, w), a.txt)
+        if a.only_masks:
+            del MODES[:]
+        om, inputs, ref = model_table(a.double, a.single, (h, w), a.txt)
+        if a.masks:
+            mask_table(om, inputs, ref, [int(v, 16) for v in a.masks.split(",")])
