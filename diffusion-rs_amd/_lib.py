@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflux_mi355x.so")
+# FMI_LIB = another build of the same library (A/B of two builds on one box: tools/ab_toggle.py, DESIGN's "alternating processes"); default: in-tree
+LIB_PATH = os.environ.get("FMI_LIB") or os.path.join(_HERE, "libflux_mi355x.so")
 
 
 class FmiError(RuntimeError):

@@ -1025,17 +1025,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
     slot_barrier();
     // ---- COMPUTE(t): the matrix pipe only
     if constexpr (I8) {
+      // two instructions per 32-byte fragment pair, the halves in separate sweeps over the 8 accumulators (no instruction follows one on its own accumulator)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            acci[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_shufflevector(wq[s][j], wq[s][j], 0, 1, 2, 3),
-                                                               __builtin_shufflevector(xq[s][i], xq[s][i], 0, 1, 2, 3), acci[i][j], 0, 0, 0);
-            acci[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_shufflevector(wq[s][j], wq[s][j], 4, 5, 6, 7),
-                                                               __builtin_shufflevector(xq[s][i], xq[s][i], 4, 5, 6, 7), acci[i][j], 0, 0, 0);
-          }
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acci[i][j] = h == 0 ? __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_shufflevector(wq[s][j], wq[s][j], 0, 1, 2, 3),
+                                                                         __builtin_shufflevector(xq[s][i], xq[s][i], 0, 1, 2, 3), acci[i][j], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_shufflevector(wq[s][j], wq[s][j], 4, 5, 6, 7),
+                                                                         __builtin_shufflevector(xq[s][i], xq[s][i], 4, 5, 6, 7), acci[i][j], 0, 0, 0);
     } else if constexpr (FP8) {
 #pragma unroll
       for (int s = 0; s < 2; ++s)
