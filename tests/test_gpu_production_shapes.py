@@ -268,6 +268,7 @@ def test_c2_dev_1024_forward_and_two_step_trajectory_of_the_full_model_match_ora
     print(f"C2 in full, 2 Euler steps of the 50-step schedule with the one-GEMM modulation path forced: latents rel-L2 {e2:.3e} "
           f"(the two steps moved them by {moved:.3e}; update alone: {rel_l2(got2 - img, ref2 - img):.3e}; modulation phase {mod_ms} ms; oracle {t_or2:.0f} s)")
     assert np.isfinite(got2).all() and e2 <= 3e-2
+    full_models["c2_traj"] = (ts3, ref2)
     # the latents barely move in 2 of 50 steps, so the bar that means something is on the UPDATE (sum of pred * dt): the per-forward one
     assert rel_l2(got2 - img, ref2 - img) <= 2e-2
 
@@ -431,6 +432,12 @@ def test_c2_int8_full_model_forward_is_within_the_8_bit_tolerance(full_models):
         print(f"C2 in full in int8 mode (default mask 0x{d.flux.INT8_DEFAULT_MASK:02x}), one Flux::forward at S=4096 + T=512: rel-L2 vs the f32 oracle {err:.3e} "
               f"(third handle loaded and quantised in {t_load:.0f} s)")
         assert np.isfinite(got).all() and err <= 3e-2
+        if "c2_traj" in full_models:  # two Euler steps of the 50-step schedule in int8 mode against the f32 oracle's two steps (computed by the C2 test above)
+            ts3, ref2 = full_models["c2_traj"]
+            got2 = host(g8.denoise(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(clip), dev(g), ts3))
+            e2, eu = rel_l2(got2, ref2), rel_l2(got2 - img, ref2 - img)
+            print(f"  2 Euler steps in int8 mode vs the f32 oracle's: latents {e2:.3e}, update alone {eu:.3e}")
+            assert np.isfinite(got2).all() and e2 <= 3e-2 and eu <= 3e-2
         # --- the GPU implements the STATED recipe: the oracle with the same mask, at a token count its weight quantisation dominates
         rng = np.random.default_rng(83)
         lat = rng.standard_normal((1, 16, 32, 48)).astype(np.float32)  # 16 x 24 = 384 tokens

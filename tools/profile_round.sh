@@ -24,7 +24,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 # traffic per block-linear launch of this mode -> profiles/pmc_summary_<mode>.json (bench.py reads it: roofline.traffic of the line / of the leg)
 MODE=latest
-case "$BENCH_ARGS" in *"--quant nf4"*) MODE=nf4 ;; *"--quant fp8"*) MODE=fp8 ;; esac
+case "$BENCH_ARGS" in *"--quant nf4"*) MODE=nf4 ;; *"--quant fp8"*) MODE=fp8 ;; *"--quant int8"*) MODE=int8 ;; esac
 python tools/pmc_summary.py "$TAG" "$OUT/${TAG}_pmc_fetch_size.txt" "$OUT/${TAG}_pmc_write_size.txt" "$PMC_STEPS" "" $MODE > /dev/null; cp profiles/pmc_summary_$MODE.json "$OUT/pmc_summary_$MODE.json"
 tail -1 "$OUT/bench_under_rocprof.json" > "$OUT/${TAG}_bench_under_rocprof.json"
 head -12 "$OUT/${TAG}_kernel_stats.txt"
