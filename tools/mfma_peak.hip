@@ -160,6 +160,57 @@ __global__ __launch_bounds__(256, 1) void mfma_tile_fp8(const uint4* in, float* 
   out[(size_t)blockIdx.x * blockDim.x + tid] = s;
 }
 
+// int8 forms (the int8 mode's GEMM, round 4): 32x32x32 (two per 32-byte fragment pair, as gemm_pp_kernel<2> issues them) vs 16x16x64, 128 x 128 wave tile
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+template <int SHAPE>  // 32 or 16
+__global__ __launch_bounds__(256, 1) void mfma_tile_i8(const uint4* in, float* out, int iters) {
+  const int tid = threadIdx.x;
+  constexpr int NT = SHAPE == 32 ? 4 : 8;
+  i32x4 a[NT][2], b[NT][2];
+  for (int i = 0; i < NT; ++i)
+    for (int h = 0; h < 2; ++h) {
+      const uint4 x = in[(tid + 64 * i + 128 * h) & 1023], y = in[(tid + 64 * i + 512 + 32 * h) & 1023];
+      a[i][h] = i32x4{(int)x.x, (int)x.y, (int)x.z, (int)x.w};  // all 256 codes occur (the bf16 bit patterns of main() as bytes)
+      b[i][h] = i32x4{(int)y.w, (int)y.x, (int)y.y, (int)y.z};
+    }
+  int s = 0;
+  if constexpr (SHAPE == 32) {
+    i32x16 acc[NT][NT];
+    for (int i = 0; i < NT; ++i)
+      for (int j = 0; j < NT; ++j)
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[j][h], a[i][h], acc[i][j], 0, 0, 0);
+      asm volatile("" : "+v"(a[0][0]));
+    }
+    for (int i = 0; i < NT; ++i)
+      for (int j = 0; j < NT; ++j) s += acc[i][j][0] + acc[i][j][7];
+  } else {
+    i32x4 acc[NT][NT];
+    for (int i = 0; i < NT; ++i)
+      for (int j = 0; j < NT; ++j)
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b[j][h], a[i][h], acc[i][j], 0, 0, 0);
+      asm volatile("" : "+v"(a[0][0]));
+    }
+    for (int i = 0; i < NT; ++i)
+      for (int j = 0; j < NT; ++j) s += acc[i][j][0] + acc[i][j][3];
+  }
+  out[(size_t)blockIdx.x * blockDim.x + tid] = (float)s;
+}
+
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 20000;
   uint4* in;
@@ -219,6 +270,8 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < 2; ++rep) {
     run2(mfma_tile_fp8<32>, "fp8: 4x4 tile of 32x32x64 f8f6f4, 1 w/SIMD", 16 * 2.0 * 32 * 32 * 64, iters * 5);
     run2(mfma_tile_fp8<16>, "fp8: 8x8 tile of 16x16x128 f8f6f4, 1 w/SIMD", 64 * 2.0 * 16 * 16 * 128, iters * 5);
+    run2(mfma_tile_i8<32>, "int8: 4x4 tile of 2 x 32x32x32 i8, 1 w/SIMD", 32 * 2.0 * 32 * 32 * 32, iters * 5);
+    run2(mfma_tile_i8<16>, "int8: 8x8 tile of 2 x 16x16x64 i8, 1 w/SIMD", 128 * 2.0 * 16 * 16 * 64, iters * 5);
   }
   return 0;
 }
