@@ -474,8 +474,8 @@ def main():
             torch.cuda.synchronize()
             el = time.perf_counter() - t1
             traffic = tnote = None
-            mode = "nf4" if name.startswith("nf4") else "int8" if name.startswith("int8") else "fp8"
-            if (wk.H, wk.W, wk.B) == (1024, 1024, 1):  # the PMC passes are taken at the headline shape
+            mode = name.split("_")[0]  # nf4 / int8 / fp8: the legs that have PMC passes of their own under profiles/
+            if (wk.H, wk.W, wk.B) == (1024, 1024, 1) and mode in ("nf4", "int8", "fp8"):  # the PMC passes are taken at the headline shape
                 try:
                     with open(os.path.join(ROOT, "profiles", f"pmc_summary_{mode}.json")) as f:
                         pm = json.load(f)
@@ -500,6 +500,11 @@ def main():
         sp["split_k_latency_mode"] = fdist.sequence_parallel_rank_time(flux, 8, ts10, dev)
         flux.set_split_k(False)
         secondary["sequence_parallel_rank"] = sp
+        # opt-in (fmi_flux_set_fp8_attention(m, 2)): the bf16 model with q and k handed to the attention as e4m3 (static scales), QK^T on the fp8 MFMA in the
+        # lock-step stream — a reduced-precision attention operand, so never the headline; the leg says what it is worth
+        flux.set_fp8_attention(2)
+        leg(flux, wl, "bf16_e4m3qk_1024", KDESC["none"], 2500.0, "bf16 block linears and P.V; q, k of the attention as e4m3 with static per-block scales (opt-in)")
+        flux.set_fp8_attention(1)
         fq = d.FluxModel(d.FLUX_DEV, local_rank)
         fill_flux(fq, "nf4")
         # default policy (flux_model.hip: densify): only the packed codes are resident; the block linears (launches above 383 rows) expand per call

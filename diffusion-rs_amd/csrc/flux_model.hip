@@ -165,10 +165,12 @@ struct fmi_flux {
   size_t fp8_bytes = 0;
   // fp8 attention operands (QK^T on the fp8 MFMA): static scales per block, 448 / (sqrt(128) * max|norm weight|) — a
   // QkNorm'ed, rotated head vector has norm sqrt(128) * |w|, so no element can exceed the e4m3 range
-  bool fp8_attn = true;
+  int fp8_attn = 1;  // 0 off, 1 on in the 8-bit modes, 2 on in bf16 mode too (fmi_flux_set_fp8_attention)
   std::vector<float> q8_dbl, k8_dbl, q8_sgl, k8_sgl;
   std::vector<int> n8_dbl, n8_sgl;  // fp8 attention: softmax_scale * log2(e) / (q8 * k8) == 2^-n8 EXACTLY (q_scale_pow2); handed to the attention as an integer
 };
+
+static int compute_attention_scales(fmi_flux* m);  // (defined with the 8-bit modes below)
 
 namespace {
 
@@ -803,6 +805,8 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
   // sequence parallel: S, T (and the ids) are this rank's shard; only the attention sees the other ranks (attention_sp)
   const bool sp = m->sp_world > 1 && m->sp_a2a;
   if (sp && (B != 1 || fp8)) return fail(FMI_ERR_UNSUPPORTED, "flux: sequence parallelism runs one image (B = 1) in bf16 mode");
+  if (m->fp8_attn == 2 && !sp && m->q8_dbl.empty()) FMI_TRY(compute_attention_scales(m));
+  const bool qk8_any = m->fp8_attn == 2 && !sp;  // opt-in: e4m3 q, k in front of QK^T whatever the block linears run on
   const int BT = B * T;  // a8 / a8s rows: [txt (B*T) | img (B*S)]
 
   {
@@ -857,7 +861,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
                    : make_problem(bw.qkv[1], xm_txt, D, B * T, w.qkv_txt, 3 * D, EPI_STORE_BF16);
       // joint order [txt, img] (model.rs:540-542): txt tokens at positions [0,T), img at [T,T+S)
       // fp8 attention operands only when BOTH streams take the fused epilogue (the stand-alone kernels write bf16)
-      qk8 = q_qkv && qk == 1 && m->fp8_attn && can_fuse_relayout(m, B * S, S, T) && can_fuse_relayout(m, B * T, T, 0);
+      qk8 = ((q_qkv && m->fp8_attn) || (qk8_any && !bw.qkv[0].q_type && !bw.qkv[1].q_type)) && can_fuse_relayout(m, B * S, S, T) && can_fuse_relayout(m, B * T, T, 0);  // (either 8-bit mode; opt-in: any)
       const float q8 = qk8 ? m->q8_dbl[i] : 0.f, k8 = qk8 ? m->k8_dbl[i] : 0.f;
       fused_img = with_qkv_relayout(m, p[0], bw.nq[0], bw.nk[0], pe_bs, S, T, L, q8, k8);
       fused_txt = with_qkv_relayout(m, p[1], bw.nq[1], bw.nk[1], pe_bs, T, 0, L, q8, k8);
@@ -973,7 +977,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     const float* mo = mod + bw.mod_off;  // shift, scale, gate
     bool fused = false;
     const bool q_w1 = fp8 && bw.w1.w8, q_w2 = fp8 && bw.w2.w8;
-    const bool qk8 = q_w1 && qk == 1 && m->fp8_attn && can_fuse_relayout(m, B * L, L, 0);
+    const bool qk8 = ((q_w1 && m->fp8_attn) || (qk8_any && !bw.w1.q_type)) && can_fuse_relayout(m, B * L, L, 0);
     {
       PhaseTimer pt(m, s, PH_LN);
       if (q_w1)
@@ -1115,7 +1119,8 @@ extern "C" void fmi_flux_destroy(fmi_flux* m) {
 
 extern "C" int fmi_flux_set_tensor(fmi_flux* m, const char* name, const void* data, fmi_dtype dtype, const int64_t* shape, int rank) {
   if (!m || !name || !data) return fail(FMI_ERR_INVALID, "flux_set_tensor: null argument");
-  if (m->fp8) return fail(FMI_ERR_STATE, "flux_set_tensor: the model was quantised to fp8 (fmi_flux_quantize_fp8); create a new one to load other weights");
+  if (m->fp8) return fail(FMI_ERR_STATE, "flux_set_tensor: the model was quantised to 8 bits (fmi_flux_quantize_fp8 / _int8); create a new one to load other weights");
+  m->q8_dbl.clear();  // (fmi_flux_set_fp8_attention(m, 2) in bf16 mode: the static attention scales follow the QkNorm weights — recomputed at the next evaluation)
   auto it = m->names.find(name);
   if (it == m->names.end()) return fail(FMI_ERR_INVALID, std::string("flux_set_tensor: unknown tensor name '") + name + "'");
   const Dest& d = it->second;
@@ -1465,47 +1470,8 @@ extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int mode) {
   m->dense_ready.clear();
   return FMI_OK;
 }
-// 8-bit modes: quantise the block Linears of `mask` once (bf16 arena -> e4m3 / int8 codes + per-output-channel scale); see the header.
-static int quantize_8bit(fmi_flux* m, int kind, unsigned mask, void* stream) {
-  if (!m) return fail(FMI_ERR_INVALID, "null handle");
-  FMI_TRY(use_device(m));
-  FMI_TRY(check_ready(m));
-  if (m->fp8) {
-    if (m->q8_kind == kind && m->q8_mask == mask) return FMI_OK;
-    return fail(FMI_ERR_STATE, "quantize: the model already holds another 8-bit form (create a new one)");
-  }
-  if (!(mask & 0x3f) || (mask & ~0x3fu)) return fail(FMI_ERR_INVALID, "quantize: the linear mask must name at least one of the six block linears (bits 0..5)");
-  std::vector<Dense*> lin;
-  for (auto& b : m->dbl)
-    for (int s = 0; s < 2; ++s) {
-      Dense* ds[4] = {&b.qkv[s], &b.proj[s], &b.mlp1[s], &b.mlp2[s]};
-      for (int k = 0; k < 4; ++k)
-        if (mask >> k & 1) lin.push_back(ds[k]);
-    }
-  for (auto& b : m->sgl) {
-    if (mask >> 4 & 1) lin.push_back(&b.w1);
-    if (mask >> 5 & 1) lin.push_back(&b.w2);
-  }
-  size_t bytes = 0;
-  for (Dense* d : lin) {
-    if (d->q_type || !d->w) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: model holds bitsandbytes-quantised linears; load a bf16 checkpoint");
-    if (d->K % 128 || d->N <= 128 || d->K > 16384) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: needs in_features % 128 == 0 (<= 16384) and out_features > 128");
-    bytes += align_up((size_t)d->N * d->K, 256) + align_up((size_t)d->N * 4, 256);
-  }
-  if (lin.empty()) return FMI_OK;
-  FMI_HIP_TRY(hipMalloc((void**)&m->fp8_arena, bytes));
-  m->fp8_bytes = bytes;
-  hipStream_t s = (hipStream_t)stream;
-  size_t off = 0;
-  for (Dense* d : lin) {
-    d->w8 = reinterpret_cast<uint8_t*>(m->fp8_arena + off);
-    off += align_up((size_t)d->N * d->K, 256);
-    d->w8_scale = reinterpret_cast<float*>(m->fp8_arena + off);
-    off += align_up((size_t)d->N * 4, 256);
-    FMI_TRY(launch_quantize_rows_fp8(d->w, d->K, d->N, d->K, d->w8, d->w8_scale, s, kind));
-  }
-  FMI_HIP_TRY(hipStreamSynchronize(s));
-  {  // static e4m3 scales of the attention operands from the QkNorm weights (see fmi_flux::fp8_attn)
+// static e4m3 scales of the attention operands from the QkNorm weights (see fmi_flux::fp8_attn); needs the weights in place
+static int compute_attention_scales(fmi_flux* m) {
     auto wmax = [&](const bf16_t* dev, float* out) -> int {
       uint16_t h[128];
       FMI_HIP_TRY(hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost));
@@ -1552,7 +1518,49 @@ static int quantize_8bit(fmi_flux* m, int kind, unsigned mask, void* stream) {
       m->k8_sgl[i] = scale_of(c);
       m->q8_sgl[i] = q_scale_pow2(scale_of(a), m->k8_sgl[i], &m->n8_sgl[i]);
     }
+    return FMI_OK;
+}
+// 8-bit modes: quantise the block Linears of `mask` once (bf16 arena -> e4m3 / int8 codes + per-output-channel scale); see the header.
+static int quantize_8bit(fmi_flux* m, int kind, unsigned mask, void* stream) {
+  if (!m) return fail(FMI_ERR_INVALID, "null handle");
+  FMI_TRY(use_device(m));
+  FMI_TRY(check_ready(m));
+  if (m->fp8) {
+    if (m->q8_kind == kind && m->q8_mask == mask) return FMI_OK;
+    return fail(FMI_ERR_STATE, "quantize: the model already holds another 8-bit form (create a new one)");
   }
+  if (!(mask & 0x3f) || (mask & ~0x3fu)) return fail(FMI_ERR_INVALID, "quantize: the linear mask must name at least one of the six block linears (bits 0..5)");
+  std::vector<Dense*> lin;
+  for (auto& b : m->dbl)
+    for (int s = 0; s < 2; ++s) {
+      Dense* ds[4] = {&b.qkv[s], &b.proj[s], &b.mlp1[s], &b.mlp2[s]};
+      for (int k = 0; k < 4; ++k)
+        if (mask >> k & 1) lin.push_back(ds[k]);
+    }
+  for (auto& b : m->sgl) {
+    if (mask >> 4 & 1) lin.push_back(&b.w1);
+    if (mask >> 5 & 1) lin.push_back(&b.w2);
+  }
+  size_t bytes = 0;
+  for (Dense* d : lin) {
+    if (d->q_type || !d->w) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: model holds bitsandbytes-quantised linears; load a bf16 checkpoint");
+    if (d->K % 128 || d->N <= 128 || d->K > 16384) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: needs in_features % 128 == 0 (<= 16384) and out_features > 128");
+    bytes += align_up((size_t)d->N * d->K, 256) + align_up((size_t)d->N * 4, 256);
+  }
+  if (lin.empty()) return FMI_OK;
+  FMI_HIP_TRY(hipMalloc((void**)&m->fp8_arena, bytes));
+  m->fp8_bytes = bytes;
+  hipStream_t s = (hipStream_t)stream;
+  size_t off = 0;
+  for (Dense* d : lin) {
+    d->w8 = reinterpret_cast<uint8_t*>(m->fp8_arena + off);
+    off += align_up((size_t)d->N * d->K, 256);
+    d->w8_scale = reinterpret_cast<float*>(m->fp8_arena + off);
+    off += align_up((size_t)d->N * 4, 256);
+    FMI_TRY(launch_quantize_rows_fp8(d->w, d->K, d->N, d->K, d->w8, d->w8_scale, s, kind));
+  }
+  FMI_HIP_TRY(hipStreamSynchronize(s));
+  FMI_TRY(compute_attention_scales(m));
   if (m->ws.base) {  // the fp8 workspace has two more buffers: rebuild on the next call
     FMI_HIP_TRY(hipFree(m->ws.base));
     m->ws.base = nullptr;
@@ -1570,7 +1578,8 @@ extern "C" int fmi_flux_quantize_int8(fmi_flux* m, unsigned linear_mask, void* s
 // both streams of a block take that epilogue (token counts multiples of 16); 0 = bf16 attention operands
 extern "C" int fmi_flux_set_fp8_attention(fmi_flux* m, int enable) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
-  m->fp8_attn = enable != 0;
+  if (enable < 0 || enable > 2) return fail(FMI_ERR_INVALID, "set_fp8_attention: 0 (off), 1 (on in the 8-bit modes) or 2 (on in every mode)");
+  m->fp8_attn = enable;  // (2 in bf16 mode: the static scales are taken from the QkNorm weights at the next evaluation)
   return FMI_OK;
 }
 // 4-bit weights, process-wide: number of rows from which the one-wave-per-SIMD fused dequant-GEMM (gemm_w4q.h) runs

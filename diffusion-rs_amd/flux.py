@@ -144,6 +144,11 @@ class FluxModel:
         linears, the attention and everything else stay on the bf16 path."""
         L.check(self.lib.fmi_flux_quantize_int8(self.h, INT8_DEFAULT_MASK if mask is None else int(mask), stream))
 
+    def set_fp8_attention(self, mode: int):
+        """q and k of the attention as e4m3 with static scales, QK^T on the fp8 MFMA: 0 never, 1 (default) in the 8-bit modes, 2 in every
+        mode — the bf16 block linears included (opt-in: a reduced-precision attention operand, not the reference's semantics)."""
+        L.check(self.lib.fmi_flux_set_fp8_attention(self.h, int(mode)))
+
     def missing(self) -> List[str]:
         n = self.lib.fmi_flux_missing_count(self.h)
         return [self.lib.fmi_flux_missing_name(self.h, i).decode() for i in range(n)]

@@ -236,8 +236,11 @@ int fmi_flux_quantize_fp8(fmi_flux*, void* stream);
  * tolerance stated for 8-bit modes where the e4m3 mode is a factor three outside it.
  * `linear_mask` says WHICH block linears are quantised (the others keep their bf16 GEMM): FMI_INT8_DEFAULT_MASK = all but the double
  * blocks' MLP, the two linears that carry most of the error per millisecond saved (DESIGN.md 4.3c's table).  Attention, residual
- * stream, modulation, embedders and final layer stay bf16 / f32.  Call once after all tensors are set; not combinable with
- * bnb-quantised linears or with fmi_flux_quantize_fp8 (FMI_ERR_STATE). */
+ * stream, modulation, embedders and final layer stay bf16 / f32 — except that, as in the fp8 mode and under the same switch
+ * (fmi_flux_set_fp8_attention, default on), the blocks whose q|k|v linear is in the mask hand q and k to the attention as e4m3 with the
+ * static scales and QK^T runs on the fp8 MFMA (measured cost: 5.9e-3 alone, 2.40e-2 -> 2.50e-2 with the default mask at 6 + 12 blocks; P, V
+ * and the accumulation are unchanged).  Call once after all tensors are set; not combinable with bnb-quantised linears or with
+ * fmi_flux_quantize_fp8 (FMI_ERR_STATE). */
 #define FMI_Q8_DOUBLE_QKV 1u      /* double blocks: q|k|v of both streams */
 #define FMI_Q8_DOUBLE_OUT 2u      /* double blocks: attention output projections */
 #define FMI_Q8_DOUBLE_MLP_IN 4u   /* double blocks: MLP linear 1 (+ GELU) */
@@ -246,10 +249,14 @@ int fmi_flux_quantize_fp8(fmi_flux*, void* stream);
 #define FMI_Q8_SINGLE_LINEAR2 32u /* single blocks: proj_out over cat(attention, gelu(mlp)) */
 #define FMI_INT8_DEFAULT_MASK (FMI_Q8_DOUBLE_QKV | FMI_Q8_DOUBLE_OUT | FMI_Q8_SINGLE_LINEAR1 | FMI_Q8_SINGLE_LINEAR2)
 int fmi_flux_quantize_int8(fmi_flux*, unsigned linear_mask, void* stream);
-/* fp8 mode, attention operands: 1 (default) = q and k leave the fused QKV epilogue as e4m3 with static per-block
+/* fp8 and int8 modes, attention operands: 1 (default) = q and k leave the fused QKV epilogue as e4m3 with static per-block
  * scales 448 / (sqrt(128) * max|QkNorm weight|) (no element of a normalised, rotated head vector can exceed them) and
  * QK^T runs on the fp8 MFMA; P and V stay bf16.  Applies when both streams of a block take the fused epilogue (token
- * counts and offsets multiples of 16, model width a multiple of 256), else that block uses bf16 operands.  0 = always bf16. */
+ * counts and offsets multiples of 16, model width a multiple of 256), else that block uses bf16 operands.  0 = always bf16.
+ * 2 = the same in EVERY mode, the bf16 block linears included (opt-in; the static scales are read from the QkNorm weights at the next
+ * evaluation; blocks whose q|k|v linear is bnb-quantised keep bf16 operands; not with sequence parallelism).  A reduced-precision
+ * attention operand is not the reference's semantics, which is why it is never the default outside the 8-bit modes — measured on
+ * FLUX.1-dev in full at the headline size it moves the result less than the bf16 path's own distance to f32. */
 int fmi_flux_set_fp8_attention(fmi_flux*, int enable);
 int fmi_flux_missing_count(const fmi_flux*);
 const char* fmi_flux_missing_name(const fmi_flux*, int i);

@@ -446,11 +446,12 @@ class Flux:
         lib().orc_flux_set_fp8(self.h, int(study_mode) if (on and study_mode) else int(bool(on)))
         lib().orc_flux_set_fp8_attention(self.h, int(bool(on and attention)))
 
-    def set_int8(self, on=True, mask=0x33):
+    def set_int8(self, on=True, mask=0x33, attention=False):
         """Block linears of `mask` on the int8 recipe (lin_blk mode 5: exact integer sums; parity unpinned, no reference counterpart),
-        the others in f32.  0x33 = the library's default mask (all but the double blocks' MLP)."""
+        the others in f32.  0x33 = the library's default mask (all but the double blocks' MLP).  attention=True: q and k of the attention
+        on e4m3 with the static scales, as in the fp8 mode (what the library does in either 8-bit mode for 16-aligned token counts)."""
         lib().orc_flux_set_fp8(self.h, 5 if on else 0)
-        lib().orc_flux_set_fp8_attention(self.h, 0)
+        lib().orc_flux_set_fp8_attention(self.h, int(bool(on and attention)))
         lib().orc_flux_set_q8_mask(self.h, int(mask) if on else 0x3f)
 
     def set_q8_mask(self, mask=0x3f):

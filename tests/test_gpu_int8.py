@@ -152,7 +152,7 @@ def models(env):
 
 
 @pytest.mark.parametrize("mask", MASKS)
-@pytest.mark.parametrize("B,S_hw,T", [(1, (8, 12), 40), (2, (6, 6), 64), (1, (16, 16), 77), (2, (8, 16), 48)])
+@pytest.mark.parametrize("B,S_hw,T", [(1, (8, 12), 40), (2, (6, 6), 64), (1, (16, 16), 77), (2, (8, 16), 48), (1, (8, 8), 32)])
 def test_flux_forward_int8_matches_int8_oracle(env, models, B, S_hw, T, mask):
     torch = env["torch"]
     img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, B, S_hw, T)
@@ -160,7 +160,8 @@ def test_flux_forward_int8_matches_int8_oracle(env, models, B, S_hw, T, mask):
     g = np.full(B, 3.5, np.float32)
     args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
     got = host(models[mask].forward(*args))
-    models["o8"].set_int8(True, mask)
+    aligned = (S_hw[0] * S_hw[1]) % 16 == 0 and T % 16 == 0  # then every block takes the fused q|k|v epilogue and QK^T runs on e4m3 operands
+    models["o8"].set_int8(True, mask, attention=aligned and bool(mask & 0x11))
     ref8 = models["o8"].forward(img, ids, txt, txt_ids, t, y, g)
     models["o8"].set_int8(False)
     ref = models["of"].forward(img, ids, txt, txt_ids, t, y, g)
@@ -180,7 +181,7 @@ def test_flux_denoise_int8(env, models):
     g = np.full(B, 3.5, np.float32)
     sched = d.SchedulerConfig()
     ts = sched.get_timesteps(steps, sched.calculate_shift(S_hw[0] * S_hw[1]))
-    models["o8"].set_int8(True, 0x33)
+    models["o8"].set_int8(True, 0x33, attention=True)   # (8, 8) / 32: aligned -> e4m3 QK^T
     ref8 = models["o8"].denoise(img, ids, txt, txt_ids, y, g, ts)
     models["o8"].set_int8(False)
     args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(y), dev(g), ts)
@@ -190,6 +191,36 @@ def test_flux_denoise_int8(env, models):
     err = rel_l2(got, ref8)
     print(f"int8 denoise {steps} steps: rel-L2 vs int8 oracle {err:.3e}")
     assert err <= 3e-2
+
+
+def test_e4m3_attention_operands_in_bf16_mode_opt_in(env, models):
+    """fmi_flux_set_fp8_attention(m, 2): bf16 block linears, q and k as e4m3 in front of QK^T (16-aligned token counts: every block).  Against the
+    oracle with NO linear quantised and its attention on e4m3 operands (the same static scales); off again = the bf16 result bit for bit."""
+    torch, d = env["torch"], env["d"]
+    gb, o8, of = models["gb"], models["o8"], models["of"]
+    B, S_hw, T = 2, (8, 16), 48
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, B, S_hw, T)
+    t, g = np.linspace(0.9, 0.4, B).astype(np.float32), np.full(B, 3.5, np.float32)
+    args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
+    base = host(gb.forward(*args))
+    gb.set_fp8_attention(2)
+    try:
+        got = host(gb.forward(*args))
+        name = "transformer_blocks.0.attn.norm_q.weight"   # a reload of a QkNorm weight must refresh the static scales (here: the same values)
+        gb.set_tensor(name, models["sd"][name])
+        np.testing.assert_array_equal(host(gb.forward(*args)), got)
+    finally:
+        gb.set_fp8_attention(1)
+    np.testing.assert_array_equal(host(gb.forward(*args)), base)
+    o8.set_int8(True, 0, attention=True)
+    ref8 = o8.forward(img, ids, txt, txt_ids, t, y, g)
+    o8.set_int8(False)
+    ref = of.forward(img, ids, txt, txt_ids, t, y, g)
+    e8, ef, eb = rel_l2(got, ref8), rel_l2(got, ref), rel_l2(base, ref)
+    print(f"bf16 linears + e4m3 QK^T operands: vs its oracle {e8:.3e}; vs f32 oracle {ef:.3e} (bf16 attention operands: {eb:.3e}); oracle e4m3-QK vs f32 {rel_l2(ref8, ref):.3e}")
+    assert not np.array_equal(got, base) and e8 <= 1e-2 and ef <= 2e-2
+    with pytest.raises(d.FmiError):
+        gb.set_fp8_attention(3)
 
 
 def test_int8_mode_guards(env, models):

@@ -244,6 +244,15 @@ def test_c2_dev_1024_forward_and_two_step_trajectory_of_the_full_model_match_ora
     print(f"C2 in full (FLUX.1-dev, D=3072, 19+38 blocks, S=4096 + T=512 tokens), one Flux::forward: rel-L2 {err:.3e} (oracle {t_or:.0f} s)")
     assert np.isfinite(got).all() and err <= 2e-2
     full_models["c2"] = (img, ids, t5, txt_ids, t, clip, g, ref)  # the int8 test below measures its mode on this very forward
+    # opt-in fmi_flux_set_fp8_attention(m, 2): the same forward with q and k handed to the attention as e4m3 — what the reduced operand costs at full size
+    gm.set_fp8_attention(2)
+    try:
+        got_qk8 = host(gm.forward(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(t), dev(clip), dev(g)))
+    finally:
+        gm.set_fp8_attention(1)
+    e_qk8 = rel_l2(got_qk8, ref)
+    print(f"  the same with e4m3 q, k in front of QK^T (opt-in, bf16 block linears): rel-L2 {e_qk8:.3e}; against the bf16-operand result {rel_l2(got_qk8, got):.3e}")
+    assert np.isfinite(got_qk8).all() and e_qk8 <= 2e-2 and not np.array_equal(got_qk8, got)
     # --- and the TRAJECTORY: two Euler steps of the 50-step schedule at full size against the oracle's, with the
     # modulation of both steps computed as ONE GEMM over the 6.5 GB (344 D x D) matrix — the path every 50-step run takes and the one
     # that carried the silent > 4 GiB offset wrap of round 3 — forced at 2 rows by fmi_flux_set_modulation_gemm(2); until now that
@@ -448,7 +457,7 @@ def test_c2_int8_full_model_forward_is_within_the_8_bit_tolerance(full_models):
         ts, gs = np.array([0.6], np.float32), np.array([3.5], np.float32)
         t0 = time.time()
         reff = om.forward(imgs, idss, t5s, txts, ts, clips, gs)
-        om.set_int8(True, d.flux.INT8_DEFAULT_MASK)
+        om.set_int8(True, d.flux.INT8_DEFAULT_MASK, attention=True)  # 384 / 128 tokens: every block on the fused epilogue, QK^T on e4m3 operands
         try:
             ref8 = om.forward(imgs, idss, t5s, txts, ts, clips, gs)
         finally:

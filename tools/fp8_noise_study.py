@@ -97,11 +97,11 @@ def model_table(n_double, n_single, S_hw, T):
 MASK_BITS = ["double q|k|v", "double attention out", "double MLP in", "double MLP out", "single linear1", "single linear2"]
 
 
-def mask_table(om, inputs, ref, masks, mode=5):
+def mask_table(om, inputs, ref, masks, mode=5, attention=False):
     """The int8 recipe (mode 5) on a SUBSET of the block linears (orc_flux_set_q8_mask): which linears carry the error?"""
     img, ids, txt, txt_ids, t, y, g = inputs
-    om.set_fp8(True, study_mode=mode)
-    print(f"int8 per row (W and A) on a subset of the block linears; rel-L2 vs f32:")
+    om.set_fp8(True, attention=attention, study_mode=mode)
+    print(f"int8 per row (W and A) on a subset of the block linears{' + e4m3 q, k in the attention (static scales)' if attention else ''}; rel-L2 vs f32:")
     for mask in masks:
         om.set_q8_mask(mask)
         out = om.forward(img, ids, txt, txt_ids, t, y, g)
@@ -120,6 +120,7 @@ if __name__ == "__main__":
     ap.add_argument("--skip-model", action="store_true")
     ap.add_argument("--masks", default="", help="comma-separated hex masks of block linears for the int8 subset table, e.g. 3f,15,2a")
     ap.add_argument("--only-masks", action="store_true")
+    ap.add_argument("--attention", action="store_true", help="mask table: also q and k of the attention on e4m3 (mask 00 = the attention operands alone)")
     a = ap.parse_args()
     if not a.only_masks:
         one_gemm_table()
@@ -129,4 +130,4 @@ if __name__ == "__main__":
             del MODES[:]
         om, inputs, ref = model_table(a.double, a.single, (h, w), a.txt)
         if a.masks:
-            mask_table(om, inputs, ref, [int(v, 16) for v in a.masks.split(",")])
+            mask_table(om, inputs, ref, [int(v, 16) for v in a.masks.split(",")], attention=a.attention)
