@@ -523,6 +523,7 @@ def main():
         leg(fi, wl, "int8_1024", KDESC["int8"], 5000.0,
             "int8 block linears (symmetric per-channel weight / per-token activation scales, exact int32 accumulate) for double q|k|v + attention out and single "
             "linear1 + linear2; the double blocks' MLP, the attention and everything else bf16; f32 residual stream")
+        leg(fi, Workload(720, 1280, 2), "int8_c5_shape", KDESC["int8"], 5000.0, "as int8_1024 (BASELINE configs[4]'s shape, 1280x720 batch 2, in the 8-bit mode that is within tolerance)")
         fi.close()
         del fi
         flux.quantize_fp8()  # last: the headline model itself switches to the fp8 path

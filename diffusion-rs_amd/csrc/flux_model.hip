@@ -1543,8 +1543,8 @@ static int quantize_8bit(fmi_flux* m, int kind, unsigned mask, void* stream) {
   }
   size_t bytes = 0;
   for (Dense* d : lin) {
-    if (d->q_type || !d->w) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: model holds bitsandbytes-quantised linears; load a bf16 checkpoint");
-    if (d->K % 128 || d->N <= 128 || d->K > 16384) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8: needs in_features % 128 == 0 (<= 16384) and out_features > 128");
+    if (d->q_type || !d->w) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8 / quantize_int8: model holds bitsandbytes-quantised linears; load a bf16 checkpoint");
+    if (d->K % 128 || d->N <= 128 || d->K > 16384) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8 / quantize_int8: needs in_features % 128 == 0 (<= 16384) and out_features > 128");
     bytes += align_up((size_t)d->N * d->K, 256) + align_up((size_t)d->N * 4, 256);
   }
   if (lin.empty()) return FMI_OK;
