@@ -64,6 +64,12 @@ void orc_flux_set_fp8_attention(orc_flux*, int on); /* with set_fp8: q, k of the
 float orc_e4m3_to_f32(uint8_t code);
 uint8_t orc_f32_to_e4m3(float x);
 void orc_quantize_rows_fp8(const float* x, int rows, int K, uint8_t* out, float* scale);
+/* int8 recipe (round 4; no reference counterpart — parity unpinned: pinned only to exact integer arithmetic, tests/test_oracle_fp8.py):
+ * orc_flux_set_fp8(m, 5) = the block linears of orc_flux_set_q8_mask's bits (0 double q|k|v, 1 double attention out, 2 double MLP in,
+ * 3 double MLP out, 4 single linear1, 5 single linear2; default all) on symmetric per-row int8 codes with EXACT integer sums, the others f32 */
+void orc_flux_set_q8_mask(orc_flux*, int mask);
+void orc_quantize_rows_i8(const float* x, int rows, int K, int8_t* out, float* scale);
+void orc_linear_i8(const float* x, const float* w, const float* bias, int M, int N, int K, float* y);
 /* returns 0 ok, <0 on missing tensor (name printed to stderr) */
 int orc_flux_forward(orc_flux*, const float* img, const float* img_ids, const float* txt, const float* txt_ids, const float* timesteps, const float* y, const float* guidance, int B, int S, int T, float* pred);
 int orc_flux_denoise(orc_flux*, float* img_inout, const float* img_ids, const float* txt, const float* txt_ids, const float* y, const float* guidance, int B, int S, int T, const double* timesteps, int n_steps);

@@ -106,3 +106,70 @@ def test_e4m3_noise_floor_is_a_property_of_the_mantissa_not_of_the_scale_granula
     assert 2.4e-2 < row[0] < 2.9e-2 and abs(mx[0] / row[0] - 1) < 0.02      # per-operand error: the mantissa's, with either scaling
     assert 3.4e-2 < row[1] < 4.0e-2 and abs(mx[1] / row[1] - 1) < 0.02      # both operands: sqrt(2) of it, block scales or not
     assert row[1] > 12 * bf16[1] and i8[1] < row[1] / 2.5 and i8[1] > 4 * bf16[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The int8 recipe (round 4; orc_quantize_rows_i8 / orc_linear_i8 / lin_blk mode 5).  No reference counterpart either: pinned to integer
+# arithmetic done independently here in numpy (int64), not to any vector.
+
+
+def test_quantize_rows_i8_recipe_and_ties():
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((8, 384)).astype(np.float32) * np.array([1e-3, 1, 50, 1e4, 0, 3, 1e-20, 1])[:, None].astype(np.float32)
+    x[7, :] = 0
+    x[7, :8] = [127.0, 0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 126.5]   # scale exactly 1: the ties of round-half-to-even
+    q, s = orc.quantize_rows_i8(x)
+    assert q.dtype == np.int8 and int(np.abs(q.astype(np.int32)).max()) <= 127
+    am = np.maximum(np.abs(x).max(1), np.float32(1e-30)).astype(np.float32)
+    np.testing.assert_array_equal(s, (am / np.float32(127)).astype(np.float32))
+    inv = (np.float32(127) / am).astype(np.float32)
+    np.testing.assert_array_equal(q, np.clip(np.rint(x * inv[:, None]), -127, 127).astype(np.int8))   # np.rint: half to even
+    assert (q[4] == 0).all()
+    assert q[7, :8].tolist() == [127, 0, 2, 2, 0, -2, -2, 126]
+    for r in (0, 1, 2, 3, 5):   # the row maximum maps to +-127 exactly; every value is within half a step
+        assert abs(int(q[r, np.abs(x[r]).argmax()])) == 127
+        assert (np.abs(q[r].astype(np.float32) * s[r] - x[r]) <= s[r] * 0.5 * 1.0001).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 7, 64), (40, 96, 3072), (9, 33, 15360)])
+def test_linear_i8_is_exact_integer_arithmetic(M, N, K):
+    """orc_linear_i8 == float(int64 sum of the code products) * (sx * sw) + b, bit for bit up to the one rounding a fused multiply-add saves
+    (the oracle is compiled with FMA contraction): the f32 slices of 1024 k it sums are exact, so the result cannot depend on their order."""
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K)).astype(np.float32) * 3
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    xq, xs = orc.quantize_rows_i8(x)
+    wq, ws = orc.quantize_rows_i8(w)
+    acc = xq.astype(np.int64) @ wq.astype(np.int64).T
+    assert np.abs(acc).max() < 2 ** 31
+    sc = (xs[:, None] * ws[None, :]).astype(np.float32)
+    exact = acc.astype(np.float64) * sc.astype(np.float64) + b.astype(np.float64)[None, :]   # float(acc) is exact here only below 2^24: compare in f64
+    y = orc.linear_i8(x, w, b)
+    assert np.abs(y - exact).max() <= 2.0 ** -22 * np.abs(exact).max()   # two f32 roundings (int -> f32 above 2^24, the multiply-add)
+    f32 = orc.linear(x, w, b)
+    err = np.linalg.norm(y - f32) / np.linalg.norm(f32)
+    assert err < 2e-2, err   # 8.5e-3 rms per Gaussian operand, two operands
+
+
+def test_int8_mask_selects_linears():
+    """orc_flux_set_q8_mask: mask 0 with the recipe on is the f32 model bit for bit; every bit changes the result; the default mask differs from all."""
+    import diffusion_rs_amd.synth as synth
+    from tests.util import SMALL_FLUX, flux_inputs
+    sd = synth.flux_state_dict_numpy(SMALL_FLUX, seed=0)
+    om = orc.Flux(SMALL_FLUX)
+    om.load(sd)
+    img, ids, txt, txt_ids, y = flux_inputs(SMALL_FLUX, 1, (4, 6), 24)
+    t, g = np.array([0.7], np.float32), np.array([3.5], np.float32)
+    ref = om.forward(img, ids, txt, txt_ids, t, y, g)
+    om.set_int8(True, 0)
+    np.testing.assert_array_equal(om.forward(img, ids, txt, txt_ids, t, y, g), ref)
+    outs = {}
+    for mask in (1, 2, 4, 8, 16, 32, 0x33, 0x3f):
+        om.set_int8(True, mask)
+        outs[mask] = om.forward(img, ids, txt, txt_ids, t, y, g)
+        assert not np.array_equal(outs[mask], ref)
+        assert np.linalg.norm(outs[mask] - ref) / np.linalg.norm(ref) < 2e-2
+    om.set_int8(False)
+    np.testing.assert_array_equal(om.forward(img, ids, txt, txt_ids, t, y, g), ref)
+    assert len({o.tobytes() for o in outs.values()}) == len(outs)
