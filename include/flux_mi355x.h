@@ -504,6 +504,11 @@ int fmi_linear_fp8(const void* x, const uint8_t* wq, const float* w_scale, const
 int fmi_quantize_rows_i8(const void* x, int rows, int K, int8_t* out, float* scale, void* stream);
 int fmi_linear_i8(const void* x, const int8_t* wq, const float* w_scale, const void* bias, void* y, int M, int N,
                   int K, fmi_epilogue epi, void* stream);
+/* The 8-bit GEMM alone on operands the caller already quantised with fmi_quantize_rows_fp8 (kind 1) / fmi_quantize_rows_i8 (kind 2):
+ * y(M,N) bf16 = epi(acc(xq · wq^T) * x_scale[m] * w_scale[n] + bias); stream-ordered, no allocation (the form a caller that keeps
+ * activations quantised between layers binds; also what tools/hipblaslt_yardstick.py times against the vendor library's fp8 GEMM). */
+int fmi_gemm_q8(const void* xq, const float* x_scale, const void* wq, const float* w_scale, const void* bias, void* y,
+                int M, int N, int K, int kind, fmi_epilogue epi, void* stream);
 /* softmax(q k^T * scale) v, q,k,v,o (B,H,L,d) bf16, d == 128, non-causal; o is written
  * token-major (B,L,H*d) when `out_token_major`, else (B,H,L,d).
  * == backend::ops::sdpa fallback (ops.rs:247-262) without materialising the scores. */

@@ -37,3 +37,35 @@ for M, N, K, name in shapes:
     t_me = timeit(lambda: L.check(lib.fmi_linear_bf16(p(x), p(w), None, p(y), M, N, K, 0, None)))
     fl = 2.0 * M * N * K
     print(f"{name:18s} M={M:5d} N={N:5d} K={K:5d}   hipBLASLt {fl / t_lt / 1e9:7.1f} TF ({t_lt * 1e3:6.1f} us)   this library {fl / t_me / 1e9:7.1f} TF ({t_me * 1e3:6.1f} us)", flush=True)
+
+
+# ---- the 8-bit GEMMs (round 4): this library's e4m3 / int8 kernels on pre-quantised operands (fmi_gemm_q8) next to the vendor library's fp8 GEMM behind
+# torch._scaled_mm (row-wise scales where this torch build has them, else per-tensor) — same shapes, bf16 output
+lib.fmi_quantize_rows_fp8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+print()
+for M, N, K, name in shapes:
+    x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    res = {}
+    for kind, nm in ((1, "e4m3"), (2, "int8")):
+        xq, wq = torch.empty(M, K, dtype=torch.uint8, device="cuda"), torch.empty(N, K, dtype=torch.uint8, device="cuda")
+        xs, ws = torch.empty(M, dtype=torch.float32, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda")
+        q = lib.fmi_quantize_rows_fp8 if kind == 1 else lib.fmi_quantize_rows_i8
+        L.check(q(p(x), M, K, p(xq), p(xs), None))
+        L.check(q(p(w), N, K, p(wq), p(ws), None))
+        res[nm] = timeit(lambda: L.check(lib.fmi_gemm_q8(p(xq), p(xs), p(wq), p(ws), None, p(y), M, N, K, kind, 0, None)))
+        if kind == 1:
+            x8, w8 = xq.view(torch.float8_e4m3fn), wq.view(torch.float8_e4m3fn)
+            t_lt, how = None, ""
+            for sa, sb, label in ((xs.view(M, 1), ws.view(1, N), "row-wise scales"), (torch.ones((), device="cuda"), torch.ones((), device="cuda"), "per-tensor scales")):
+                try:
+                    t_lt = timeit(lambda: torch._scaled_mm(x8, w8.t(), scale_a=sa, scale_b=sb, out_dtype=torch.bfloat16))
+                    how = label
+                    break
+                except Exception as e:  # noqa: BLE001
+                    how = f"unavailable ({type(e).__name__})"
+    fl = 2.0 * M * N * K
+    lt = f"{fl / t_lt / 1e9:7.1f} TF ({t_lt * 1e3:6.1f} us, {how})" if t_lt else how
+    print(f"{name:18s} M={M:5d} N={N:5d} K={K:5d}   hipBLASLt fp8 {lt}   this library e4m3 {fl / res['e4m3'] / 1e9:7.1f} TF ({res['e4m3'] * 1e3:6.1f} us)   "
+          f"int8 {fl / res['int8'] / 1e9:7.1f} TOPS ({res['int8'] * 1e3:6.1f} us)", flush=True)
