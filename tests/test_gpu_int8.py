@@ -116,6 +116,31 @@ def test_linear_i8_matches_oracle(env, M, N, K, epi):
     assert noise <= 2.5e-2  # (the e4m3 recipe on the same operands: 3.7e-2 and up)
 
 
+@pytest.mark.parametrize("kind", [1, 2], ids=["e4m3", "int8"])
+def test_gemm_q8_on_prequantised_operands_equals_the_linear(env, kind):
+    """fmi_gemm_q8 (both operands quantised by the caller) is the same launch as fmi_linear_fp8 / fmi_linear_i8 behind their internal row pass: bit-identical."""
+    torch, L, lib = env["torch"], env["L"], env["lib"]
+    M, N, K = 300, 520, 1280
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    quant = lib.fmi_quantize_rows_fp8 if kind == 1 else lib.fmi_quantize_rows_i8
+    linear = lib.fmi_linear_fp8 if kind == 1 else lib.fmi_linear_i8
+    xq, wq = torch.empty(M, K, dtype=torch.uint8, device="cuda"), torch.empty(N, K, dtype=torch.uint8, device="cuda")
+    xs, ws = torch.empty(M, dtype=torch.float32, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda")
+    L.check(quant(_p(x), M, K, _p(xq), _p(xs), None))
+    L.check(quant(_p(w), N, K, _p(wq), _p(ws), None))
+    y1, y2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    for epi in (0, 1):
+        L.check(linear(_p(x), _p(wq), _p(ws), _p(b), _p(y1), M, N, K, epi, None))
+        L.check(lib.fmi_gemm_q8(_p(xq), _p(xs), _p(wq), _p(ws), _p(b), _p(y2), M, N, K, kind, epi, None))
+        torch.cuda.synchronize()
+        assert torch.equal(y1.view(torch.int16), y2.view(torch.int16))
+    assert lib.fmi_gemm_q8(_p(xq), _p(xs), _p(wq), _p(ws), None, _p(y2), M, N, K, 3, 0, None) < 0   # no such kind
+    assert lib.fmi_gemm_q8(_p(xq), None, _p(wq), _p(ws), None, _p(y2), M, N, K, 1, 0, None) < 0
+
+
 def test_linear_i8_rejects_bad_shapes(env):
     torch, lib = env["torch"], env["lib"]
     x = torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda")
