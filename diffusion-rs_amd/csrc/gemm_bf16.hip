@@ -1401,7 +1401,8 @@ static std::atomic<bool> g_w4{[] {
   return e ? atoi(e) != 0 : false;
 }()};
 static std::atomic<int> g_w4q_min_rows{256};
-static std::atomic<int> g_w4_qkv_min_n{1 << 30};  // never for dense weights (measured: slower, see launch_gemm); the packed 4-bit kernel always fuses
+// never for dense weights (measured: slower, see launch_gemm); the packed 4-bit kernel always fuses.  FMI_GEMM_W4_QKV_MIN_N = the bound for experiments
+static std::atomic<int> g_w4_qkv_min_n{[]() { const char* e = getenv("FMI_GEMM_W4_QKV_MIN_N"); return e && atoi(e) > 0 ? atoi(e) : 1 << 30; }()};
 void set_gemm_w4_qkv_min_n(int n) { g_w4_qkv_min_n = n; }
 void set_gemm_w4q_min_rows(int rows) { g_w4q_min_rows = rows; }
 void set_gemm_w4(bool on) { g_w4 = on; }
