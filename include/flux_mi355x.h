@@ -188,7 +188,7 @@ int fmi_comm_broadcast(fmi_comm*, void* buf, size_t bytes, int root, void* strea
 int fmi_comm_gather(fmi_comm*, const void* send, void* recv, size_t bytes, int root, void* stream);
 /* PROCESS-WIDE test / ablation hooks — fmi_set_bnb4_onewave_min_rows, fmi_set_attention_kernel (below; a model handle can override it for itself: fmi_flux_set_attention_kernel) and the environment
  * variables FMI_GEMM_W4 / FMI_ATT_W4 / FMI_ATT_W16 / FMI_ATT_W32 / FMI_ATT_W16L (read once at load: the initial state of fmi_set_attention_kernel's switches), FMI_TWO_STREAMS=1 (read
- * by fmi_flux_create: the text chain of a double block on an internal second stream — an experiment measured at -0.3 %, same bits, default off) FMI_GEMM_W4_QKV_MIN_N=<n> (read at load: dense q|k|v launches at least n wide on the 4-wave GEMM kernel — measured a wash in round 4, default never) and FMI_GEMM_BAND=<n> (read at the first GEMM launch: pins the band height of the
+ * by fmi_flux_create: the text chain of a double block on an internal second stream — an experiment measured at -0.3 %, same bits, default off) FMI_GEMM_W4_QKV_MIN_N=<n> (read at load, with FMI_GEMM_W4=1: dense q|k|v launches at least n wide on the 4-wave GEMM kernel too — measured 5 % slower in round 4, default never) and FMI_GEMM_BAND=<n> (read at the first GEMM launch: pins the band height of the
  * GEMM tile order, a bijection of the tiles whatever its value) — are shared by every handle and thread of the process: they pick between
  * kernels that produce identical bits (the attention kernels: identical within a family, equal to rounding across, see
  * fmi_set_attention_kernel), so they move time, not results.  Set them before starting work on other threads.
