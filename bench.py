@@ -412,10 +412,10 @@ def main():
         # includes ~0.3 s of idle (two rocm-smi calls) around the timed region: a <= 1 % overestimate per image
         extra["energy_j_per_image_rank0"] = round((e_end - e_start) / 1e6 / (args.steps * B), 1)
         extra["avg_power_w_rank0"] = round((e_end - e_start) / 1e6 / elapsed, 1)
-    KDESC = {"none": "gemm_pp_kernel + gemm_w4_kernel (bf16 MFMA GEMM: the 152 block-linear launches of a step)",
+    KDESC = {"none": "gemm_pp_kernel (bf16 MFMA GEMM: the 152 block-linear launches of a step)",
              "nf4": "gemm_w4q_kernel (fused nf4 dequant-GEMM on the packed weights: the 152 block-linear launches of a step; dense-equivalent FLOPs)",
              "fp8": "gemm_pp_kernel<fp8> (e4m3 MFMA GEMM, all block linears)",
-             "int8": "gemm_pp_kernel<int8> (v_mfma_i32_32x32x32_i8: double q|k|v + attention out, single linear1 + linear2) + gemm_pp_kernel / gemm_w4_kernel (bf16: the double "
+             "int8": "gemm_pp_kernel<int8> (v_mfma_i32_32x32x32_i8: double q|k|v + attention out, single linear1 + linear2) + gemm_pp_kernel<bf16> (the double "
                      "blocks' MLP); one average over both kinds of launch, priced against the int8 peak"}
     PEAK_NOTE = "2500 = dense bf16 MFMA peak at 2.4 GHz; a register-only MFMA loop (tools/mfma_peak.hip) sustains 2020-2160 on this part (power cap, ~1.95 GHz)"
     if rank == 0 and not args.no_profile_pass and spg is None:  # (the profiled pass is a single-device pass)
