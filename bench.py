@@ -528,7 +528,7 @@ def main():
         fill_flux(fq, "nf4")
         # default policy (flux_model.hip: densify): only the packed codes are resident; the block linears (launches above 383 rows) expand per call
         # into a 264 MB scratch (stand-alone dequant kernel) and run the dense GEMM, smaller launches multiply from the packed codes
-        leg(fq, wl, "nf4_c3", "dequant4_kernel + gemm_pp_kernel / gemm_w4_kernel (nf4 block linears expanded per call into a scratch, then the dense bf16 MFMA GEMM; "
+        leg(fq, wl, "nf4_c3", "dequant4_kernel + gemm_pp_kernel (nf4 block linears expanded per call into a scratch, then the dense bf16 MFMA GEMM; "
             "the expansions are inside the timed phases; dense-equivalent FLOPs)", 2500.0,
             "bf16 MFMA on nf4 weights (bitsandbytes blocksize 64; every block + modulation linear packed; no bf16 copy resident)")
         # (round 2 also timed every launch on the fused dequant-GEMM, fmi_flux_set_quant_dense_cache(2): 85-86 ms per step against 68-69
