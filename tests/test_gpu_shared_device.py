@@ -116,6 +116,14 @@ def test_attention_and_gemm_reproduce_their_idle_results_while_another_process_u
         L.check(lib.fmi_linear_fp8(_p(x), _p(wq), _p(ws), None, _p(y), M, N, K, 0, None))
         return y
     cases.append((f"linear fp8 {M}x{N}x{K}", run_fp8))
+    wq8, ws8 = torch.empty((N, K), dtype=torch.int8, device="cuda"), torch.empty((N,), dtype=torch.float32, device="cuda")
+    L.check(lib.fmi_quantize_rows_i8(_p(w), N, K, _p(wq8), _p(ws8), None))
+
+    def run_i8(x=x, wq8=wq8, ws8=ws8, M=M, N=N, K=K):  # the int8 mode's GEMM (round 4): the fp8 pipeline on v_mfma_i32_32x32x32_i8
+        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        L.check(lib.fmi_linear_i8(_p(x), _p(wq8), _p(ws8), None, _p(y), M, N, K, 0, None))
+        return y
+    cases.append((f"linear int8 MFMA {M}x{N}x{K}", run_i8))
     H, Lq = 24, 4608
     q, k, v = (torch.randn((1, H, Lq, 128), generator=g, device="cuda").to(torch.bfloat16) for _ in range(3))
     q8, k8 = (torch.empty((1, H, Lq, 128), dtype=torch.uint8, device="cuda") for _ in range(2))
