@@ -849,15 +849,27 @@ void lin_blk(orc_flux* m, const Lin& l, const float* x, int rows, float* y, int 
     return;
   }
   if (m->fp8 != 1) {  // study modes: dequantised operands through the plain f32 GEMM
-    static const int wk[7] = {0, 1, 2, 1, 0, 5, 0}, ak[7] = {0, 1, 2, 0, 1, 5, 2};
-    const int mode = std::min(std::max(m->fp8, 2), 6);
+    // 7 = int8 as 5, but the input of the single blocks' linear2 — cat(attention, gelu(mlp)) — gets one scale per SEGMENT and row instead of one per row
+    static const int wk[8] = {0, 1, 2, 1, 0, 5, 0, 5}, ak[8] = {0, 1, 2, 0, 1, 5, 2, 5};
+    const int mode = std::min(std::max(m->fp8, 2), 7);
     Fp8Weight& fw = m->fp8_w[l.w];
     if (fw.q.empty()) {
       fw.q.resize((size_t)l.out * l.in);
       study_quantise(l.w, l.out, l.in, wk[mode], fw.q.data());
     }
     std::vector<float> xq((size_t)rows * l.in);
-    study_quantise(x, rows, l.in, ak[mode], xq.data());
+    if (mode == 7 && which == LIN_SGL_2) {
+      const int D = m->D;
+      std::vector<float> seg((size_t)rows * l.in), segq((size_t)rows * l.in);
+      for (int part = 0; part < 2; ++part) {  // columns [0, D) and [D, in): gathered, quantised per row, scattered back
+        const int c0 = part ? D : 0, w = part ? l.in - D : D;
+        for (int r = 0; r < rows; ++r) memcpy(seg.data() + (size_t)r * w, x + (size_t)r * l.in + c0, sizeof(float) * w);
+        study_quantise(seg.data(), rows, w, 5, segq.data());
+        for (int r = 0; r < rows; ++r) memcpy(xq.data() + (size_t)r * l.in + c0, segq.data() + (size_t)r * w, sizeof(float) * w);
+      }
+    } else {
+      study_quantise(x, rows, l.in, ak[mode], xq.data());
+    }
     gemm_nt(xq.data(), l.in, fw.q.data(), l.in, l.b, rows, l.out, l.in, y, l.out, 1.0f);
     return;
   }

@@ -120,6 +120,7 @@ if __name__ == "__main__":
     ap.add_argument("--skip-model", action="store_true")
     ap.add_argument("--masks", default="", help="comma-separated hex masks of block linears for the int8 subset table, e.g. 3f,15,2a")
     ap.add_argument("--only-masks", action="store_true")
+    ap.add_argument("--mask-mode", type=int, default=5, help="study mode of the mask table: 5 = the int8 recipe, 7 = the same with one scale per segment of linear2's input")
     ap.add_argument("--attention", action="store_true", help="mask table: also q and k of the attention on e4m3 (mask 00 = the attention operands alone)")
     a = ap.parse_args()
     if not a.only_masks:
@@ -130,4 +131,4 @@ if __name__ == "__main__":
             del MODES[:]
         om, inputs, ref = model_table(a.double, a.single, (h, w), a.txt)
         if a.masks:
-            mask_table(om, inputs, ref, [int(v, 16) for v in a.masks.split(",")], attention=a.attention)
+            mask_table(om, inputs, ref, [int(v, 16) for v in a.masks.split(",")], mode=a.mask_mode, attention=a.attention)
