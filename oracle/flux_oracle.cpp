@@ -911,7 +911,42 @@ void to_heads(const float* x, int rows, int H, int d, float* out, int row_off, i
 // attention(), model.rs:97-102: rope on q,k; sdpa in f32 (model.rs:40-50); (H,L,d)->(L,H*d)
 // q8 / k8 > 0 (fp8 recipe, no reference counterpart): the rotated q and k are replaced by e4m3(value * scale) / scale
 // with the static scales 448 / (sqrt(d) * max|QkNorm weight|) before the scores are formed; P and V are untouched.
-void attention(const float* q, const float* k, const float* v, const float* pe, int H, int L, int d, float* out_tok, float q8 = 0.f, float k8 = 0.f) {
+// STUDY ONLY (orc_flux_set_fp8_attention(m, 2); tools/fp8_noise_study.py --attention 2): softmax(q k^T scale) v with P and V on e4m3 as well — the
+// unnormalised probabilities exp(s - max) <= 1 as they are, V with one scale per head (448 / absmax of the head's V), the row sum taken over the quantised
+// probabilities (what a ones-row MFMA on the same operand would see).  Not a recipe of the library: it prices one before anybody builds it.
+static void sdpa_pv8(const float* q, const float* k, const float* v, int H, int Lq, int Lk, int d, float scale, float* out) {
+  std::vector<float> att((size_t)Lq * Lk), vt((size_t)d * Lk), rs(Lq);
+  for (int h = 0; h < H; ++h) {
+    const float* qp = q + (int64_t)h * Lq * d;
+    const float* kp = k + (int64_t)h * Lk * d;
+    const float* vp = v + (int64_t)h * Lk * d;
+    gemm_nt(qp, d, kp, d, nullptr, Lq, Lk, d, att.data(), Lk, 1.0f);
+    float vmax = 1e-30f;
+    for (int64_t i = 0; i < (int64_t)Lk * d; ++i) vmax = fmaxf(vmax, fabsf(vp[i]));
+    const float v8 = 448.0f / vmax;
+#pragma omp parallel for
+    for (int i = 0; i < Lq; ++i) {
+      float* a = att.data() + (size_t)i * Lk;
+      float mx = -INFINITY;
+      for (int j = 0; j < Lk; ++j) mx = fmaxf(mx, a[j] * scale);
+      float sum = 0.f;
+      for (int j = 0; j < Lk; ++j) {
+        a[j] = orc_e4m3_to_f32(orc_f32_to_e4m3(expf(a[j] * scale - mx)));
+        sum += a[j];
+      }
+      rs[i] = sum;
+    }
+#pragma omp parallel for
+    for (int j = 0; j < d; ++j)
+      for (int i = 0; i < Lk; ++i) vt[(size_t)j * Lk + i] = orc_e4m3_to_f32(orc_f32_to_e4m3(vp[(size_t)i * d + j] * v8));
+    float* o = out + (int64_t)h * Lq * d;
+    gemm_nt(att.data(), Lk, vt.data(), Lk, nullptr, Lq, d, Lk, o, d, 1.0f);
+#pragma omp parallel for
+    for (int i = 0; i < Lq; ++i)
+      for (int j = 0; j < d; ++j) o[(size_t)i * d + j] /= rs[i] * v8;
+  }
+}
+void attention(const float* q, const float* k, const float* v, const float* pe, int H, int L, int d, float* out_tok, float q8 = 0.f, float k8 = 0.f, bool pv8 = false) {
   std::vector<float> qr((size_t)H * L * d), kr((size_t)H * L * d), o((size_t)H * L * d);
   orc_apply_rope(q, pe, H, L, d, qr.data());
   orc_apply_rope(k, pe, H, L, d, kr.data());
@@ -923,7 +958,8 @@ void attention(const float* q, const float* k, const float* v, const float* pe, 
     }
   }
   float scale = (float)(1.0 / sqrt((double)d));
-  orc_sdpa(qr.data(), kr.data(), v, 1, H, L, L, d, scale, o.data());
+  if (pv8) sdpa_pv8(qr.data(), kr.data(), v, H, L, L, d, scale, o.data());
+  else orc_sdpa(qr.data(), kr.data(), v, 1, H, L, L, d, scale, o.data());
 #pragma omp parallel for
   for (int l = 0; l < L; ++l)
     for (int h = 0; h < H; ++h) memcpy(out_tok + ((int64_t)l * H + h) * d, o.data() + ((int64_t)h * L + l) * d, sizeof(float) * d);
@@ -1005,7 +1041,7 @@ static int double_block_one(orc_flux* m, int idx, float* img, float* txt, const 
     k8 = fp8_attn_scale(m, p + "attn.norm_k", p + "attn.norm_added_k", d);
     q8 = fp8_q_scale_pow2(fp8_attn_scale(m, p + "attn.norm_q", p + "attn.norm_added_q", d), k8, d);
   }
-  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8);
+  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8, m->fp8 && m->fp8_attn == 2);
   const float* txt_attn = attn.data();
   const float* img_attn = attn.data() + (size_t)T * D;
   Lin ip = get_lin(m, p + "attn.to_out.0", D, D), tp = get_lin(m, p + "attn.to_add_out", D, D);
@@ -1054,7 +1090,7 @@ static int single_block_one(orc_flux* m, int idx, float* x, const float* vec, co
     k8 = fp8_attn_scale(m, p + "attn.norm_k", "", d);
     q8 = fp8_q_scale_pow2(fp8_attn_scale(m, p + "attn.norm_q", "", d), k8, d);
   }
-  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8);
+  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8, m->fp8 && m->fp8_attn == 2);
   orc_gelu(mlp.data(), (int64_t)L * M, mlp.data());
 #pragma omp parallel for
   for (int l = 0; l < L; ++l) {  // Tensor::cat(&[attn, mlp.gelu()], 2)  (model.rs:660)

@@ -444,7 +444,7 @@ class Flux:
         block take the fused QKV epilogue: token counts / offsets multiples of 16).  study_mode 2..6 = the alternative
         quantisers of tools/fp8_noise_study.py (flux_oracle.cpp: lin_blk), never what the library is compared with."""
         lib().orc_flux_set_fp8(self.h, int(study_mode) if (on and study_mode) else int(bool(on)))
-        lib().orc_flux_set_fp8_attention(self.h, int(bool(on and attention)))
+        lib().orc_flux_set_fp8_attention(self.h, (2 if attention == 2 else 1) if (on and attention) else 0)  # 2: study only, e4m3 P and V too
 
     def set_int8(self, on=True, mask=0x33, attention=False):
         """Block linears of `mask` on the int8 recipe (lin_blk mode 5: exact integer sums; parity unpinned, no reference counterpart),

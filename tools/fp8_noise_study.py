@@ -101,7 +101,7 @@ def mask_table(om, inputs, ref, masks, mode=5, attention=False):
     """The int8 recipe (mode 5) on a SUBSET of the block linears (orc_flux_set_q8_mask): which linears carry the error?"""
     img, ids, txt, txt_ids, t, y, g = inputs
     om.set_fp8(True, attention=attention, study_mode=mode)
-    print(f"int8 per row (W and A) on a subset of the block linears{' + e4m3 q, k in the attention (static scales)' if attention else ''}; rel-L2 vs f32:")
+    print(f"int8 per row (W and A) on a subset of the block linears{' + e4m3 q, k in the attention (static scales)' if attention else ''}{', e4m3 P and V too' if attention == 2 else ''}; rel-L2 vs f32:")
     for mask in masks:
         om.set_q8_mask(mask)
         out = om.forward(img, ids, txt, txt_ids, t, y, g)
@@ -121,7 +121,8 @@ if __name__ == "__main__":
     ap.add_argument("--masks", default="", help="comma-separated hex masks of block linears for the int8 subset table, e.g. 3f,15,2a")
     ap.add_argument("--only-masks", action="store_true")
     ap.add_argument("--mask-mode", type=int, default=5, help="study mode of the mask table: 5 = the int8 recipe, 7 = the same with one scale per segment of linear2's input")
-    ap.add_argument("--attention", action="store_true", help="mask table: also q and k of the attention on e4m3 (mask 00 = the attention operands alone)")
+    ap.add_argument("--attention", type=int, nargs="?", const=1, default=0,
+                    help="mask table: also q and k of the attention on e4m3 (mask 00 = the attention operands alone); 2 = P and V on e4m3 as well (study of an unbuilt recipe)")
     a = ap.parse_args()
     if not a.only_masks:
         one_gemm_table()
