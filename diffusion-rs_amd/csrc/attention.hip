@@ -613,16 +613,22 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
     // round 3: the one-wave kernel's fp8-QK^T stream (attention_w16.h, QK8) carries scale * log2(e) / (sq * sk) as an E8M0 block
     // scale of the score MFMA, so it serves the calls whose factor is a power of two 2^-n, n = 0 .. 126 — the model's fp8 mode
     // picks its q scale that way (flux_model.hip: fp8_q_scale_pow2); anything else runs on the 8-wave kernel below
-    // The exponent comes from the caller as an integer when it has one (score_exp2); a bare float (fmi_sdpa_fp8qk) qualifies only if it
-    // IS a power of two, bit for bit — no tolerance window: a factor a few ulps off means the caller did not construct it as one.
+    // The exponent comes from the caller as an integer when it has one (score_exp2: the model, fmi_sdpa_fp8qk_ws).  A bare float
+    // (fmi_sdpa_fp8qk) qualifies if scale * log2(e), rounded to f32 here, is a power of two or ONE ulp beside one: a caller who builds
+    // scale = 2^n / log2(e) in f32 lands there by construction — anything further off was not constructed as one.
     int n2 = 1;
     if (score_exp2 != ATT_NO_EXP2) n2 = score_exp2;
     else if (sl > 0.f) {
       int e;
-      if (frexpf(sl, &e) == 0.5f) n2 = e - 1;
+      const float mant = frexpf(sl, &e);  // in [0.5, 1)
+      if (mant == 0.5f || mant == nextafterf(0.5f, 1.0f)) n2 = e - 1;
+      else if (mant == nextafterf(1.0f, 0.0f)) n2 = e;
     }
     const bool pow2 = n2 <= 0 && n2 >= -126;
-    if (!(g_att_w16 && Lk > ATT_KV && pow2)) g_fp8_fallbacks.fetch_add(1, std::memory_order_relaxed);
+    // counted (fmi_device_info: fp8_attention_fallbacks): launches that WOULD take a one-wave stream — that kernel family is selected and
+    // there is more than one KV tile — but whose factor is not a power of two.  A handle or user that picked kernel 0..2 chose the 8-wave
+    // kernel; a single-tile problem has no stream to fall back from.
+    if (g_att_w16 && Lk > ATT_KV && !pow2) g_fp8_fallbacks.fetch_add(1, std::memory_order_relaxed);
     if (g_att_w16l && g_att_w16 && Lk > ATT_KV && pow2) {  // round 4: the lock-step schedule's fp8-QK^T stream
       const float sl2 = ldexpf(1.0f, n2);
       if (rescale_thr_x16 == 0)

@@ -35,8 +35,10 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 /* 4 (round 4): + fmi_build_id, fmi_comm_probe, fmi_flux_set_attention_kernel; fmi_flux_set_modulation_gemm accepts 2; fmi_set_attention_kernel accepts 5.
+ * 5 (round 5): + the caller-owned-workspace forms fmi_sdpa_bf16_ws / fmi_sdpa_fp8qk_ws / fmi_linear_fp8_ws / fmi_linear_i8_ws and their size queries;
+ *   fmi_sdpa_* / fmi_linear_fp8 / fmi_linear_i8 no longer synchronise the stream or call hipMalloc.
  * Additions only: a host bound against version 3 keeps working. */
-#define FMI_ABI_VERSION 4
+#define FMI_ABI_VERSION 5
 
 typedef enum fmi_status {
   FMI_OK = 0,
@@ -504,6 +506,16 @@ int fmi_linear_fp8(const void* x, const uint8_t* wq, const float* w_scale, const
 int fmi_quantize_rows_i8(const void* x, int rows, int K, int8_t* out, float* scale, void* stream);
 int fmi_linear_i8(const void* x, const int8_t* wq, const float* w_scale, const void* bias, void* y, int M, int N,
                   int K, fmi_epilogue epi, void* stream);
+/* Caller-owned workspace forms of the two (the reference's convention: the caller allocates, bitsandbytes/op.rs:204-228): `workspace`
+ * = at least fmi_linear_q8_workspace_bytes(M, K) bytes of device memory, 256-byte aligned, that must stay untouched until the call's work
+ * has run on `stream`.  fmi_linear_fp8 / fmi_linear_i8 above are these with the workspace drawn from the device's default memory pool ON
+ * `stream` (hipMallocAsync / hipFreeAsync): every form is asynchronous on the stream — no device allocation in the steady state, no
+ * host synchronisation. */
+size_t fmi_linear_q8_workspace_bytes(int M, int K);
+int fmi_linear_fp8_ws(const void* x, const uint8_t* wq, const float* w_scale, const void* bias, void* y, int M, int N, int K,
+                      fmi_epilogue epi, void* workspace, size_t workspace_bytes, void* stream);
+int fmi_linear_i8_ws(const void* x, const int8_t* wq, const float* w_scale, const void* bias, void* y, int M, int N, int K,
+                     fmi_epilogue epi, void* workspace, size_t workspace_bytes, void* stream);
 /* The 8-bit GEMM alone on operands the caller already quantised with fmi_quantize_rows_fp8 (kind 1) / fmi_quantize_rows_i8 (kind 2):
  * y(M,N) bf16 = epi(acc(xq · wq^T) * x_scale[m] * w_scale[n] + bias); stream-ordered, no allocation (the form a caller that keeps
  * activations quantised between layers binds; also what tools/hipblaslt_yardstick.py times against the vendor library's fp8 GEMM). */
@@ -514,6 +526,14 @@ int fmi_gemm_q8(const void* xq, const float* x_scale, const void* wq, const floa
  * == backend::ops::sdpa fallback (ops.rs:247-262) without materialising the scores. */
 int fmi_sdpa_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
                   int Lk, int d, float scale, int out_token_major, void* stream);
+/* The attention kernels read V transposed (B,H,128,Lk rounded up to 64) with the kv index permuted inside groups of 16; the op-level
+ * entry points build that image first.  fmi_sdpa_bf16 / fmi_sdpa_fp8qk draw it from the device's default memory pool ON `stream`
+ * (hipMallocAsync / hipFreeAsync: ordered like a launch, no device allocation in the steady state, no host synchronisation — a host that
+ * binds ops::sdpa to them enqueues 57 calls per denoise step without ever waiting); the *_ws forms take it from the caller
+ * (fmi_sdpa_workspace_bytes(B, H, Lk) bytes, 16-byte aligned, untouched until the call's work has run on `stream`). */
+size_t fmi_sdpa_workspace_bytes(int B, int H, int Lk);
+int fmi_sdpa_bf16_ws(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int d, float scale,
+                     int out_token_major, void* workspace, size_t workspace_bytes, void* stream);
 /* Process-wide choice of the bf16 attention kernel (test / benchmark hook):
  *   5 (default) round 4's lock-step schedule of kernel 3 (attention_w16l.h: the wave's four 16-query blocks walk a KV tile together, one
  *     K / V^T fragment read feeds four MFMAs) — the arithmetic of 3 / 4; bit-identical to them when every tile rescales, equal to
@@ -528,6 +548,13 @@ int fmi_set_attention_kernel(int kind);
  * `scale` must include 1 / (q scale * k scale).  The fp8-mode attention of fmi_flux_* (fmi_flux_set_fp8_attention). */
 int fmi_sdpa_fp8qk(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
                   int Lk, int d, float scale, int out_token_major, void* stream);
+/* The one-wave fp8 streams carry the score factor scale * log2(e) in the MFMA's E8M0 block scale, so they serve factors 2^n,
+ * n = -126 .. 0; anything else runs the 8-wave kernel (slower; counted in fmi_device_info's "fp8_attention_fallbacks").  A caller that
+ * KNOWS its factor is 2^n says so as an integer: score_exp2 = n (then `scale` is not read); FMI_SDPA_NO_EXP2 = derive it from `scale`
+ * (accepted when f32(scale * log2 e) is a power of two or one ulp beside one, which is where scale = 2^n / log2(e) built in f32 lands). */
+#define FMI_SDPA_NO_EXP2 (1 << 30)
+int fmi_sdpa_fp8qk_ws(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int d, float scale,
+                      int score_exp2, int out_token_major, void* workspace, size_t workspace_bytes, void* stream);
 /* LayerNorm(eps, no affine) then x*(1+scale)+shift: x (rows,D) f32 -> out bf16;
  * scale/shift f32 (D) (layer_norm helper model.rs:33-38 + ModulationOut::scale_shift :218-221).
  * scale/shift may be NULL (plain LN). */

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -82,14 +83,169 @@ static inline float round_out(float v, int out_dtype) {
 // per k, broadcasts 6 x values against two 8-float loads of the panel row (12 FMAs per 2 loads).
 // Every y[m][n] is therefore a k-ordered f32 FMA chain per 256-deep K block, blocks added in
 // order — the same class of ordering as the reference's `gemm` 0.17.1 micro-kernels (unpinned).
+//
+// Round 5, speed only (the arithmetic of every output element is unchanged, bit for bit —
+// tests/test_oracle_kats.py::test_gemm_isa_paths_are_bit_identical): (i) the packed panels live in a
+// grow-only per-thread scratch instead of a fresh zero-filled vector per call (at 256 rows the page
+// faults of that vector cost more than the multiply); (ii) on hosts with AVX-512 (checked at run time;
+// the library itself is still built for x86-64-v3) the micro-kernel holds a 6x32 block in 12 ZMM
+// accumulators: two neighbouring 16-column panels, one ZMM each — the same chain per element, twice
+// the lanes.  orc_set_isa(1) pins the AVX2 form.
+namespace {
+constexpr int GEMM_NR = 16, GEMM_MR = 6, GEMM_KC = 256, GEMM_MC = 96, GEMM_NC = 256;
+typedef float v16f __attribute__((vector_size(64)));
+
+struct PackScratch {
+  float* p = nullptr;
+  size_t cap = 0;
+  ~PackScratch() { free(p); }
+  float* get(size_t n) {
+    if (n > cap) {
+      free(p);
+      cap = (n + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+      p = static_cast<float*>(aligned_alloc(64, cap * sizeof(float)));
+      if (!p) {
+        cap = 0;
+        fprintf(stderr, "flux_oracle: out of memory for the packed-W scratch (%zu floats)\n", n);
+        abort();
+      }
+    }
+    return p;
+  }
+};
+thread_local PackScratch g_pack;
+
+int g_isa = 0;  // bit 0: AVX2 only; bit 1: no direct few-row path (both for the bit-identity test)
+
+// one MC x NC tile: cblk[i][j] += sum over this tile's K blocks (AVX2: one 16-column panel per pass)
+void tile_avx2(const float* __restrict x, int64_t ldx, const float* __restrict wt, int K, int m0, int mb, int n0, int nb,
+               float (*__restrict cblk)[GEMM_NC]) {
+  const int NR = GEMM_NR, MR = GEMM_MR, KC = GEMM_KC;
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    const int kb = std::min(KC, K - k0);
+    for (int jr = 0; jr < nb; jr += NR) {
+      const float* bp = wt + ((size_t)((n0 + jr) / NR) * K + k0) * NR;
+      for (int ir = 0; ir < mb; ir += MR) {
+        const int ib = std::min(MR, mb - ir);
+        v8f c[MR][2];
+        for (int a = 0; a < MR; ++a) c[a][0] = c[a][1] = (v8f){0, 0, 0, 0, 0, 0, 0, 0};
+        const float* xr[MR];
+        for (int a = 0; a < MR; ++a) xr[a] = x + (int64_t)(m0 + ir + std::min(a, ib - 1)) * ldx + k0;
+        for (int k = 0; k < kb; ++k) {
+          v8f b0, b1;
+          memcpy(&b0, bp + (size_t)k * NR, 32);
+          memcpy(&b1, bp + (size_t)k * NR + 8, 32);
+          for (int a = 0; a < MR; ++a) {
+            const float s = xr[a][k];
+            const v8f av = {s, s, s, s, s, s, s, s};
+            c[a][0] += av * b0;
+            c[a][1] += av * b1;
+          }
+        }
+        for (int a = 0; a < ib; ++a)
+          for (int e = 0; e < 8; ++e) {
+            cblk[ir + a][jr + e] += c[a][0][e];
+            cblk[ir + a][jr + 8 + e] += c[a][1][e];
+          }
+      }
+    }
+  }
+}
+
+// the same tile with 512-bit registers: a pass covers two neighbouring panels (32 columns), one ZMM per panel and row; a last odd
+// panel runs alone.  Per output element: the same k-ordered FMA chain per K block, the same block-sum order.
+__attribute__((target("avx512f"))) void tile_avx512(const float* __restrict x, int64_t ldx, const float* __restrict wt, int K, int m0, int mb,
+                                                     int n0, int nb, float (*__restrict cblk)[GEMM_NC]) {
+  const int NR = GEMM_NR, MR = GEMM_MR, KC = GEMM_KC;
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    const int kb = std::min(KC, K - k0);
+    for (int jr = 0; jr < nb; jr += 2 * NR) {
+      const bool two = jr + NR < nb;
+      const float* bp0 = wt + ((size_t)((n0 + jr) / NR) * K + k0) * NR;
+      const float* bp1 = two ? bp0 + (size_t)K * NR : bp0;
+      for (int ir = 0; ir < mb; ir += MR) {
+        const int ib = std::min(MR, mb - ir);
+        v16f c[MR][2];
+        for (int a = 0; a < MR; ++a)
+          for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 16; ++e) c[a][h][e] = 0.f;
+        const float* xr[MR];
+        for (int a = 0; a < MR; ++a) xr[a] = x + (int64_t)(m0 + ir + std::min(a, ib - 1)) * ldx + k0;
+        if (two) {
+          for (int k = 0; k < kb; ++k) {
+            v16f b0, b1;
+            memcpy(&b0, bp0 + (size_t)k * NR, 64);
+            memcpy(&b1, bp1 + (size_t)k * NR, 64);
+            for (int a = 0; a < MR; ++a) {
+              const float s = xr[a][k];
+              const v16f av = {s, s, s, s, s, s, s, s, s, s, s, s, s, s, s, s};
+              c[a][0] += av * b0;
+              c[a][1] += av * b1;
+            }
+          }
+        } else {
+          for (int k = 0; k < kb; ++k) {
+            v16f b0;
+            memcpy(&b0, bp0 + (size_t)k * NR, 64);
+            for (int a = 0; a < MR; ++a) {
+              const float s = xr[a][k];
+              const v16f av = {s, s, s, s, s, s, s, s, s, s, s, s, s, s, s, s};
+              c[a][0] += av * b0;
+            }
+          }
+        }
+        for (int a = 0; a < ib; ++a)
+          for (int e = 0; e < 16; ++e) {
+            cblk[ir + a][jr + e] += c[a][0][e];
+            if (two) cblk[ir + a][jr + 16 + e] += c[a][1][e];
+          }
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" void orc_set_isa(int isa) { g_isa = isa; }
+extern "C" int orc_get_isa(void) { return (!(g_isa & 1) && __builtin_cpu_supports("avx512f")) ? 512 : 256; }
+
 static void gemm_nt(const float* __restrict x, int64_t ldx, const float* __restrict w, int64_t ldw,
                     const float* bias, int M, int N, int K, float* __restrict y, int64_t ldy, float alpha) {
-  const int NR = 16, MR = 6, KC = 256, MC = 96, NC = 256;
+  const int NR = GEMM_NR, MC = GEMM_MC, NC = GEMM_NC;
+  if (M <= 4 && !(g_isa & 2)) {
+    // Few rows (the modulation / embedder linears at batch 1: 13 GB of f32 weights per model evaluation): packing W would move three
+    // times the bytes the product needs.  Each output is computed straight from its W row as the SAME chain the micro-kernel runs for
+    // it — fma over k inside a 256-deep block starting from 0, block sums added in order — eight rows at a time for latency.
+#pragma omp parallel for schedule(static)
+    for (int n0 = 0; n0 < N; n0 += 8) {
+      const int nb = std::min(8, N - n0);
+      for (int m = 0; m < M; ++m) {
+        const float* xr = x + (int64_t)m * ldx;
+        float tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k0 = 0; k0 < K; k0 += GEMM_KC) {
+          const int kb = std::min(GEMM_KC, K - k0);
+          float c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          const float* wr[8];
+          for (int j = 0; j < 8; ++j) wr[j] = w + (int64_t)(n0 + std::min(j, nb - 1)) * ldw + k0;
+          for (int k = 0; k < kb; ++k) {
+            const float s = xr[k0 + k];
+            for (int j = 0; j < 8; ++j) c[j] = __builtin_fmaf(s, wr[j][k], c[j]);
+          }
+          for (int j = 0; j < 8; ++j) tot[j] += c[j];
+        }
+        for (int j = 0; j < nb; ++j) {
+          float v = tot[j] * alpha;
+          if (bias) v += bias[n0 + j];
+          y[(int64_t)m * ldy + n0 + j] = v;
+        }
+      }
+    }
+    return;
+  }
   const int npan = (N + NR - 1) / NR;
-  std::vector<float> wt((size_t)npan * K * NR);
+  float* const wt = g_pack.get((size_t)npan * K * NR);
 #pragma omp parallel for schedule(static)
   for (int p = 0; p < npan; ++p) {
-    float* dst = wt.data() + (size_t)p * K * NR;
+    float* dst = wt + (size_t)p * K * NR;
     for (int j = 0; j < NR; ++j) {
       const int n = p * NR + j;
       if (n < N) {
@@ -100,6 +256,7 @@ static void gemm_nt(const float* __restrict x, int64_t ldx, const float* __restr
       }
     }
   }
+  const bool use512 = orc_get_isa() == 512;
   const int mt = (M + MC - 1) / MC, nt = (N + NC - 1) / NC;
 #pragma omp parallel for collapse(2) schedule(dynamic, 1)
   for (int tm = 0; tm < mt; ++tm) {
@@ -109,35 +266,10 @@ static void gemm_nt(const float* __restrict x, int64_t ldx, const float* __restr
       float cblk[MC][NC];
       for (int i = 0; i < mb; ++i)
         for (int j = 0; j < NC; ++j) cblk[i][j] = 0.f;
-      for (int k0 = 0; k0 < K; k0 += KC) {
-        const int kb = std::min(KC, K - k0);
-        for (int jr = 0; jr < nb; jr += NR) {
-          const float* bp = wt.data() + ((size_t)((n0 + jr) / NR) * K + k0) * NR;
-          for (int ir = 0; ir < mb; ir += MR) {
-            const int ib = std::min(MR, mb - ir);
-            v8f c[MR][2];
-            for (int a = 0; a < MR; ++a) c[a][0] = c[a][1] = (v8f){0, 0, 0, 0, 0, 0, 0, 0};
-            const float* xr[MR];
-            for (int a = 0; a < MR; ++a) xr[a] = x + (int64_t)(m0 + ir + std::min(a, ib - 1)) * ldx + k0;
-            for (int k = 0; k < kb; ++k) {
-              v8f b0, b1;
-              memcpy(&b0, bp + (size_t)k * NR, 32);
-              memcpy(&b1, bp + (size_t)k * NR + 8, 32);
-              for (int a = 0; a < MR; ++a) {
-                const float s = xr[a][k];
-                const v8f av = {s, s, s, s, s, s, s, s};
-                c[a][0] += av * b0;
-                c[a][1] += av * b1;
-              }
-            }
-            for (int a = 0; a < ib; ++a)
-              for (int e = 0; e < 8; ++e) {
-                cblk[ir + a][jr + e] += c[a][0][e];
-                cblk[ir + a][jr + 8 + e] += c[a][1][e];
-              }
-          }
-        }
-      }
+      if (use512)
+        tile_avx512(x, ldx, wt, K, m0, mb, n0, nb, cblk);
+      else
+        tile_avx2(x, ldx, wt, K, m0, mb, n0, nb, cblk);
       for (int i = 0; i < mb; ++i)
         for (int j = 0; j < nb; ++j) {
           float v = cblk[i][j] * alpha;

@@ -94,6 +94,16 @@ def get_threads():
     return lib().orc_get_threads()
 
 
+def set_isa(isa=0):
+    """GEMM paths (same bits whichever runs): 0 = widest micro-kernel the host has (AVX-512 where available) and the direct few-row
+    path; bit 0 = the AVX2 micro-kernel; bit 1 = launches of <= 4 rows through the packed path too."""
+    lib().orc_set_isa(int(isa))
+
+
+def get_isa():
+    return lib().orc_get_isa()
+
+
 def linear(x, w, b=None):
     x, xp = _f(x)
     w, wp = _f(w)

@@ -311,6 +311,80 @@ def test_c5_shape_1280x720_bf16_forward_of_the_full_model_matches_oracle(full_mo
     full_models["c5"] = (img, ids, t5, txt_ids, t, clip, g, ref)  # the int8 test measures its mode on this ragged shape too
 
 
+def _decode_u8(d, orc, gv, ov, lat_gpu, lat_ref, h, w):
+    """latents (1, S, 64) -> unpack + affine -> the real-config VAE -> u8, on the GPU for `lat_gpu` and in the oracle for `lat_ref`
+    (pipelines/flux/mod.rs:320-332)."""
+    import torch
+    sf, sh = d.VAE_FLUX["scaling_factor"], d.VAE_FLUX["shift_factor"]
+    z_g = d.unpack_latents(torch.from_numpy(lat_gpu).cuda(), 16, h, w, sf, sh)
+    u_g = d.postprocess_u8(gv.decode(z_g)).cpu().numpy()
+    z_r = orc.unpack_latents(lat_ref, 16, h, w) * np.float32(1.0 / sf) + np.float32(sh)
+    u_r = orc.postprocess_u8(ov.decode(z_r.astype(np.float32)))
+    diff = np.abs(u_g.astype(np.int32) - u_r.astype(np.int32))
+    return int(diff.max()), float((diff <= 2).mean()), u_r
+
+
+TRAJ_MARKS = (10, 25, 50)
+# what the int8 mode is held to over the 50 steps (stated after measuring, DESIGN 5): the bar of the 8-bit modes on the latents at every mark
+INT8_TRAJ_BAR = 3e-2
+INT8_TRAJ_U8_BAR = 0.95
+
+
+def test_c2_fifty_step_trajectory_of_the_full_model_matches_oracle(full_models):
+    """The headline metric is a 50-STEP image (VERDICT r4 item 1): `Sampler::sample` (pipelines/sampling.rs:25-48) around the step
+    closure (pipelines/flux/mod.rs:305-332) for FLUX.1-dev at its true width and depth — D = 3072, 19 + 38 blocks, every block its
+    own weights — over the REAL 50-step dynamic-shift schedule, guidance 3.5, against the f32 oracle's 50 steps.  Token count chosen so
+    that the oracle's 50 model evaluations fit the suite: a 192 x 256 image, S = 192 image + T = 64 text tokens (3.4e12 FLOP per step).
+    The GPU runs the production path — fmi_flux_denoise, all 50 modulation rows through ONE GEMM over the 6.5 GB matrix, f32 latents —
+    and is stopped after 10, 25 and 50 steps (three calls from the same start) to show how the distance to the oracle's trajectory
+    grows.  Bars: latents rel-L2 <= 3e-2 at every mark; the u8 image after the real-config VAE decode (16 x 24 x 32
+    latent -> 192 x 256 pixels) within 2 of the oracle's on >= 99 % of the values."""
+    if not full_models["wide"]:
+        pytest.skip("the host cannot hold the oracle's 48 GB of f32 weights")
+    torch, d, orc, gm, om = (full_models[k] for k in ("torch", "d", "orc", "gm_dev", "om"))
+    cfg = dict(d.FLUX_DEV)
+    h, w, T = 24, 32, 64
+    rng = np.random.default_rng(90)
+    lat = rng.standard_normal((1, 16, h, w)).astype(np.float32)
+    t5 = bf16_round(rng.standard_normal((1, T, cfg["joint_attention_dim"])).astype(np.float32))
+    clip = rng.standard_normal((1, cfg["pooled_projection_dim"])).astype(np.float32)
+    img, ids = orc.pack_latents(lat)
+    S = img.shape[1]
+    assert S == 192
+    txt_ids = np.zeros((1, T, 3), np.float32)
+    g = np.array([3.5], np.float32)
+    # the schedule from the ORACLE's restatement (flux/sampling.rs:70-80, scheduler.rs:22-51); the product's must be the same numbers
+    ts = [float(v) for v in orc.get_timesteps(50, True, orc.calculate_shift(S), 1.0)]
+    sched = d.SchedulerConfig()
+    assert len(ts) == 51 and np.abs(np.array(sched.get_timesteps(50, sched.calculate_shift(S))) - np.array(ts)).max() <= 1e-15
+    args = (dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(clip), dev(g))
+    got = {n: host(gm.denoise(dev(img), *args, ts[:n + 1])) for n in TRAJ_MARKS}
+    t0 = time.time()
+    ref, cur, at = {}, img, 0
+    for n in TRAJ_MARKS:  # the oracle's ONE trajectory, read out at the marks
+        cur = om.denoise(cur, ids, t5, txt_ids, clip, g, ts[at:n + 1])
+        ref[n], at = cur.copy(), n
+    t_or = time.time() - t0
+    drift = {n: rel_l2(got[n], ref[n]) for n in TRAJ_MARKS}
+    moved = {n: rel_l2(ref[n], img) for n in TRAJ_MARKS}
+    print("C2 trajectory in full (FLUX.1-dev, D=3072, 19+38 blocks, S=192 + T=64, the real 50-step schedule), bf16: latents rel-L2 vs the f32 oracle after "
+          + ", ".join(f"{n} steps {drift[n]:.3e} (moved {moved[n]:.2f})" for n in TRAJ_MARKS) + f"  (oracle {t_or:.0f} s)")
+    for n in TRAJ_MARKS:
+        assert np.isfinite(got[n]).all() and drift[n] <= 3e-2, (n, drift[n])
+    # the image: real-config VAE decode + u8 on both sides
+    vsd = d.synth.vae_state_dict_numpy(d.VAE_FLUX, seed=4)
+    gv, ov = d.AutoEncoderKl(d.VAE_FLUX), orc.Vae(d.VAE_FLUX)
+    gv.load_state_dict(vsd)
+    ov.load(vsd)
+    mx, frac, u_ref = _decode_u8(d, orc, gv, ov, got[50], ref[50], h, w)
+    mx_v, frac_v, _ = _decode_u8(d, orc, gv, ov, ref[50], ref[50], h, w)  # the decoder's own share: the GPU VAE on the ORACLE's latents
+    sat = float(((u_ref == 0) | (u_ref == 255)).mean())
+    print(f"  u8 image after 50 steps + VAE (192 x 256): max |d| {mx}, within 2 on {frac:.4%} (the VAE alone on the oracle's latents: max {mx_v}, {frac_v:.4%}; "
+          f"{sat:.1%} of the oracle's values saturated)")
+    assert frac >= 0.99
+    full_models["traj50"] = dict(img=img, ids=ids, t5=t5, txt_ids=txt_ids, clip=clip, g=g, ts=ts, ref=ref, hw=(h, w), gv=gv, ov=ov, bf16=drift)
+
+
 def test_batch_of_8_at_full_size_equals_the_samples_run_alone(full_models):
     """`Pipeline.MAX_BATCH` = 8 at the headline shape: FLUX.1-dev in full, 8 samples x (4096 + 512) tokens in ONE denoise call (36 864
     rows per launch, a 1.6 GB fused-projection buffer, 8 x 3 = 24 rows in the modulation precompute) — every row of every kernel is
@@ -448,6 +522,18 @@ def test_c2_int8_full_model_forward_is_within_the_8_bit_tolerance(full_models):
             e2, eu = rel_l2(got2, ref2), rel_l2(got2 - img, ref2 - img)
             print(f"  2 Euler steps in int8 mode vs the f32 oracle's: latents {e2:.3e}, update alone {eu:.3e}")
             assert np.isfinite(got2).all() and e2 <= 3e-2 and eu <= 3e-2
+        if "traj50" in full_models:  # the 50-step trajectory in int8 mode against the ORACLE's (f32), not against the bf16 path's
+            tj = full_models["traj50"]
+            a8 = (dev(tj["ids"]), dev(tj["t5"], torch.bfloat16), dev(tj["txt_ids"]), dev(tj["clip"]), dev(tj["g"]))
+            g50 = {n: host(g8.denoise(dev(tj["img"]), *a8, tj["ts"][:n + 1])) for n in TRAJ_MARKS}
+            d8 = {n: rel_l2(g50[n], tj["ref"][n]) for n in TRAJ_MARKS}
+            mx8, frac8, _ = _decode_u8(d, orc, tj["gv"], tj["ov"], g50[50], tj["ref"][50], *tj["hw"])
+            print("  50-step trajectory (S=192 + T=64) in int8 mode vs the f32 oracle: latents after "
+                  + ", ".join(f"{n} steps {d8[n]:.3e} (bf16: {tj['bf16'][n]:.3e})" for n in TRAJ_MARKS)
+                  + f"; u8 image max |d| {mx8}, within 2 on {frac8:.4%}")
+            for n in TRAJ_MARKS:
+                assert np.isfinite(g50[n]).all() and d8[n] <= INT8_TRAJ_BAR, (n, d8[n])
+            assert frac8 >= INT8_TRAJ_U8_BAR
         if "c5" in full_models:  # BASELINE configs[4]'s shape (4112 tokens: ragged GEMM row tiles, a 16-row last query block, a 16-key last KV tile) in int8 mode
             i5, d5, t55, x5, tt5, c5, g5, r5 = full_models["c5"]
             got5 = host(g8.forward(dev(i5), dev(d5), dev(t55, torch.bfloat16), dev(x5), dev(tt5), dev(c5), dev(g5)))

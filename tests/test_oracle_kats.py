@@ -184,3 +184,34 @@ def test_division_by_127_as_reciprocal_plus_newton_step_is_correctly_rounded():
     x = bits.view(np.float32)
     x = x[np.isfinite(x) & (np.abs(x) >= np.float32(2.0) ** -100) & (np.abs(x) <= np.float32(2.0) ** 120)]
     np.testing.assert_array_equal(div127(x).view(np.uint32), (x / np.float32(127.0)).astype(np.float32).view(np.uint32))
+
+
+def test_gemm_isa_paths_are_bit_identical():
+    """The oracle's GEMM picks a 512-bit micro-kernel on hosts that have AVX-512 (round 5: speed only).  Every output element must be the
+    same f32 FMA chain as in the AVX2 form — ragged rows, an odd number of 16-column panels, K not a multiple of the 256-deep block."""
+    rng = np.random.default_rng(11)
+    try:
+        for (M, N, K) in ((1, 48, 64), (7, 3, 27), (97, 272, 300), (256, 1040, 513), (13, 16, 1024)):
+            x = rng.standard_normal((M, K)).astype(np.float32)
+            w = rng.standard_normal((N, K)).astype(np.float32)
+            b = rng.standard_normal(N).astype(np.float32)
+            orc.set_isa(1)
+            assert orc.get_isa() == 256
+            a = orc.linear(x, w, b)
+            orc.set_isa(0)
+            c = orc.linear(x, w, b)
+            assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), (M, N, K, orc.get_isa())
+            ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+            assert np.abs(a - ref).max() <= 1e-4 * np.abs(ref).max()
+        # few rows (M <= 4): computed straight from the W rows, no packing — the same chain per output
+        for (M, N, K) in ((1, 100, 700), (4, 19, 256), (3, 64, 3072)):
+            x = rng.standard_normal((M, K)).astype(np.float32)
+            w = rng.standard_normal((N, K)).astype(np.float32)
+            b = rng.standard_normal(N).astype(np.float32)
+            orc.set_isa(3)  # AVX2 micro-kernel, packed path
+            a = orc.linear(x, w, b)
+            orc.set_isa(0)
+            c = orc.linear(x, w, b)
+            assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), (M, N, K)
+    finally:
+        orc.set_isa(0)
