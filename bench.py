@@ -176,7 +176,7 @@ def main():
     ap.add_argument("--txt-tokens", type=int, default=512)
     ap.add_argument("--quant", choices=["none", "nf4", "fp8", "int8"], default="none",
                     help="nf4: block linears stored bitsandbytes-nf4, fused dequant-GEMM (config C3); fp8: block linears on the e4m3 MFMA path (config C5); "
-                         "int8: the int8 MFMA on the default linear mask (all but the double blocks' MLP), bf16 attention")
+                         "int8: the int8 MFMA on the default linear mask (all but the double blocks' MLP); both 8-bit modes hand q and k to the attention as e4m3 (static scales), P.V stays bf16")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU per image step (C5: 2)")
     ap.add_argument("--sequence-parallel", action="store_true",
                     help="N > 1: all ranks denoise ONE image together (token shards, two all-to-alls per block; strong scaling) instead of one image each")
@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from profiles/pmc_summary_latest.json instead of two rocprofv3 --pmc passes of a short child run (~1 min)")
     ap.add_argument("--cpu-baseline-tokens", type=int, default=0, help="override L of the CPU sample (debug)")
+    ap.add_argument("--cpu-baseline-budget-s", type=float, default=300.0,
+                    help="host seconds the default run may spend on the whole-step CPU sample (estimated from a probe GEMM); beyond it the two-block sample is used")
     ap.add_argument("--cpu-baseline-blocks", action="store_true",
                     help="cpu_baseline from one double + one single block (round 3's bounded sample) instead of one WHOLE C2 step on the full f32 model "
                          "(the default when the host has the memory for its 48 GB of weights)")
@@ -526,13 +528,19 @@ def main():
         flux.set_fp8_attention(1)
         fq = d.FluxModel(d.FLUX_DEV, local_rank)
         fill_flux(fq, "nf4")
-        # default policy (flux_model.hip: densify): only the packed codes are resident; the block linears (launches above 383 rows) expand per call
+        # opt-in policy (fmi_flux_set_quant_dense_cache(0)): only the packed codes are resident; the block linears (launches above 383 rows) expand per call
         # into a 264 MB scratch (stand-alone dequant kernel) and run the dense GEMM, smaller launches multiply from the packed codes
-        leg(fq, wl, "nf4_c3", "dequant4_kernel + gemm_pp_kernel (nf4 block linears expanded per call into a scratch, then the dense bf16 MFMA GEMM; "
+        fq.set_quant_dense_cache(0)
+        leg(fq, wl, "nf4_c3_packed", "dequant4_kernel + gemm_pp_kernel (nf4 block linears expanded per call into a scratch, then the dense bf16 MFMA GEMM; "
             "the expansions are inside the timed phases; dense-equivalent FLOPs)", 2500.0,
             "bf16 MFMA on nf4 weights (bitsandbytes blocksize 64; every block + modulation linear packed; no bf16 copy resident)")
-        # (round 2 also timed every launch on the fused dequant-GEMM, fmi_flux_set_quant_dense_cache(2): 85-86 ms per step against 68-69
-        # for this policy and the same bits — DESIGN 4.5 states the per-call policy as final, the leg was dropped in round 3)
+        # default policy since round 5 (by memory, flux_model.hip: resolve_quant_mode): on a part with the room the block matrices of the large launches are
+        # expanded ONCE (BnbLinear::forward's "dequantise, then matmul" without repeating the first half 228 times per step); the 6.5 GB modulation matrix and
+        # every launch of up to 383 rows keep multiplying from the packed codes.  Same bits as the packed policy.
+        fq.set_quant_dense_cache(-1)
+        leg(fq, wl, "nf4_c3", "gemm_pp_kernel on nf4 block linears expanded once into the bf16 arena (+16 GB; the modulation matrix and small launches stay on the "
+            "fused dequant-GEMM); dense-equivalent FLOPs", 2500.0,
+            "bf16 MFMA on nf4 weights (bitsandbytes blocksize 64): packed codes + one expanded copy of the block matrices resident (the default when HBM allows)")
         fq.close()
         del fq
         # int8 mode (round 4): its own handle (bf16 weights + int8 codes of the masked linears), default mask = all but the double blocks' MLP
@@ -541,7 +549,7 @@ def main():
         fi.quantize_int8()
         leg(fi, wl, "int8_1024", KDESC["int8"], 5000.0,
             "int8 block linears (symmetric per-channel weight / per-token activation scales, exact int32 accumulate) for double q|k|v + attention out and single "
-            "linear1 + linear2; the double blocks' MLP, the attention and everything else bf16; f32 residual stream")
+            "linear1 + linear2; attention with e4m3 q / k operands (static per-block scales, QK^T on the fp8 MFMA) and bf16 P.V; the double blocks' MLP and everything else bf16; f32 residual stream")
         leg(fi, wl_c5, "int8_c5_shape", KDESC["int8"], 5000.0, "as int8_1024 (BASELINE configs[4]'s shape, 1280x720 batch 2, in the 8-bit mode that is within tolerance)")
         fi.close()
         del fi
@@ -550,9 +558,61 @@ def main():
         leg(flux, wl, "fp8_1024", KDESC["fp8"], 5000.0, fp8_dtype)  # the headline workload (1024x1024, batch 1) in fp8 mode
         leg(flux, wl_c5, "fp8_c5_shape", KDESC["fp8"], 5000.0, fp8_dtype)
 
+    if rank == 0:
+        ms_per_image = elapsed / args.steps * 1e3
+        total_images = args.steps * B * (1 if spg is not None else world)
+        out = {
+            "metric": "images/sec, FLUX.1-dev 1024x1024 50-step" if (H, W, NS) == (1024, 1024, 50) else f"images/sec, FLUX.1-dev {W}x{H} {NS}-step",
+            "value": total_images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "strong" if spg is not None else "weak", "vs_baseline": None, "dtype": {"none": "bf16", "nf4": "bf16 MFMA on nf4 weights (fused dequant-GEMM, packed weights only)",
+                                                                                                                 "fp8": "fp8 e4m3 block linears (per-channel weight / per-token activation scales, f32 accumulate); attention: e4m3 q / k operands with static per-block scales (QK^T on the fp8 MFMA), bf16 P.V; f32 residual stream",
+                                                                                                                 "int8": "int8 block linears on the default mask (per-channel / per-token scales, exact int32 accumulate); attention: e4m3 q / k operands with static per-block scales (QK^T on the fp8 MFMA), bf16 P.V; the double blocks' MLP and everything else bf16, f32 residual stream"}[args.quant],
+            "data": "synthetic (random-init FLUX.1-dev + FLUX VAE weights, N(0,1) embeddings, Philox latents)",
+            "config": {"workload": f"FLUX.1-dev {args.quant if args.quant in ('fp8', 'int8') else 'bf16'} {W}x{H} {NS}-step, batch={B} per GPU, S={S} img + T={T} txt tokens, step = one image "
+                                   "(50x Flux::forward + Euler, unpack, VAE decode, u8)",
+                       "global_batch": B if spg is not None else world * B,
+                       "parallelism": (f"sequence-parallel x{world} (one image on all ranks{', split-K latency mode' if args.split_k else ''})" if spg is not None
+                                       else f"batch-sharded x{world}" if world > 1 else "single GPU")},
+            "ms_per_denoise_step": round((ms_per_image - extra.get("vae_decode_ms", 0.0)) / NS, 2),
+            "ms_per_image": round(ms_per_image, 1),
+            "output_ok": finite, "load_s": round(load_s, 1), "weights_generated_s": round(gen_s, 1),
+            "roofline": roof, "cpu_baseline": None,
+        }
+        out["ms_per_step_per_rank"] = [round(x, 1) for x in per_rank_ms]
+        out["build_id"] = lib.fmi_build_id().decode()
+        if image_crc is not None:
+            out["image_crc32"] = image_crc
+        if args.as_rank is not None:
+            out["drawn_as"] = {"rank": args.as_rank, "world": args.as_world}
+        if world > 1:
+            out["rccl_ranks"] = world
+            out["backend"] = backend
+            out["broadcast_s"] = round(bcast["seconds"], 2)
+            out["broadcast_gib"] = round(bcast["bytes"] / 2**30, 2)
+            out["broadcast_messages"] = bcast["messages"]
+            if gather_ms is not None:
+                out["gather_ms"] = round(gather_ms, 2)
+            if spg is not None:
+                out["exchanges"] = spg.exchanges
+                out["exchange_gb_sent_rank0"] = round(spg.bytes_sent / 1e9, 2)
+        if secondary is not None:
+            out["secondary"] = secondary
+        out.update(extra)
+        # The GPU figures are complete here.  They go to stderr (and to gpurun_out/bench_gpu_line.json when that directory exists) BEFORE the CPU
+        # baseline starts — minutes of host work that can be OOM-killed — and to stdout as THE one JSON line once the baseline has been added.
+        sys.stderr.write("[bench] GPU line (cpu_baseline pending): " + json.dumps(out) + "\n")
+        sys.stderr.flush()
+        try:
+            if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+                with open(os.path.join(ROOT, "gpurun_out", "bench_gpu_line.json"), "w") as f:
+                    json.dump(out, f)
+        except OSError:
+            pass
+
     # ---------------- CPU baseline (rank 0, N=1 only): oracle = port of the reference CPU semantics
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+      try:  # (a host-side failure of the reported baseline must not take the measured GPU line with it: ADVICE r4)
         from oracle import oracle as orc
 
         orc.set_threads(orc.usable_cpus())  # affinity capped by the cgroup CPU quota (16 of the box's 256 logical CPUs)
@@ -585,6 +645,19 @@ def main():
         Dh = D_HID
         rng = np.random.default_rng(0)
         whole = not args.cpu_baseline_blocks and not args.cpu_baseline_tokens and (H, W, B) == (1024, 1024, 1) and host_mem_gib() >= 100
+        if whole:
+            # bounded by a time budget: a probe GEMM at the step's dominant shape class prices the whole-step sample (model build + one
+            # Flux::forward + the C1 run) before 48 GB are built for it; over budget -> the two-block sample below
+            px, pw = rng.standard_normal((2048, Dh), dtype=np.float32), rng.standard_normal((Dh, Dh), dtype=np.float32)
+            orc.linear(px, pw)
+            tp = time.perf_counter()
+            orc.linear(px, pw)
+            rate = 2.0 * 2048 * Dh * Dh / (time.perf_counter() - tp)
+            est_s = 30.0 + 1.2 * (step_flops(S, T)["total"] + 4 * step_flops(256, 256)["total"]) / rate
+            if est_s > args.cpu_baseline_budget_s:
+                sys.stderr.write(f"[bench] whole-step CPU sample estimated at {est_s:.0f} s > --cpu-baseline-budget-s {args.cpu_baseline_budget_s}: using the two-block sample\n")
+                whole = False
+            del px, pw
         if whole:
             # ONE WHOLE denoise step of the headline config on the oracle: the full FLUX.1-dev (19 + 38 blocks, every block its own
             # weights: the values rank 0 generated for the GPU, regenerated from the same seed and widened to f32 = 48 GB on the host),
@@ -712,46 +785,13 @@ def main():
         if cpu.get("value") is None:  # (whole-step sample without the C1 leg: the VAE by FLOPs at the DiT's rate)
             cpu["value"] = 1.0 / (cpu["step_seconds"] * NS * (1.0 + vae_flops(h, w) / (step_flops(S, T)["total"] * NS)))
 
+      except Exception as e:  # noqa: BLE001 — reported, not raised
+        import traceback
+        traceback.print_exc()
+        cpu = {"value": None, "unit": "images/s", "cores": None, "kind": "port", "sample": f"the CPU baseline failed on this host: {type(e).__name__}: {e}"}
+
     if rank == 0:
-        ms_per_image = elapsed / args.steps * 1e3
-        total_images = args.steps * B * (1 if spg is not None else world)
-        out = {
-            "metric": "images/sec, FLUX.1-dev 1024x1024 50-step" if (H, W, NS) == (1024, 1024, 50) else f"images/sec, FLUX.1-dev {W}x{H} {NS}-step",
-            "value": total_images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "strong" if spg is not None else "weak", "vs_baseline": None, "dtype": {"none": "bf16", "nf4": "bf16 MFMA on nf4 weights (fused dequant-GEMM, packed weights only)",
-                                                                                                                 "fp8": "fp8 e4m3 block linears (per-channel weight / per-token activation scales, f32 accumulate), bf16 attention, f32 residual stream",
-                                                                                                                 "int8": "int8 block linears on the default mask (per-channel / per-token scales, exact int32 accumulate), the rest bf16, f32 residual stream"}[args.quant],
-            "data": "synthetic (random-init FLUX.1-dev + FLUX VAE weights, N(0,1) embeddings, Philox latents)",
-            "config": {"workload": f"FLUX.1-dev {args.quant if args.quant in ('fp8', 'int8') else 'bf16'} {W}x{H} {NS}-step, batch={B} per GPU, S={S} img + T={T} txt tokens, step = one image "
-                                   "(50x Flux::forward + Euler, unpack, VAE decode, u8)",
-                       "global_batch": B if spg is not None else world * B,
-                       "parallelism": (f"sequence-parallel x{world} (one image on all ranks{', split-K latency mode' if args.split_k else ''})" if spg is not None
-                                       else f"batch-sharded x{world}" if world > 1 else "single GPU")},
-            "ms_per_denoise_step": round((ms_per_image - extra.get("vae_decode_ms", 0.0)) / NS, 2),
-            "ms_per_image": round(ms_per_image, 1),
-            "output_ok": finite, "load_s": round(load_s, 1), "weights_generated_s": round(gen_s, 1),
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        out["ms_per_step_per_rank"] = [round(x, 1) for x in per_rank_ms]
-        out["build_id"] = lib.fmi_build_id().decode()
-        if image_crc is not None:
-            out["image_crc32"] = image_crc
-        if args.as_rank is not None:
-            out["drawn_as"] = {"rank": args.as_rank, "world": args.as_world}
-        if world > 1:
-            out["rccl_ranks"] = world
-            out["backend"] = backend
-            out["broadcast_s"] = round(bcast["seconds"], 2)
-            out["broadcast_gib"] = round(bcast["bytes"] / 2**30, 2)
-            out["broadcast_messages"] = bcast["messages"]
-            if gather_ms is not None:
-                out["gather_ms"] = round(gather_ms, 2)
-            if spg is not None:
-                out["exchanges"] = spg.exchanges
-                out["exchange_gb_sent_rank0"] = round(spg.bytes_sent / 1e9, 2)
-        if secondary is not None:
-            out["secondary"] = secondary
-        out.update(extra)
+        out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
         dist.barrier()  # rank 0 ran the (untimed) profiled pass meanwhile: leave together

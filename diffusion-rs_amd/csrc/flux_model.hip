@@ -137,7 +137,11 @@ struct fmi_flux {
   // Opt-in cache (fmi_flux_set_quant_dense_cache(1)): expand ONCE into the layer's slot of the BLOCKS arena — allocated
   // on first use, 17 GB more — and run the dense kernels.
   bool dense_cache = false;
-  int quant_mode = 0;  // 0: by size (fused below the row thresholds of densify(), per-call expansion above); 1: dense cache; 2: always fused
+  // fmi_flux_set_quant_dense_cache.  -1 (default): 3 if the device has the room when the first large quantised launch comes, else 0.
+  // 0: packed only — fused below the row thresholds of densify(), per-call expansion into a scratch above; 1: dense cache (every matrix
+  // expanded once); 2: always fused; 3: by size like 0, but a matrix that 0 would expand per call is expanded ONCE into its dense slot
+  // (the small launches keep multiplying from the packed codes: the 50-row modulation GEMM reads 1.8 GB instead of 6.5)
+  int quant_mode = -1;
   std::set<const void*> dense_ready;
   bf16_t* wscratch[2] = {nullptr, nullptr};  // per-call expansion of quantised matrices at large M (densify)
   size_t wscratch_elems = 0;
@@ -167,6 +171,7 @@ struct fmi_flux {
   // QkNorm'ed, rotated head vector has norm sqrt(128) * |w|, so no element can exceed the e4m3 range
   int fp8_attn = 1;  // 0 off, 1 on in the 8-bit modes, 2 on in bf16 mode too (fmi_flux_set_fp8_attention)
   std::vector<float> q8_dbl, k8_dbl, q8_sgl, k8_sgl;
+  bool attn_scales_valid = false;  // set by compute_attention_scales on success only; cleared whenever a weight can have changed (set_tensor, state_adopt)
   std::vector<int> n8_dbl, n8_sgl;  // fp8 attention: softmax_scale * log2(e) / (q8 * k8) == 2^-n8 EXACTLY (q_scale_pow2); handed to the attention as an integer
 };
 
@@ -188,6 +193,7 @@ int ensure_arena(fmi_flux* m, int ar) {
   hipError_t e = hipMalloc((void**)&a.base, a.bytes);
   if (e != hipSuccess) return fail(FMI_ERR_NOMEM, "flux: hipMalloc of " + std::to_string(a.bytes) + " bytes (weight arena " + std::to_string(ar) + ") failed: " + hipGetErrorString(e));
   FMI_HIP_TRY(hipMemset(a.base, 0, a.bytes));
+  FMI_HIP_TRY(hipDeviceSynchronize());  // (an arena can appear in the middle of a forward — the expand-once policy — on a stream the null stream does not order)
   for (Dense* d : m->fused) {
     if (ar == d->ar) d->w = reinterpret_cast<bf16_t*>(a.base + d->w_off);
     if (ar == AR_Q4 && !d->q_own) {
@@ -529,11 +535,24 @@ void with_gate(GemmProblem& p, const float* gate, int rows_per_batch, int bstrid
 // bytes and the packed read wins).  Either way only the packed codes are resident.
 constexpr int INT8_FUSED_MAX_ROWS = 256;
 constexpr int Q4_FUSED_MAX_ROWS = 383;
+// The default policy follows the memory: BnbLinear::forward is "dequantise, then matmul" for every call
+// (bitsandbytes/mod.rs:301-312) because the reference targets 24 GB cards; on a 288 GB part the per-call expansion of a large launch
+// (228 per denoise step, 4.4 ms) buys nothing.  When the first launch that would take the scratch comes and the device has at least
+// twice the dense arenas' bytes free, those matrices are expanded once (mode 3); otherwise only the packed codes stay resident (mode 0).
+static int resolve_quant_mode(fmi_flux* m) {
+  if (m->quant_mode >= 0) return m->quant_mode;
+  size_t need = 0, fr = 0, tot = 0;
+  if (!m->arena[AR_BLOCKS].base) need += m->arena[AR_BLOCKS].bytes;
+  if (!m->arena[AR_MOD].base && (size_t)m->mod_all.N * m->mod_all.K < (1ull << 31)) need += m->arena[AR_MOD].bytes;  // (FLUX.1's stays packed: densify)
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
+  m->quant_mode = fr >= 2 * need ? 3 : 0;
+  return m->quant_mode;
+}
 int densify(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s) {
   // one decision per launch group (the img + txt problems of a double block stay one grouped launch)
   bool scratch = false;
   for (int i = 0; i < n && i < 2; ++i)
-    if (dn[i] && p[i].q_type && m->quant_mode == 0)
+    if (dn[i] && p[i].q_type && m->quant_mode != 1 && m->quant_mode != 2)
       scratch = scratch || p[i].M > (p[i].q_type == 3 ? INT8_FUSED_MAX_ROWS : Q4_FUSED_MAX_ROWS);
   // A matrix of 2^31 or more weights (the fused modulation matrix of FLUX.1: 344 D x D = 3.2e9) never goes through the scratch —
   // the stand-alone dequant launchers count elements in 32 bits and the scratch is sized for the block matrices — it stays on
@@ -545,7 +564,8 @@ int densify(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s)
     if (!d || !p[i].q_type) continue;
     if (!m->dense_cache && !scratch) continue;  // fused paths (launch_gemm picks the kernel)
     const size_t elems = (size_t)p[i].N * p[i].K;
-    if (m->dense_cache) {
+    const bool once = m->dense_cache || (scratch && resolve_quant_mode(m) == 3);
+    if (once) {
       FMI_TRY(ensure_arena(m, d->ar));
       if (!m->dense_ready.count(d)) {
         // expanded once, in row chunks of at most 2^28 elements (chunk starts stay multiples of the quantisation block: K % 64 == 0)
@@ -805,7 +825,9 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
   // sequence parallel: S, T (and the ids) are this rank's shard; only the attention sees the other ranks (attention_sp)
   const bool sp = m->sp_world > 1 && m->sp_a2a;
   if (sp && (B != 1 || fp8)) return fail(FMI_ERR_UNSUPPORTED, "flux: sequence parallelism runs one image (B = 1) in bf16 mode");
-  if (m->fp8_attn == 2 && !sp && m->q8_dbl.empty()) FMI_TRY(compute_attention_scales(m));
+  // (normally computed by fmi_flux_set_fp8_attention(m, 2) / quantize_8bit, outside any evaluation; this is the path of a weight reloaded
+  // afterwards: 4 n_double + 2 n_single small synchronous device-to-host copies, once — not legal under stream capture, like set_tensor itself)
+  if (m->fp8_attn == 2 && !sp && !m->attn_scales_valid) FMI_TRY(compute_attention_scales(m));
   const bool qk8_any = m->fp8_attn == 2 && !sp;  // opt-in: e4m3 q, k in front of QK^T whatever the block linears run on
   const int BT = B * T;  // a8 / a8s rows: [txt (B*T) | img (B*S)]
 
@@ -1120,7 +1142,7 @@ extern "C" void fmi_flux_destroy(fmi_flux* m) {
 extern "C" int fmi_flux_set_tensor(fmi_flux* m, const char* name, const void* data, fmi_dtype dtype, const int64_t* shape, int rank) {
   if (!m || !name || !data) return fail(FMI_ERR_INVALID, "flux_set_tensor: null argument");
   if (m->fp8) return fail(FMI_ERR_STATE, "flux_set_tensor: the model was quantised to 8 bits (fmi_flux_quantize_fp8 / _int8); create a new one to load other weights");
-  m->q8_dbl.clear();  // (fmi_flux_set_fp8_attention(m, 2) in bf16 mode: the static attention scales follow the QkNorm weights — recomputed at the next evaluation)
+  m->attn_scales_valid = false;  // (fmi_flux_set_fp8_attention(m, 2) in bf16 mode: the static attention scales follow the QkNorm weights — recomputed once at the next evaluation)
   auto it = m->names.find(name);
   if (it == m->names.end()) return fail(FMI_ERR_INVALID, std::string("flux_set_tensor: unknown tensor name '") + name + "'");
   const Dest& d = it->second;
@@ -1331,6 +1353,7 @@ extern "C" int fmi_flux_state_adopt(fmi_flux* m, const uint8_t* blob_host, size_
   }
   m->missing.clear();
   m->dense_ready.clear();
+  m->attn_scales_valid = false;  // the weights arrive after this call (broadcast into the arenas)
   m->finalized = true;
   return FMI_OK;
 }
@@ -1464,7 +1487,8 @@ extern "C" int fmi_flux_set_split_k(fmi_flux* m, int enable) {
 }
 extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int mode) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
-  if (mode < 0 || mode > 2) return fail(FMI_ERR_INVALID, "set_quant_dense_cache: mode must be 0 (by size), 1 (dense cache) or 2 (always fused)");
+  if (mode < -1 || mode > 3)
+    return fail(FMI_ERR_INVALID, "set_quant_dense_cache: mode must be -1 (by memory), 0 (packed only, by size), 1 (dense cache), 2 (always fused) or 3 (by size, large launches expanded once)");
   m->dense_cache = mode == 1;
   m->quant_mode = mode;
   m->dense_ready.clear();
@@ -1472,6 +1496,7 @@ extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int mode) {
 }
 // static e4m3 scales of the attention operands from the QkNorm weights (see fmi_flux::fp8_attn); needs the weights in place
 static int compute_attention_scales(fmi_flux* m) {
+    m->attn_scales_valid = false;  // a failure half way must not leave vectors that the next call takes for valid
     auto wmax = [&](const bf16_t* dev, float* out) -> int {
       uint16_t h[128];
       FMI_HIP_TRY(hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost));
@@ -1518,6 +1543,7 @@ static int compute_attention_scales(fmi_flux* m) {
       m->k8_sgl[i] = scale_of(c);
       m->q8_sgl[i] = q_scale_pow2(scale_of(a), m->k8_sgl[i], &m->n8_sgl[i]);
     }
+    m->attn_scales_valid = true;
     return FMI_OK;
 }
 // 8-bit modes: quantise the block Linears of `mask` once (bf16 arena -> e4m3 / int8 codes + per-output-channel scale); see the header.
@@ -1579,7 +1605,13 @@ extern "C" int fmi_flux_quantize_int8(fmi_flux* m, unsigned linear_mask, void* s
 extern "C" int fmi_flux_set_fp8_attention(fmi_flux* m, int enable) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
   if (enable < 0 || enable > 2) return fail(FMI_ERR_INVALID, "set_fp8_attention: 0 (off), 1 (on in the 8-bit modes) or 2 (on in every mode)");
-  m->fp8_attn = enable;  // (2 in bf16 mode: the static scales are taken from the QkNorm weights at the next evaluation)
+  m->fp8_attn = enable;
+  // 2 in bf16 mode: the static scales come from the QkNorm weights — taken here when the weights are complete (not inside the next evaluation: they
+  // are small synchronous copies), else at the first evaluation after the last tensor arrived
+  if (enable == 2 && !m->attn_scales_valid && m->missing.empty()) {
+    FMI_TRY(use_device(m));
+    FMI_TRY(compute_attention_scales(m));
+  }
   return FMI_OK;
 }
 // 4-bit weights, process-wide: number of rows from which the one-wave-per-SIMD fused dequant-GEMM (gemm_w4q.h) runs

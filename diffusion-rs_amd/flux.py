@@ -141,7 +141,9 @@ class FluxModel:
     def quantize_int8(self, mask: int = None, stream=None):
         """Switch the DiT block linears named by `mask` (Q8_* bits; default INT8_DEFAULT_MASK) to the int8 MFMA path: symmetric per-row
         int8 codes (weights once per output channel, activations per token on the fly), exact int32 accumulation; the other block
-        linears, the attention and everything else stay on the bf16 path."""
+        linears and everything else stay on the bf16 path — except the attention operands: as in the fp8 mode (set_fp8_attention, default
+        on) the blocks whose q|k|v linear is in the mask hand q and k to the attention as e4m3 with static scales (QK^T on the fp8
+        MFMA; P.V stays bf16).  set_fp8_attention(0) keeps bf16 operands."""
         L.check(self.lib.fmi_flux_quantize_int8(self.h, INT8_DEFAULT_MASK if mask is None else int(mask), stream))
 
     def set_fp8_attention(self, mode: int):
@@ -162,9 +164,10 @@ class FluxModel:
         return self.lib.fmi_flux_size_in_bytes(self.h)
 
     def set_quant_dense_cache(self, mode):
-        """Quantised linears: 0 / False (default) = only the packed codes are resident: fused dequant-GEMM for small launches,
-        per-call expansion into a 264 MB scratch + dense GEMM for large ones (whichever is measured faster, DESIGN 4.5);
-        1 / True = expand each matrix once into the bf16 arena and run the dense kernels; 2 = always the fused kernels."""
+        """Quantised linears, launches above 383 (nf4 / fp4) / 256 (LLM.int8) rows — smaller ones always multiply from the packed codes:
+        -1 (default) = by memory: 3 when the device has the room, else 0; 0 / False = packed only: per-call expansion into a 264 MB
+        scratch + dense GEMM; 1 / True = every matrix expanded once into the bf16 arenas; 2 = always the fused kernels; 3 = the matrices
+        of the large launches expanded once.  Same bits in every mode."""
         L.check(self.lib.fmi_flux_set_quant_dense_cache(self.h, int(mode)))
 
     def set_split_k(self, on: bool):

@@ -134,13 +134,17 @@ int fmi_flux_set_linear_bnb4(fmi_flux*, const char* prefix, const uint8_t* packe
  * bf16 inside the layer's GEMM (small launches) or right before it (see fmi_flux_set_quant_dense_cache).
  * Same prefix rules as fmi_flux_set_linear_bnb4. */
 int fmi_flux_set_linear_int8(fmi_flux*, const char* prefix, const int8_t* weight, const float* scb, int out_features, int in_features);
-/* Quantised block / modulation linears (BnbLinear::forward = dequantize, then matmul: bitsandbytes/mod.rs:293-312).
- * Only the packed codes are resident (an nf4 FLUX.1-dev occupies ~7 GB).  mode 0 (default): by size — launches of up
- * to 383 rows (nf4 / fp4) or 256 rows (LLM.int8) multiply straight from the codes with the fused dequant-GEMM (the
- * expansion is an LDS stage of the GEMM); larger launches expand the matrix per call into a reusable scratch (2 x the
- * largest fused matrix) and run the dense kernel, which is measured faster there.  mode 1: each quantised matrix is
- * expanded ONCE into its slot of the bf16 arena (allocated on first use, +16 GB).  mode 2: every launch on the fused
- * kernels.  All three produce the same bits. */
+/* Quantised block / modulation linears (BnbLinear::forward = dequantize, then matmul: bitsandbytes/mod.rs:293-312) — where the expanded
+ * weights live.  Launches of up to 383 rows (nf4 / fp4) or 256 rows (LLM.int8) always multiply straight from the packed codes with the
+ * fused dequant-GEMM (the expansion is an LDS stage of the GEMM; the packed read wins there).  For larger launches the dense kernel on
+ * expanded weights is measured faster, and `mode` says where those come from:
+ *   -1 (default) by memory: 3 if, when the first such launch comes, the device has at least twice the dense block arena free (it does
+ *      on a 288 GB part: an nf4 FLUX.1-dev then holds 7 GB of codes + 16 GB of expanded block matrices and runs at bf16 speed), else 0;
+ *    0 packed only: the matrix is expanded per call into a reusable scratch (2 x the largest fused matrix); ~7 GB resident for FLUX.1-dev;
+ *    1 every quantised matrix, the 6.5 GB modulation matrix included, is expanded ONCE into its slot of the bf16 arenas (+23 GB);
+ *    2 every launch on the fused kernels;
+ *    3 as 0, but a matrix that 0 would expand per call is expanded once into its dense slot (small launches stay on the codes).
+ * All of them produce the same bits. */
 int fmi_flux_set_quant_dense_cache(fmi_flux*, int mode);
 /* Single-image sequence parallelism.  The reference runs one image on one device
  * (pipelines/mod.rs:214-217 "This will need to be updated!"); here the tokens of ONE image are sharded over the
@@ -508,9 +512,9 @@ int fmi_linear_i8(const void* x, const int8_t* wq, const float* w_scale, const v
                   int K, fmi_epilogue epi, void* stream);
 /* Caller-owned workspace forms of the two (the reference's convention: the caller allocates, bitsandbytes/op.rs:204-228): `workspace`
  * = at least fmi_linear_q8_workspace_bytes(M, K) bytes of device memory, 256-byte aligned, that must stay untouched until the call's work
- * has run on `stream`.  fmi_linear_fp8 / fmi_linear_i8 above are these with the workspace drawn from the device's default memory pool ON
- * `stream` (hipMallocAsync / hipFreeAsync): every form is asynchronous on the stream — no device allocation in the steady state, no
- * host synchronisation. */
+ * has run on `stream`.  fmi_linear_fp8 / fmi_linear_i8 above are these with the workspace taken from a grow-only block the
+ * library keeps per (device, stream): every form is asynchronous on the stream — a call allocates only if it needs more than any earlier
+ * call on that stream did (once, without waiting for the stream), and none synchronises the host. */
 size_t fmi_linear_q8_workspace_bytes(int M, int K);
 int fmi_linear_fp8_ws(const void* x, const uint8_t* wq, const float* w_scale, const void* bias, void* y, int M, int N, int K,
                       fmi_epilogue epi, void* workspace, size_t workspace_bytes, void* stream);
@@ -527,9 +531,10 @@ int fmi_gemm_q8(const void* xq, const float* x_scale, const void* wq, const floa
 int fmi_sdpa_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq,
                   int Lk, int d, float scale, int out_token_major, void* stream);
 /* The attention kernels read V transposed (B,H,128,Lk rounded up to 64) with the kv index permuted inside groups of 16; the op-level
- * entry points build that image first.  fmi_sdpa_bf16 / fmi_sdpa_fp8qk draw it from the device's default memory pool ON `stream`
- * (hipMallocAsync / hipFreeAsync: ordered like a launch, no device allocation in the steady state, no host synchronisation — a host that
- * binds ops::sdpa to them enqueues 57 calls per denoise step without ever waiting); the *_ws forms take it from the caller
+ * entry points build that image first.  fmi_sdpa_bf16 / fmi_sdpa_fp8qk keep it in a grow-only block the library holds per (device, stream)
+ * — calls on one stream run in order and share it; a call allocates only when it needs more than any earlier call on that stream (once,
+ * without waiting for the stream) and none synchronises the host: a host that binds ops::sdpa to them enqueues 57 calls per denoise step
+ * without ever waiting —; the *_ws forms take it from the caller
  * (fmi_sdpa_workspace_bytes(B, H, Lk) bytes, 16-byte aligned, untouched until the call's work has run on `stream`). */
 size_t fmi_sdpa_workspace_bytes(int B, int H, int Lk);
 int fmi_sdpa_bf16_ws(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int d, float scale,

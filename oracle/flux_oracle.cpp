@@ -789,7 +789,11 @@ struct Fp8Weight {
 };
 struct orc_flux {
   int fp8 = 0;  // block linears on the fp8 recipe above
-  int fp8_attn = 0;  // q, k of the attention quantised to e4m3 with static scales (see attention())
+  // attention operands (see attention()): bit 0 = q, k quantised to e4m3 with static scales — in the blocks whose q|k|v linear is in q8_mask, which is
+  // what the library's 8-bit modes do (fmi_flux_set_fp8_attention(m, 1): double blocks need bit LIN_DBL_QKV, single blocks bit LIN_SGL_1);
+  // bit 2 (4) = in EVERY block whatever the mask (the library's fmi_flux_set_fp8_attention(m, 2), and the noise study's "attention alone");
+  // bit 1 (2) = P and V on e4m3 too (study of an unbuilt recipe)
+  int fp8_attn = 0;
   // which block linears take the 8-bit recipe (the others stay f32 / lin_fwd): bit 0 double q|k|v, 1 double attention out, 2 double MLP in,
   // 3 double MLP out, 4 single linear1 (q, k, v, proj_mlp), 5 single linear2 (proj_out).  orc_flux_set_q8_mask; default all.
   int q8_mask = 0x3f;
@@ -947,6 +951,11 @@ static void study_quantise(const float* x, int rows, int K, int kind, float* out
         const float sc = ldexpf(1.0f, (int)ceilf(log2f(am / 448.0f)));
         for (int k = 0; k < n; ++k) o[k0 + k] = orc_e4m3_to_f32(orc_f32_to_e4m3(xr[k0 + k] / sc)) * sc;
       }
+    } else if (kind == 8) {  // asymmetric 8-bit grid: 256 levels over [min, max] of the row (for operands that do not straddle zero evenly: gelu(h) >= -0.17)
+      float lo = xr[0], hi = xr[0];
+      for (int k = 1; k < K; ++k) lo = fminf(lo, xr[k]), hi = fmaxf(hi, xr[k]);
+      const float sc = fmaxf(hi - lo, 1e-30f) / 255.0f, inv = 255.0f / fmaxf(hi - lo, 1e-30f);
+      for (int k = 0; k < K; ++k) o[k] = fminf(fmaxf(nearbyintf((xr[k] - lo) * inv), 0.f), 255.f) * sc + lo;
     } else {
       float am = 0.f;
       for (int k = 0; k < K; ++k) am = fmaxf(am, fabsf(xr[k]));
@@ -982,21 +991,28 @@ void lin_blk(orc_flux* m, const Lin& l, const float* x, int rows, float* y, int 
   }
   if (m->fp8 != 1) {  // study modes: dequantised operands through the plain f32 GEMM
     // 7 = int8 as 5, but the input of the single blocks' linear2 — cat(attention, gelu(mlp)) — gets one scale per SEGMENT and row instead of one per row
-    static const int wk[8] = {0, 1, 2, 1, 0, 5, 0, 5}, ak[8] = {0, 1, 2, 0, 1, 5, 2, 5};
-    const int mode = std::min(std::max(m->fp8, 2), 7);
+    // 8 = int8 as 5 with the ASYMMETRIC grid (kind 8: 256 levels over [min, max] of the row) on the post-GELU operands: the input of the double blocks'
+    //     MLP-out, and the gelu(mlp) segment of linear2's input (its attention segment symmetric, a scale per segment as in 7)      [round 5 study]
+    // 9 = as 8, but linear2's input as ONE asymmetric row (one scale + offset over cat(attention, gelu(mlp)): what a single launch can apply)
+    static const int wk[10] = {0, 1, 2, 1, 0, 5, 0, 5, 5, 5}, ak[10] = {0, 1, 2, 0, 1, 5, 2, 5, 5, 5};
+    const int mode = std::min(std::max(m->fp8, 2), 9);
     Fp8Weight& fw = m->fp8_w[l.w];
     if (fw.q.empty()) {
       fw.q.resize((size_t)l.out * l.in);
       study_quantise(l.w, l.out, l.in, wk[mode], fw.q.data());
     }
     std::vector<float> xq((size_t)rows * l.in);
-    if (mode == 7 && which == LIN_SGL_2) {
+    if ((mode == 8 || mode == 9) && which == LIN_DBL_MLP2) {
+      study_quantise(x, rows, l.in, 8, xq.data());
+    } else if (mode == 9 && which == LIN_SGL_2) {
+      study_quantise(x, rows, l.in, 8, xq.data());
+    } else if ((mode == 7 || mode == 8) && which == LIN_SGL_2) {
       const int D = m->D;
       std::vector<float> seg((size_t)rows * l.in), segq((size_t)rows * l.in);
       for (int part = 0; part < 2; ++part) {  // columns [0, D) and [D, in): gathered, quantised per row, scattered back
         const int c0 = part ? D : 0, w = part ? l.in - D : D;
         for (int r = 0; r < rows; ++r) memcpy(seg.data() + (size_t)r * w, x + (size_t)r * l.in + c0, sizeof(float) * w);
-        study_quantise(seg.data(), rows, w, 5, segq.data());
+        study_quantise(seg.data(), rows, w, (mode == 8 && part) ? 8 : 5, segq.data());
         for (int r = 0; r < rows; ++r) memcpy(xq.data() + (size_t)r * l.in + c0, segq.data() + (size_t)r * w, sizeof(float) * w);
       }
     } else {
@@ -1169,11 +1185,12 @@ static int double_block_one(orc_flux* m, int idx, float* img, float* txt, const 
   // cat([txt, img], seq) is realised by the row offsets above (model.rs:540-542)
   std::vector<float> attn((size_t)L * D);
   float q8 = 0.f, k8 = 0.f;
-  if (m->fp8 && m->fp8_attn) {
+  const bool att8 = m->fp8 && (m->fp8_attn & 1) && ((m->fp8_attn & 4) || ((m->q8_mask >> LIN_DBL_QKV) & 1));
+  if (att8) {
     k8 = fp8_attn_scale(m, p + "attn.norm_k", p + "attn.norm_added_k", d);
     q8 = fp8_q_scale_pow2(fp8_attn_scale(m, p + "attn.norm_q", p + "attn.norm_added_q", d), k8, d);
   }
-  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8, m->fp8 && m->fp8_attn == 2);
+  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8, att8 && (m->fp8_attn & 2));
   const float* txt_attn = attn.data();
   const float* img_attn = attn.data() + (size_t)T * D;
   Lin ip = get_lin(m, p + "attn.to_out.0", D, D), tp = get_lin(m, p + "attn.to_add_out", D, D);
@@ -1218,11 +1235,12 @@ static int single_block_one(orc_flux* m, int idx, float* x, const float* vec, co
   std::vector<float> cat((size_t)L * (D + M)), mlp((size_t)L * M), attn((size_t)L * D);
   lin_blk(m, pm, xm.data(), L, mlp.data(), LIN_SGL_1);
   float q8 = 0.f, k8 = 0.f;
-  if (m->fp8 && m->fp8_attn) {
+  const bool att8 = m->fp8 && (m->fp8_attn & 1) && ((m->fp8_attn & 4) || ((m->q8_mask >> LIN_SGL_1) & 1));
+  if (att8) {
     k8 = fp8_attn_scale(m, p + "attn.norm_k", "", d);
     q8 = fp8_q_scale_pow2(fp8_attn_scale(m, p + "attn.norm_q", "", d), k8, d);
   }
-  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8, m->fp8 && m->fp8_attn == 2);
+  attention(Q.data(), K.data(), V.data(), pe, H, L, d, attn.data(), q8, k8, att8 && (m->fp8_attn & 2));
   orc_gelu(mlp.data(), (int64_t)L * M, mlp.data());
 #pragma omp parallel for
   for (int l = 0; l < L; ++l) {  // Tensor::cat(&[attn, mlp.gelu()], 2)  (model.rs:660)

@@ -451,17 +451,23 @@ class Flux:
     def set_fp8(self, on=True, attention=False, study_mode=None):
         """Block linears on the fp8 recipe (flux_oracle.cpp: parity unpinned, no reference counterpart); attention=True
         also puts q and k of the attention on e4m3 with the static scales (what the library does when both streams of a
-        block take the fused QKV epilogue: token counts / offsets multiples of 16).  study_mode 2..6 = the alternative
-        quantisers of tools/fp8_noise_study.py (flux_oracle.cpp: lin_blk), never what the library is compared with."""
+        block take the fused QKV epilogue: token counts / offsets multiples of 16).  study_mode 2..9 = the alternative
+        quantisers of tools/fp8_noise_study.py (flux_oracle.cpp: lin_blk), never what the library is compared with; in a study the
+        attention operands are quantised in every block whatever the linear mask (attention=2: P and V too)."""
         lib().orc_flux_set_fp8(self.h, int(study_mode) if (on and study_mode) else int(bool(on)))
-        lib().orc_flux_set_fp8_attention(self.h, (2 if attention == 2 else 1) if (on and attention) else 0)  # 2: study only, e4m3 P and V too
+        att = 0
+        if on and attention:
+            att = 1 | (2 if attention == 2 else 0) | (4 if study_mode else 0)
+        lib().orc_flux_set_fp8_attention(self.h, att)
 
-    def set_int8(self, on=True, mask=0x33, attention=False):
+    def set_int8(self, on=True, mask=0x33, attention=False, attention_everywhere=False):
         """Block linears of `mask` on the int8 recipe (lin_blk mode 5: exact integer sums; parity unpinned, no reference counterpart),
         the others in f32.  0x33 = the library's default mask (all but the double blocks' MLP).  attention=True: q and k of the attention
-        on e4m3 with the static scales, as in the fp8 mode (what the library does in either 8-bit mode for 16-aligned token counts)."""
+        on e4m3 with the static scales in the blocks whose q|k|v linear is in the mask (bit 0 for the double blocks, bit 4 for the single
+        ones) — what the library does in either 8-bit mode for 16-aligned token counts; attention_everywhere=True: in every block whatever
+        the mask (the library's fmi_flux_set_fp8_attention(m, 2))."""
         lib().orc_flux_set_fp8(self.h, 5 if on else 0)
-        lib().orc_flux_set_fp8_attention(self.h, int(bool(on and attention)))
+        lib().orc_flux_set_fp8_attention(self.h, (1 | (4 if attention_everywhere else 0)) if (on and attention) else 0)
         lib().orc_flux_set_q8_mask(self.h, int(mask) if on else 0x3f)
 
     def set_q8_mask(self, mask=0x3f):

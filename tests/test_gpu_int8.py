@@ -154,7 +154,8 @@ def test_linear_i8_rejects_bad_shapes(env):
     assert lib.fmi_quantize_rows_i8(_p(x), 4, 12, _p(q), _p(s), None) < 0                    # K % 8
 
 
-MASKS = [0x33, 0x3f, 0x15, 0x0c]  # the default, every block linear, the LayerNorm-fed ones, the double blocks' MLP alone
+MASKS = [0x33, 0x3f, 0x15, 0x0c, 0x01, 0x10]  # the default, every block linear, the LayerNorm-fed ones, the double blocks' MLP alone, and q|k|v of ONE block kind
+# (0x01 / 0x10: e4m3 attention operands in the double blocks only / the single blocks only — ADVICE r4: the oracle gates them per block kind like the library)
 
 
 @pytest.fixture(scope="module")
@@ -186,7 +187,7 @@ def test_flux_forward_int8_matches_int8_oracle(env, models, B, S_hw, T, mask):
     args = (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(t), dev(y), dev(g))
     got = host(models[mask].forward(*args))
     aligned = (S_hw[0] * S_hw[1]) % 16 == 0 and T % 16 == 0  # then every block takes the fused q|k|v epilogue and QK^T runs on e4m3 operands
-    models["o8"].set_int8(True, mask, attention=aligned and bool(mask & 0x11))
+    models["o8"].set_int8(True, mask, attention=aligned)  # (the oracle gates the attention operands on the mask per block kind, like the library)
     ref8 = models["o8"].forward(img, ids, txt, txt_ids, t, y, g)
     models["o8"].set_int8(False)
     ref = models["of"].forward(img, ids, txt, txt_ids, t, y, g)
@@ -237,7 +238,7 @@ def test_e4m3_attention_operands_in_bf16_mode_opt_in(env, models):
     finally:
         gb.set_fp8_attention(1)
     np.testing.assert_array_equal(host(gb.forward(*args)), base)
-    o8.set_int8(True, 0, attention=True)
+    o8.set_int8(True, 0, attention=True, attention_everywhere=True)
     ref8 = o8.forward(img, ids, txt, txt_ids, t, y, g)
     o8.set_int8(False)
     ref = of.forward(img, ids, txt, txt_ids, t, y, g)

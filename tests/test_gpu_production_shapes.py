@@ -426,7 +426,7 @@ def test_batch_of_8_at_full_size_equals_the_samples_run_alone(full_models):
 
 def test_c3_nf4_full_model_forward_matches_oracle_on_dequantised_weights(full_models):
     """BASELINE configs[2] (C3: Q4-bnb) with the FULL model: every block and modulation Linear of FLUX.1-dev as bitsandbytes nf4
-    (blocksize 64; 7.4 GiB resident, no bf16 copy), one `Flux::forward` at 1024 image + 256 text tokens — above 383 rows, so the
+    (blocksize 64; packed-only policy: 7.4 GiB resident, no bf16 copy), one `Flux::forward` at 1024 image + 256 text tokens — above 383 rows, so the
     block Linears take the per-call expansion + dense GEMM and the 50-row-class launches the fused dequant-GEMM — against the
     oracle on the dequantised weights (BnbLinear::forward = dequantise + matmul, bitsandbytes/mod.rs:293-312; the dequantisation
     is the library's bit-exact kDequantizeBlockwise).  Tolerance: rel-L2 <= 2e-2."""
@@ -468,8 +468,17 @@ def test_c3_nf4_full_model_forward_matches_oracle_on_dequantised_weights(full_mo
     img, ids = orc.pack_latents(lat)
     txt_ids = np.zeros((1, 256, 3), np.float32)
     t, g = np.array([0.6], np.float32), np.array([3.5], np.float32)
+    gq.set_quant_dense_cache(0)  # packed only (the opt-in since round 5): per-call expansion of the large launches
     got = host(gq.forward(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(t), dev(clip), dev(g)))
     resident = gq.size_in_bytes() / 2**30
+    bufs = gq.state_buffers()
+    assert bufs[1][1] == 0 and bufs[2][1] == 0  # still no bf16 arena
+    gq.set_quant_dense_cache(-1)  # the default: by memory — this 288 GB part expands the block matrices of the large launches once
+    got_d = host(gq.forward(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(t), dev(clip), dev(g)))
+    bufs = gq.state_buffers()
+    assert np.array_equal(got_d.view(np.uint32), got.view(np.uint32))  # same bits
+    assert bufs[2][1] > 0 and bufs[1][1] == 0  # the block arena appeared, the 6.5 GB modulation matrix stays packed
+    print(f"  default policy (by memory): {gq.size_in_bytes() / 2**30:.1f} GiB resident, the same bits as packed-only ({resident:.1f} GiB)")
     gq.close()
     t0 = time.time()
     ref = oq.forward(img, ids, t5, txt_ids, t, clip, g)

@@ -5,7 +5,7 @@ fmi_linear_fp8 / fmi_linear_i8 used to hipMalloc, hipStreamSynchronize and hipFr
 
 Checked here: (i) 57 attention calls (one per DiT block of a step) enqueued behind ~100 ms of other work return to the host while that
 work is still running — an event recorded BEFORE the calls has not completed when the last call returns —, (ii) their results equal the
-caller-owned-workspace form's bit for bit and are what the same call gives on an idle stream, (iii) the pool-backed scratch is reused
+caller-owned-workspace form's bit for bit and are what the same call gives on an idle stream, (iii) the library-held scratch is reused
 (free device memory does not shrink with the number of calls), (iv) the same for the 8-bit linears, (v) the workspace forms reject a
 workspace that is too small, and fmi_sdpa_fp8qk_ws takes its power-of-two score factor as an integer.
 """
@@ -76,12 +76,13 @@ def test_57_sdpa_calls_behind_a_long_kernel_do_not_block_the_host(env):
     # a workspace one byte short is refused, nothing is launched
     assert lib.fmi_sdpa_bf16_ws(_p(q), _p(k), _p(v), _p(ref), B, H, Lq, Lq, 128, scale, 1, _p(ws), nbytes - 1, None) == -1
     assert b"workspace" in lib.fmi_last_error()
-    # warm the pool once (the first hipMallocAsync of a size may reach the driver), then measure
+    # the first call of a size on a stream allocates the library's scratch block for it; every later one reuses it
     outs = [torch.full_like(ref, float("nan")) for _ in range(n_calls)]
     L.check(lib.fmi_sdpa_bf16(_p(q), _p(k), _p(v), _p(outs[0]), B, H, Lq, Lq, 128, scale, 1, None))
     torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
     go, keep, busy_ms = _busy(torch)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
     import time
     ev_busy = go()
     t0 = time.perf_counter()
@@ -98,7 +99,7 @@ def test_57_sdpa_calls_behind_a_long_kernel_do_not_block_the_host(env):
     assert still_running and host_ms < 0.5 * busy_ms
     for o in outs:
         assert torch.equal(o.view(torch.int16), ref.view(torch.int16))
-    assert free0 - free1 <= 4 * nbytes  # pool reuse: not 57 scratch buffers
+    assert free0 - free1 <= 4 * nbytes  # one block reused: not 57 scratch buffers
     # what the header promises must be findable in the binary's behaviour too: no entry point of this family synchronises
     del keep
 
@@ -157,7 +158,7 @@ def test_fp8qk_and_q8_linears_are_stream_ordered_and_equal_their_workspace_forms
         L.check(lin_ws(_p(x), _p(wq), _p(wscale), _p(bias), _p(y_ws), M, N, K, 0, _p(wsp), nb, None))
         assert lin_ws(_p(x), _p(wq), _p(wscale), _p(bias), _p(y_ws), M, N, K, 0, _p(wsp), nb - 1, None) == -1
         ys = [torch.empty_like(y_ws) for _ in range(20)]
-        L.check(lin(_p(x), _p(wq), _p(wscale), _p(bias), _p(ys[0]), M, N, K, 0, None))  # warm the pool
+        L.check(lin(_p(x), _p(wq), _p(wscale), _p(bias), _p(ys[0]), M, N, K, 0, None))  # (first call of this size: allocates the scratch block)
         torch.cuda.synchronize()
         ev_busy = go()
         t0 = time.perf_counter()

@@ -250,10 +250,14 @@ def test_committed_attention_streams_are_what_their_generators_emit(tmp_path):
 
 
 def test_no_entry_point_of_the_op_seam_synchronises_or_allocates_in_source():
-    """`grep -n hipStreamSynchronize capi.hip` shows only fmi_stream_synchronize (VERDICT r4 'Done' criterion), and no hipMalloc( / hipFree( besides
-    fmi_malloc / fmi_free."""
+    """`grep -n hipStreamSynchronize capi.hip` shows only fmi_stream_synchronize (VERDICT r4 'Done' criterion); the bodies of the op-level entry
+    points (everything from the workspace-size queries to the attention-kernel switch) call no allocator and no synchronisation at all —
+    the one hipMalloc besides fmi_malloc sits in the grow-only scratch cache, reached only when a stream's block is outgrown."""
     import re
     src = open(os.path.join(ROOT, "diffusion-rs_amd", "csrc", "capi.hip")).read()
     code = re.sub(r"//[^\n]*", "", src)
-    assert len(re.findall(r"\bhipStreamSynchronize\s*\(", code)) == 1
-    assert len(re.findall(r"\bhipMalloc\s*\(", code)) == 1 and len(re.findall(r"\bhipFree\s*\(", code)) <= 2  # fmi_malloc; fmi_free + fmi_init's hipFree(nullptr)
+    assert len(re.findall(r"\bhipStreamSynchronize\s*\(", code)) == 1 and "hipDeviceSynchronize" not in code
+    assert len(re.findall(r"\bhipMalloc\s*\(", code)) == 2
+    ops = code[code.index('extern "C" size_t fmi_linear_q8_workspace_bytes'):code.index('extern "C" int fmi_set_attention_kernel')]
+    for banned in ("hipMalloc", "hipFree", "Synchronize", "hipMemcpy("):
+        assert banned not in ops, banned
