@@ -245,6 +245,10 @@ struct GemmProblem {
   int fp8;
   const float* a_scale;
   const float* w_scale;
+  // int8 only, optional (both or neither): the activation rows carry an offset segment (fp8.hip: the post-GELU form of the int8 recipe) —
+  // a_off[m] * w_sum[n] is added behind the scaling: y = acc * (a_scale[m] * w_scale[n]) + a_off[m] * w_sum[n] (+ bias ... in the epilogue)
+  const float* a_off;
+  const float* w_sum;
 };
 int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream);
 // Process-wide kernel-selection hooks (tests, ablations; the alternatives are bit-identical):
@@ -323,6 +327,11 @@ int launch_layernorm_mod(const float* x, const float* scale, const float* shift,
 // out[r,k] = e4m3_rne(x[r,k] * (448 / max(absmax, 1e-30))); x bf16 with row stride ld, out (rows, K) dense.
 // kind 2: the int8 form (scale = absmax / 127, codes = clamp(rint(x * 127 / absmax), -127, 127)) — fp8.hip's header
 int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* out, float* scale, hipStream_t stream, int kind = 1);
+// int8, post-GELU form (fp8.hip's header): columns [0, d0) symmetric, columns [d0, K) on 256 levels over their [min, max], one step per row;
+// offset[r] = lo + 128 * scale[r].  d0 % 8 == 0, 0 <= d0 < K.
+int launch_quantize_rows_i8_asym(const bf16_t* x, int ld, int rows, int K, int d0, uint8_t* out, float* scale, float* offset, hipStream_t stream);
+// w_sum[n] = w_scale[n] * float(sum_{k >= d0} wq[n,k]) over int8 codes (N, K) row-major: the column term of the offset segment
+int launch_rowsum_i8(const int8_t* wq, const float* w_scale, int N, int K, int d0, float* w_sum, hipStream_t stream);
 // launch_layernorm_mod with the row quantisation fused (values quantised from f32, not via bf16)
 int launch_layernorm_mod_fp8(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch,
                              uint8_t* out, float* out_scale, int rows, int D, float eps, hipStream_t stream, int kind = 1);

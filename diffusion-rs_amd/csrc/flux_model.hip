@@ -50,6 +50,11 @@ struct Dense {  // one (possibly fused) Linear: W (N,K) bf16 row-major, bias (N)
   // optional fp8 form (fmi_flux_quantize_fp8): e4m3 (N,K) + per-output-channel f32 scale, used instead of w
   uint8_t* w8 = nullptr;
   float* w8_scale = nullptr;
+  // int8 mode, linears whose input is a post-GELU operand (the double blocks' MLP-out: d0 = 0; the single blocks' linear2 over
+  // cat(attention, gelu(mlp)): d0 = D): the input rows carry an offset segment from column w8_d0 on (fp8.hip's header) and
+  // w8_sum[n] = w8_scale[n] * sum_{k >= w8_d0} w8[n,k] is the column factor of the offset term.  w8_d0 < 0: symmetric rows.
+  float* w8_sum = nullptr;
+  int w8_d0 = -1;
   // the named Linears this matrix is made of (rows r0 .. r0+rows) and what each was loaded as
   struct Part {
     int r0, rows;
@@ -112,6 +117,7 @@ struct fmi_flux {
     bf16_t *img_bf, *txt_bf, *xm, *qkv_img, *qkv_txt, *big, *Qh, *Kh, *Vt, *attn_img, *attn_txt, *hid, *vec_bf;
     uint8_t* a8 = nullptr;  // fp8 mode: the current GEMM input, rows [txt | img], (B*L, <= D+M) e4m3
     float* a8s = nullptr;   //           its per-token scales (B*L)
+    float* a8o = nullptr;   // int8 mode: the per-token offsets of a post-GELU input (B*L; Dense::w8_d0)
     int Lpad = 0;
   } ws;
   // profiling
@@ -445,6 +451,7 @@ int ensure_workspace(fmi_flux* m, int B, int S, int T) {
   if (m->fp8) {
     add((void**)&w.a8, (size_t)B * L * (D + M));
     add((void**)&w.a8s, (size_t)B * L * 4);
+    add((void**)&w.a8o, (size_t)B * L * 4);
   }
   const size_t total = align_up(off, 256);
   if (w.base) {
@@ -474,7 +481,15 @@ GemmProblem make_problem_fp8(const fmi_flux* m, const Dense& d, int row0, int Mr
   p.fp8 = m->q8_kind;
   p.a_scale = m->ws.a8s + row0;
   p.w_scale = d.w8_scale;
+  if (d.w8_d0 >= 0) p.a_off = m->ws.a8o + row0, p.w_sum = d.w8_sum;  // the input was quantised by quantize_act (post-GELU form)
   return p;
+}
+// 8-bit modes: the row pass in front of a block linear whose input no producer quantises (attention output, gelu(mlp), their concat) —
+// the int8 mode's post-GELU form when the consuming linear asks for it (Dense::w8_d0), else the symmetric per-row recipe
+int quantize_act(fmi_flux* m, const Dense& d, const bf16_t* x, int ld, int rows, int row0, hipStream_t s) {
+  uint8_t* out = m->ws.a8 + (size_t)row0 * d.K;
+  if (d.w8_d0 >= 0) return launch_quantize_rows_i8_asym(x, ld, rows, d.K, d.w8_d0, out, m->ws.a8s + row0, m->ws.a8o + row0, s);
+  return launch_quantize_rows_fp8(x, ld, rows, d.K, out, m->ws.a8s + row0, s, m->q8_kind);
 }
 GemmProblem make_problem(const Dense& d, const bf16_t* A, int lda, int Mrows, void* out, int ldo, int epi) {
   GemmProblem p{};
@@ -943,8 +958,8 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
       GemmProblem p[2];
       if (q_out) {
-        FMI_TRY(launch_quantize_rows_fp8(w.attn_img, D, B * S, D, w.a8 + (size_t)BT * D, w.a8s + BT, s, qk));
-        FMI_TRY(launch_quantize_rows_fp8(w.attn_txt, D, B * T, D, w.a8, w.a8s, s, qk));
+        FMI_TRY(quantize_act(m, bw.proj[0], w.attn_img, D, B * S, BT, s));
+        FMI_TRY(quantize_act(m, bw.proj[1], w.attn_txt, D, B * T, 0, s));
       }
       p[0] = q_out ? make_problem_fp8(m, bw.proj[0], BT, B * S, w.x_img, D, EPI_RESID_GATE_F32)
                    : make_problem(bw.proj[0], w.attn_img, D, B * S, w.x_img, D, EPI_RESID_GATE_F32);
@@ -975,7 +990,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       Dense* dn1[2] = {&bw.mlp1[0], &bw.mlp1[1]};
       FMI_TRY(gemm2(m, p, dn1, 2, s));
       if (q_m2) {  // hid is (B*L, M) with the txt rows first, like a8
-        FMI_TRY(launch_quantize_rows_fp8(w.hid, Mh, B * L, Mh, w.a8, w.a8s, s, qk));
+        FMI_TRY(quantize_act(m, bw.mlp2[0], w.hid, Mh, B * L, 0, s));  // (both streams' MLP-out read it: same form, one pass)
       }
       p[0] = q_m2 ? make_problem_fp8(m, bw.mlp2[0], BT, B * S, w.x_img, D, EPI_RESID_GATE_F32)
                   : make_problem(bw.mlp2[0], hid_img, Mh, B * S, w.x_img, D, EPI_RESID_GATE_F32);
@@ -1034,7 +1049,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     }
     {
       PhaseTimer pt(m, s, PH_GEMM_PROJ);
-      if (q_w2) FMI_TRY(launch_quantize_rows_fp8(w.big + 2 * D, ldbig, B * L, D + Mh, w.a8, w.a8s, s, qk));
+      if (q_w2) FMI_TRY(quantize_act(m, bw.w2, w.big + 2 * D, ldbig, B * L, 0, s));
       GemmProblem p = q_w2 ? make_problem_fp8(m, bw.w2, 0, B * L, w.x, D, EPI_RESID_GATE_F32)
                            : make_problem(bw.w2, w.big + 2 * D, ldbig, B * L, w.x, D, EPI_RESID_GATE_F32);
       with_gate(p, mo + 2 * D, L, nmod);
@@ -1567,11 +1582,18 @@ static int quantize_8bit(fmi_flux* m, int kind, unsigned mask, void* stream) {
     if (mask >> 4 & 1) lin.push_back(&b.w1);
     if (mask >> 5 & 1) lin.push_back(&b.w2);
   }
+  // int8 mode: the linears fed by a post-GELU operand take it on the offset grid (fp8.hip's header) unless FMI_INT8_SYMMETRIC=1 asks for
+  // round 4's all-symmetric recipe (a study switch: the oracle's orc_flux_set_q8_symmetric)
+  const char* sym_env = getenv("FMI_INT8_SYMMETRIC");
+  const bool asym = kind == 2 && !(sym_env && atoi(sym_env) != 0);
+  for (auto& b : m->dbl)
+    for (int s = 0; s < 2; ++s) b.mlp2[s].w8_d0 = (asym && (mask >> 3 & 1)) ? 0 : -1;
+  for (auto& b : m->sgl) b.w2.w8_d0 = (asym && (mask >> 5 & 1)) ? m->D : -1;
   size_t bytes = 0;
   for (Dense* d : lin) {
     if (d->q_type || !d->w) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8 / quantize_int8: model holds bitsandbytes-quantised linears; load a bf16 checkpoint");
     if (d->K % 128 || d->N <= 128 || d->K > 16384) return fail(FMI_ERR_UNSUPPORTED, "quantize_fp8 / quantize_int8: needs in_features % 128 == 0 (<= 16384) and out_features > 128");
-    bytes += align_up((size_t)d->N * d->K, 256) + align_up((size_t)d->N * 4, 256);
+    bytes += align_up((size_t)d->N * d->K, 256) + align_up((size_t)d->N * 4, 256) + (d->w8_d0 >= 0 ? align_up((size_t)d->N * 4, 256) : 0);
   }
   if (lin.empty()) return FMI_OK;
   FMI_HIP_TRY(hipMalloc((void**)&m->fp8_arena, bytes));
@@ -1584,6 +1606,11 @@ static int quantize_8bit(fmi_flux* m, int kind, unsigned mask, void* stream) {
     d->w8_scale = reinterpret_cast<float*>(m->fp8_arena + off);
     off += align_up((size_t)d->N * 4, 256);
     FMI_TRY(launch_quantize_rows_fp8(d->w, d->K, d->N, d->K, d->w8, d->w8_scale, s, kind));
+    if (d->w8_d0 >= 0) {
+      d->w8_sum = reinterpret_cast<float*>(m->fp8_arena + off);
+      off += align_up((size_t)d->N * 4, 256);
+      FMI_TRY(launch_rowsum_i8(reinterpret_cast<const int8_t*>(d->w8), d->w8_scale, d->N, d->K, d->w8_d0, d->w8_sum, s));
+    }
   }
   FMI_HIP_TRY(hipStreamSynchronize(s));
   FMI_TRY(compute_attention_scales(m));

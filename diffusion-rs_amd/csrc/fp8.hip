@@ -13,6 +13,15 @@
 //   q[r,k]     = clamp(rint(x[r,k] * (127 / max(absmax, 1e-30))), -127, 127)      (round half to even)
 //   y[m,n]     = float(sum_k q_a[m,k] q_w[n,k]) * (scale_a[m] * scale_w[n]) + bias[n]     (exact int32 sum)
 // — uniform steps instead of a 3-bit mantissa: 8.5e-3 rms per Gaussian operand against e4m3's 2.65e-2.
+// Round 5, the int8 recipe's form for POST-GELU operands (oracle: orc_quantize_rows_i8_asym).  gelu(h) >= -0.17, so a grid symmetric around 0
+// spends half of its codes on values that never occur (the oracle study: the double blocks' MLP-out alone 2.14e-2 -> 1.54e-2, the single
+// blocks' linear2 1.82e-2 -> 1.3e-2).  Columns [0, d0) of a row — a signed segment in front: linear2 reads cat(attention, gelu(mlp)), d0 = D;
+// d0 = 0 for none — stay symmetric, columns [d0, K) take 256 levels over [lo, hi] = their min / max, all with ONE step s per row, so the
+// product stays one exact integer sum per output:
+//   s = max(max((hi - lo) / 255, absmax(front) / 127), 1e-30), inv = 1 / s
+//   k <  d0: q = clamp(rint(x * inv), -127, 127)              value = s * q
+//   k >= d0: q = clamp(rint((x - lo) * inv), 0, 255) - 128     value = s * q + offset,  offset = lo + 128 s
+//   y[m,n] = float(sum_k q[m,k] q_w[n,k]) * (s[m] * scale_w[n]) + offset[m] * wsum[n] + bias[n],  wsum[n] = scale_w[n] * float(sum_{k >= d0} q_w[n,k])
 // Both kernels are one pass over HBM per row block: a 256-thread block owns a row, keeps it in
 // registers between the absmax reduction and the conversion, 16-byte loads, 8-byte stores.
 #include "common.h"
@@ -93,6 +102,89 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __
       o[i] = make_uint2(pack_q8x4<I8>(f[0], f[1], f[2], f[3]), pack_q8x4<I8>(f[4], f[5], f[6], f[7]));
     }
   }
+}
+
+__device__ __forceinline__ float block_min_256(float v, float* red) {
+  v = -wave_max(-v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+}
+// the post-GELU form (header): chunks of 8 columns below d0 / 8 are the symmetric front segment
+__global__ __launch_bounds__(256) void quantize_rows_i8_asym_kernel(const bf16_t* __restrict x, int ld, int K, int d0c, uint8_t* __restrict out,
+                                                                    float* __restrict scale, float* __restrict offset) {
+  __shared__ float red[3][4];
+  const int row = blockIdx.x;
+  const uint4* xr = reinterpret_cast<const uint4*>(x + (int64_t)row * ld);
+  const int nc = K >> 3;
+  uint4 v[QR_MAXC];
+  float am = 0.f, lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < QR_MAXC; ++c) {
+    const int i = threadIdx.x + c * 256;
+    if (i < nc) {
+      v[c] = xr[i];
+      const uint32_t u[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+      float cmin = INFINITY, cmax = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = __uint_as_float(u[e] << 16), b = __uint_as_float(u[e] & 0xffff0000u);
+        cmin = fminf(cmin, fminf(a, b)), cmax = fmaxf(cmax, fmaxf(a, b));
+      }
+      if (i < d0c) am = fmaxf(am, fmaxf(fabsf(cmin), fabsf(cmax)));
+      else lo = fminf(lo, cmin), hi = fmaxf(hi, cmax);
+    }
+  }
+  am = block_max_256(am, red[0]);
+  hi = block_max_256(hi, red[1]);
+  lo = block_min_256(lo, red[2]);
+  const float s = fmaxf(fmaxf((hi - lo) / 255.0f, am / 127.0f), 1e-30f);
+  const float inv = 1.0f / s;
+  if (threadIdx.x == 0) {
+    scale[row] = s;
+    offset[row] = lo + 128.0f * s;
+  }
+  uint2* o = reinterpret_cast<uint2*>(out + (int64_t)row * K);
+#pragma unroll
+  for (int c = 0; c < QR_MAXC; ++c) {
+    const int i = threadIdx.x + c * 256;
+    if (i < nc) {
+      const uint32_t u[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f[2 * e] = __uint_as_float(u[e] << 16);
+        f[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+      }
+      uint32_t w[2];
+      if (i < d0c) {
+        w[0] = pack_i8x4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv);
+        w[1] = pack_i8x4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv);
+      } else {
+        auto q = [&](float t) { return (uint32_t)((int)fminf(fmaxf(rintf((t - lo) * inv), 0.0f), 255.0f) - 128) & 0xffu; };
+        w[0] = q(f[0]) | (q(f[1]) << 8) | (q(f[2]) << 16) | (q(f[3]) << 24);
+        w[1] = q(f[4]) | (q(f[5]) << 8) | (q(f[6]) << 16) | (q(f[7]) << 24);
+      }
+      o[i] = make_uint2(w[0], w[1]);
+    }
+  }
+}
+// one wave per weight row: the exact integer sum of its codes from column d0 on, times the row's scale
+__global__ __launch_bounds__(256) void rowsum_i8_kernel(const int8_t* __restrict wq, const float* __restrict w_scale, int N, int K, int d0,
+                                                        float* __restrict w_sum) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const int4* r = reinterpret_cast<const int4*>(wq + (int64_t)n * K);
+  int t = 0;
+  for (int i = (d0 >> 4) + lane; i < (K >> 4); i += 64) {
+    const int4 x = r[i];
+    const int w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t += (int)(int8_t)(w[e] & 0xff) + (int)(int8_t)((w[e] >> 8) & 0xff) + (int)(int8_t)((w[e] >> 16) & 0xff) + (w[e] >> 24);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  if (lane == 0) w_sum[n] = w_scale[n] * (float)t;
 }
 
 // layernorm_mod_kernel (norm_rope.hip) with the quantisation fused: statistics, then the modulated
@@ -187,6 +279,22 @@ int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* 
   if (K <= 0 || K % 8 || ld % 8 || K > 256 * 8 * QR_MAXC) return fail(FMI_ERR_INVALID, "quantize_rows_fp8: K and ld must be multiples of 8, K <= 16384");
   if (kind == 2) hipLaunchKernelGGL(quantize_rows_fp8_kernel<true>, dim3(rows), dim3(256), 0, stream, x, ld, K, out, scale);
   else hipLaunchKernelGGL(quantize_rows_fp8_kernel<false>, dim3(rows), dim3(256), 0, stream, x, ld, K, out, scale);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
+int launch_quantize_rows_i8_asym(const bf16_t* x, int ld, int rows, int K, int d0, uint8_t* out, float* scale, float* offset, hipStream_t stream) {
+  if (rows <= 0) return FMI_OK;
+  if (K <= 0 || K % 8 || ld % 8 || K > 256 * 8 * QR_MAXC) return fail(FMI_ERR_INVALID, "quantize_rows_i8_asym: K and ld must be multiples of 8, K <= 16384");
+  if (d0 < 0 || d0 >= K || d0 % 8) return fail(FMI_ERR_INVALID, "quantize_rows_i8_asym: the offset segment starts at a multiple of 8 below K");
+  hipLaunchKernelGGL(quantize_rows_i8_asym_kernel, dim3(rows), dim3(256), 0, stream, x, ld, K, d0 >> 3, out, scale, offset);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+int launch_rowsum_i8(const int8_t* wq, const float* w_scale, int N, int K, int d0, float* w_sum, hipStream_t stream) {
+  if (N <= 0) return FMI_OK;
+  if (K % 16 || d0 % 16 || d0 < 0 || d0 > K) return fail(FMI_ERR_INVALID, "rowsum_i8: K and d0 must be multiples of 16");
+  hipLaunchKernelGGL(rowsum_i8_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, wq, w_scale, N, K, d0, w_sum);
   FMI_LAUNCH_CHECK();
   return FMI_OK;
 }

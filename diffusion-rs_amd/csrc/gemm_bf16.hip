@@ -1072,21 +1072,36 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_pp_kernel(const GemmBatc
         for (int r = 0; r < 16; ++r) acc[i][j][r] = (float)acci[i][j][r];
   }
   if constexpr (FP8) {  // dequantise: per-token scale of the row, per-channel scale of the 4 consecutive columns
-    float sa[4];
+    float sa[4], oa[4];
+    const bool off = I8 && P.a_off != nullptr;  // int8, post-GELU form of the row codes: + a_off[m] * w_sum[n] (uniform per problem)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sa[i] = P.a_scale[min(m0 + g * 128 + i * 32 + (lane & 31), P.M - 1)];
+    for (int i = 0; i < 4; ++i) {
+      const int r = min(m0 + g * 128 + i * 32 + (lane & 31), P.M - 1);
+      sa[i] = P.a_scale[r];
+      oa[i] = off ? P.a_off[r] : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
-        float sn[4];
+        float sn[4], wsn[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) sn[c] = P.w_scale[min(n + c, P.N - 1)];
+        for (int c = 0; c < 4; ++c) {
+          sn[c] = P.w_scale[min(n + c, P.N - 1)];
+          wsn[c] = off ? P.w_sum[min(n + c, P.N - 1)] : 0.f;
+        }
+        if (off) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] *= sa[i] * sn[c];
+            for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] = acc[i][j][4 * q + c] * (sa[i] * sn[c]) + oa[i] * wsn[c];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] *= sa[i] * sn[c];
+        }
       }
   }
   // the lane id is laundered (as in w4_epilogue): what the epilogue derives from it is then computed here, not hoisted above the
@@ -1457,6 +1472,8 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
     if (p.fp8 != probs[0].fp8 || p.fp8 < 0 || p.fp8 > 2) return fail(FMI_ERR_INVALID, "launch_gemm: cannot mix e4m3 / int8 / bf16 problems in one group");
     if (fp8 && (p.q_type || p.cv_ks || bn != 256 || p.K % 128 || p.lda % 16 || p.ldw % 16 || !p.a_scale || !p.w_scale))
       return fail(FMI_ERR_INVALID, "launch_gemm: fp8 needs dense operands, N > 128, K / lda / ldw multiples of 128 / 16 / 16 and both scale vectors");
+    if ((p.a_off != nullptr) != (p.w_sum != nullptr) || (p.a_off && p.fp8 != 2))
+      return fail(FMI_ERR_INVALID, "launch_gemm: the offset term (a_off, w_sum) belongs to int8 problems and needs both vectors");
     if (p.K <= 0 || p.K % BK != 0) return fail(FMI_ERR_INVALID, "launch_gemm: K must be a positive multiple of 64, got " + std::to_string(p.K));
     if ((p.q_type != 0) != quant || (p.cv_ks != 0) != conv) return fail(FMI_ERR_INVALID, "launch_gemm: cannot mix dense / 4-bit / conv problems in one group");
     if (quant && conv) return fail(FMI_ERR_UNSUPPORTED, "launch_gemm: quantised convolution");

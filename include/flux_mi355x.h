@@ -36,7 +36,8 @@ extern "C" {
 
 /* 4 (round 4): + fmi_build_id, fmi_comm_probe, fmi_flux_set_attention_kernel; fmi_flux_set_modulation_gemm accepts 2; fmi_set_attention_kernel accepts 5.
  * 5 (round 5): + the caller-owned-workspace forms fmi_sdpa_bf16_ws / fmi_sdpa_fp8qk_ws / fmi_linear_fp8_ws / fmi_linear_i8_ws and their size queries;
- *   fmi_sdpa_* / fmi_linear_fp8 / fmi_linear_i8 no longer synchronise the stream or call hipMalloc.
+ *   fmi_sdpa_* / fmi_linear_fp8 / fmi_linear_i8 no longer synchronise the stream or call hipMalloc; + fmi_quantize_rows_i8_asym, fmi_rowsum_i8,
+ *   fmi_gemm_i8_asym (the int8 mode's post-GELU operand form); fmi_flux_set_quant_dense_cache accepts -1 (default: by memory) and 3.
  * Additions only: a host bound against version 3 keeps working. */
 #define FMI_ABI_VERSION 5
 
@@ -525,6 +526,20 @@ int fmi_linear_i8_ws(const void* x, const int8_t* wq, const float* w_scale, cons
  * activations quantised between layers binds; also what tools/hipblaslt_yardstick.py times against the vendor library's fp8 GEMM). */
 int fmi_gemm_q8(const void* xq, const float* x_scale, const void* wq, const float* w_scale, const void* bias, void* y,
                 int M, int N, int K, int kind, fmi_epilogue epi, void* stream);
+/* The int8 recipe's form for POST-GELU operands (round 5; oracle: orc_quantize_rows_i8_asym / orc_linear_i8_asym).  gelu(h) >= -0.17, so a grid
+ * symmetric around 0 wastes half of its codes there.  Columns [0, d0) of a row (a signed segment in front — the single blocks' linear2 reads
+ * cat(attention, gelu(mlp)), d0 = 3072; d0 = 0 for none) stay symmetric, columns [d0, K) take 256 levels over their [min, max] = [lo, hi], all with
+ * ONE step per row so the product stays one exact int32 sum:
+ *   scale[r] = s = max(max((hi - lo) / 255, absmax(front) / 127), 1e-30);  offset[r] = lo + 128 s
+ *   k <  d0: out = clamp(rint(x / s), -127, 127)            k >= d0: out = clamp(rint((x - lo) / s), 0, 255) - 128
+ *   fmi_rowsum_i8:    w_sum[n] = w_scale[n] * float(sum_{k >= d0} wq[n,k])      (once per weight)
+ *   fmi_gemm_i8_asym: y = epi(float(xq · wq^T) * (x_scale[m] * w_scale[n]) + x_offset[m] * w_sum[n] + bias[n])
+ * x (rows,K) bf16, K % 8 == 0, K <= 16384, d0 % 16 == 0; GEMM shape rules as fmi_gemm_q8.  What fmi_flux_quantize_int8 uses in front of the double
+ * blocks' MLP-out and the single blocks' linear2.  Stream-ordered, nothing allocated. */
+int fmi_quantize_rows_i8_asym(const void* x, int rows, int K, int d0, int8_t* out, float* scale, float* offset, void* stream);
+int fmi_rowsum_i8(const int8_t* wq, const float* w_scale, int N, int K, int d0, float* w_sum, void* stream);
+int fmi_gemm_i8_asym(const void* xq, const float* x_scale, const float* x_offset, const void* wq, const float* w_scale, const float* w_sum,
+                     const void* bias, void* y, int M, int N, int K, fmi_epilogue epi, void* stream);
 /* softmax(q k^T * scale) v, q,k,v,o (B,H,L,d) bf16, d == 128, non-causal; o is written
  * token-major (B,L,H*d) when `out_token_major`, else (B,H,L,d).
  * == backend::ops::sdpa fallback (ops.rs:247-262) without materialising the scores. */

@@ -754,10 +754,43 @@ extern "C" void orc_quantize_rows_i8(const float* x, int rows, int K, int8_t* ou
     for (int k = 0; k < K; ++k) out[(int64_t)r * K + k] = (int8_t)fminf(fmaxf(nearbyintf(xr[k] * inv), -127.0f), 127.0f);
   }
 }
+// Round 5, the int8 recipe's form for POST-GELU operands (no reference counterpart; csrc/fp8.hip's header states it for the HIP path).  gelu(h) >= -0.17:
+// a grid symmetric around 0 spends half of its codes on values that never occur.  Columns [0, d0) of a row — a signed segment in front, d0 = 0 for none;
+// the single blocks' linear2 reads cat(attention, gelu(mlp)), d0 = D — stay symmetric, columns [d0, K) take 256 levels over [lo, hi] = their min / max,
+// all with ONE step s per row so that the product is still one integer sum:
+//   s = max(max((hi - lo) / 255, absmax(front) / 127), 1e-30), inv = 1 / s
+//   k <  d0: q = clamp(rint(x * inv), -127, 127)                     value = s * q
+//   k >= d0: q = clamp(rint((x - lo) * inv), 0, 255) - 128            value = s * q + (lo + 128 s)
+//   y[m,n] = float(sum_k q[m,k] qw[n,k]) * (s[m] * sw[n]) + offset[m] * wsum[n] + b[n],   offset = lo + 128 s,  wsum[n] = sw[n] * float(sum_{k >= d0} qw[n,k])
+extern "C" void orc_quantize_rows_i8_asym(const float* x, int rows, int K, int d0, int8_t* out, float* scale, float* offset) {
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r) {
+    const float* xr = x + (int64_t)r * K;
+    float am = 0.f, lo = xr[d0], hi = xr[d0];
+    for (int k = 0; k < d0; ++k) am = fmaxf(am, fabsf(xr[k]));
+    for (int k = d0; k < K; ++k) lo = fminf(lo, xr[k]), hi = fmaxf(hi, xr[k]);
+    const float s = fmaxf(fmaxf((hi - lo) / 255.0f, am / 127.0f), 1e-30f), inv = 1.0f / s;
+    scale[r] = s;
+    offset[r] = lo + 128.0f * s;
+    int8_t* o = out + (int64_t)r * K;
+    for (int k = 0; k < d0; ++k) o[k] = (int8_t)fminf(fmaxf(nearbyintf(xr[k] * inv), -127.0f), 127.0f);
+    for (int k = d0; k < K; ++k) o[k] = (int8_t)(fminf(fmaxf(nearbyintf((xr[k] - lo) * inv), 0.0f), 255.0f) - 128.0f);
+  }
+}
+// wsum[n] = sw[n] * float(sum_{k >= d0} qw[n,k]): the integer sum is exact in f32 (< 2^24)
+static void i8_wsum(const float* qw, const float* sw, int N, int K, int d0, float* wsum) {
+#pragma omp parallel for
+  for (int n = 0; n < N; ++n) {
+    int32_t t = 0;
+    for (int k = d0; k < K; ++k) t += (int32_t)qw[(int64_t)n * K + k];
+    wsum[n] = sw[n] * (float)t;
+  }
+}
 // y[m,n] = float(sum_k qx[m,k] qw[n,k]) * (sx[m] * sw[n]) + b[n], the sum an EXACT integer (as the int8 MFMA's int32 accumulator):
 // the f32 GEMM runs over slices of 1024 k, inside which every partial sum is an integer below 2^24 (1024 * 127^2) and therefore exact
 // in any order, and the slices are added in double.  qx / qw hold the codes as floats.
-static void gemm_i8_exact(const float* qx, const float* sx, const float* qw, const float* sw, const float* bias, int M, int N, int K, float* y) {
+static void gemm_i8_exact(const float* qx, const float* sx, const float* qw, const float* sw, const float* bias, int M, int N, int K, float* y,
+                          const float* xoff = nullptr, const float* wsum = nullptr) {
   std::vector<double> acc((size_t)M * N, 0.0);
   std::vector<float> part((size_t)M * N);
   for (int k0 = 0; k0 < K; k0 += 1024) {
@@ -768,7 +801,22 @@ static void gemm_i8_exact(const float* qx, const float* sx, const float* qw, con
   }
 #pragma omp parallel for
   for (int r = 0; r < M; ++r)
-    for (int n = 0; n < N; ++n) y[(int64_t)r * N + n] = (float)(int32_t)acc[(int64_t)r * N + n] * (sx[r] * sw[n]) + (bias ? bias[n] : 0.f);
+    for (int n = 0; n < N; ++n) {
+      float v = (float)(int32_t)acc[(int64_t)r * N + n] * (sx[r] * sw[n]);
+      if (xoff) v += xoff[r] * wsum[n];
+      y[(int64_t)r * N + n] = v + (bias ? bias[n] : 0.f);
+    }
+}
+// linear with the activation on the post-GELU form (d0 as above), weights symmetric per row
+extern "C" void orc_linear_i8_asym(const float* x, const float* w, const float* bias, int M, int N, int K, int d0, float* y) {
+  std::vector<int8_t> xc((size_t)M * K), wc((size_t)N * K);
+  std::vector<float> xs(M), xo(M), ws(N), wsum(N), xq((size_t)M * K), wq((size_t)N * K);
+  orc_quantize_rows_i8_asym(x, M, K, d0, xc.data(), xs.data(), xo.data());
+  orc_quantize_rows_i8(w, N, K, wc.data(), ws.data());
+  for (size_t i = 0; i < xc.size(); ++i) xq[i] = (float)xc[i];
+  for (size_t i = 0; i < wc.size(); ++i) wq[i] = (float)wc[i];
+  i8_wsum(wq.data(), ws.data(), N, K, d0, wsum.data());
+  gemm_i8_exact(xq.data(), xs.data(), wq.data(), ws.data(), bias, M, N, K, y, xo.data(), wsum.data());
 }
 extern "C" void orc_linear_i8(const float* x, const float* w, const float* bias, int M, int N, int K, float* y) {
   std::vector<int8_t> xc((size_t)M * K), wc((size_t)N * K);
@@ -786,6 +834,7 @@ extern "C" void orc_linear_i8(const float* x, const float* w, const float* bias,
 struct Fp8Weight {
   std::vector<float> q;  // e4m3 values (dequantised codes, unscaled), (N, K)
   std::vector<float> s;  // per-output-channel scale
+  std::vector<float> wsum;  // int8 recipe, post-GELU operand: s[n] * sum of the codes over the offset segment's columns (i8_wsum)
 };
 struct orc_flux {
   int fp8 = 0;  // block linears on the fp8 recipe above
@@ -797,6 +846,7 @@ struct orc_flux {
   // which block linears take the 8-bit recipe (the others stay f32 / lin_fwd): bit 0 double q|k|v, 1 double attention out, 2 double MLP in,
   // 3 double MLP out, 4 single linear1 (q, k, v, proj_mlp), 5 single linear2 (proj_out).  orc_flux_set_q8_mask; default all.
   int q8_mask = 0x3f;
+  int q8_sym = 0;  // 1 = round 4's int8 recipe: every operand symmetric, the post-GELU ones included (orc_flux_set_q8_symmetric; the library's FMI_INT8_SYMMETRIC study switch)
   std::map<const float*, Fp8Weight> fp8_w;
   int in_channels, pooled_dim, joint_dim, heads, n_double, n_single, guidance;
   int axes[3], theta;
@@ -889,6 +939,7 @@ extern "C" void orc_flux_set_fp8(orc_flux* m, int on) {
 }
 extern "C" void orc_flux_set_fp8_attention(orc_flux* m, int on) { m->fp8_attn = on; }
 extern "C" void orc_flux_set_q8_mask(orc_flux* m, int mask) { m->q8_mask = mask; }
+extern "C" void orc_flux_set_q8_symmetric(orc_flux* m, int on) { m->q8_sym = on; }
 extern "C" int orc_flux_set_tensor(orc_flux* m, const char* name, const float* data, int64_t numel) {
   m->t[name] = std::vector<float>(data, data + numel);
   m->t16.erase(name);
@@ -984,6 +1035,20 @@ void lin_blk(orc_flux* m, const Lin& l, const float* x, int rows, float* y, int 
     }
     std::vector<int8_t> xc((size_t)rows * l.in);
     std::vector<float> xs(rows), xq((size_t)rows * l.in);
+    // round 5: the post-GELU operands — the input of the double blocks' MLP-out and the gelu(mlp) segment of the single blocks' linear2 input — on the
+    // offset grid (orc_quantize_rows_i8_asym); everything else symmetric as before
+    const int d0 = which == LIN_DBL_MLP2 ? 0 : which == LIN_SGL_2 ? m->D : -1;
+    if (d0 >= 0 && !m->q8_sym) {
+      std::vector<float> xo(rows);
+      if (fw.wsum.empty()) {
+        fw.wsum.resize(l.out);
+        i8_wsum(fw.q.data(), fw.s.data(), l.out, l.in, d0, fw.wsum.data());
+      }
+      orc_quantize_rows_i8_asym(x, rows, l.in, d0, xc.data(), xs.data(), xo.data());
+      for (size_t i = 0; i < xc.size(); ++i) xq[i] = (float)xc[i];
+      gemm_i8_exact(xq.data(), xs.data(), fw.q.data(), fw.s.data(), l.b, rows, l.out, l.in, y, xo.data(), fw.wsum.data());
+      return;
+    }
     orc_quantize_rows_i8(x, rows, l.in, xc.data(), xs.data());
     for (size_t i = 0; i < xc.size(); ++i) xq[i] = (float)xc[i];
     gemm_i8_exact(xq.data(), xs.data(), fw.q.data(), fw.s.data(), l.b, rows, l.out, l.in, y);
@@ -994,16 +1059,32 @@ void lin_blk(orc_flux* m, const Lin& l, const float* x, int rows, float* y, int 
     // 8 = int8 as 5 with the ASYMMETRIC grid (kind 8: 256 levels over [min, max] of the row) on the post-GELU operands: the input of the double blocks'
     //     MLP-out, and the gelu(mlp) segment of linear2's input (its attention segment symmetric, a scale per segment as in 7)      [round 5 study]
     // 9 = as 8, but linear2's input as ONE asymmetric row (one scale + offset over cat(attention, gelu(mlp)): what a single launch can apply)
-    static const int wk[10] = {0, 1, 2, 1, 0, 5, 0, 5, 5, 5}, ak[10] = {0, 1, 2, 0, 1, 5, 2, 5, 5, 5};
-    const int mode = std::min(std::max(m->fp8, 2), 9);
+    // 10 = as 8, but linear2's input with ONE step per row shared by its two segments — s = max((hi - lo) / 255 of the gelu segment, absmax / 127 of the
+    //     attention segment) — the attention segment symmetric around 0, the gelu segment offset by its minimum: what a single launch can apply with an
+    //     offset term over the gelu columns only
+    static const int wk[11] = {0, 1, 2, 1, 0, 5, 0, 5, 5, 5, 5}, ak[11] = {0, 1, 2, 0, 1, 5, 2, 5, 5, 5, 5};
+    const int mode = std::min(std::max(m->fp8, 2), 10);
     Fp8Weight& fw = m->fp8_w[l.w];
     if (fw.q.empty()) {
       fw.q.resize((size_t)l.out * l.in);
       study_quantise(l.w, l.out, l.in, wk[mode], fw.q.data());
     }
     std::vector<float> xq((size_t)rows * l.in);
-    if ((mode == 8 || mode == 9) && which == LIN_DBL_MLP2) {
+    if ((mode == 8 || mode == 9 || mode == 10) && which == LIN_DBL_MLP2) {
       study_quantise(x, rows, l.in, 8, xq.data());
+    } else if (mode == 10 && which == LIN_SGL_2) {
+      const int D = m->D, K = l.in;
+#pragma omp parallel for
+      for (int r = 0; r < rows; ++r) {
+        const float* xr = x + (size_t)r * K;
+        float* o = xq.data() + (size_t)r * K;
+        float am = 0.f, lo = xr[D], hi = xr[D];
+        for (int k = 0; k < D; ++k) am = fmaxf(am, fabsf(xr[k]));
+        for (int k = D; k < K; ++k) lo = fminf(lo, xr[k]), hi = fmaxf(hi, xr[k]);
+        const float sc = fmaxf(fmaxf((hi - lo) / 255.0f, am / 127.0f), 1e-30f), inv = 1.0f / sc;
+        for (int k = 0; k < D; ++k) o[k] = fminf(fmaxf(nearbyintf(xr[k] * inv), -127.f), 127.f) * sc;
+        for (int k = D; k < K; ++k) o[k] = fminf(fmaxf(nearbyintf((xr[k] - lo) * inv), 0.f), 255.f) * sc + lo;
+      }
     } else if (mode == 9 && which == LIN_SGL_2) {
       study_quantise(x, rows, l.in, 8, xq.data());
     } else if ((mode == 7 || mode == 8) && which == LIN_SGL_2) {

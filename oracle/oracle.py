@@ -58,6 +58,12 @@ def lib():
         _lib.orc_quantize_rows_i8.restype = None
         _lib.orc_linear_i8.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p]
         _lib.orc_linear_i8.restype = None
+        _lib.orc_quantize_rows_i8_asym.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, f32p, f32p]
+        _lib.orc_quantize_rows_i8_asym.restype = None
+        _lib.orc_linear_i8_asym.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+        _lib.orc_linear_i8_asym.restype = None
+        _lib.orc_flux_set_q8_symmetric.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_flux_set_q8_symmetric.restype = None
     return _lib
 
 
@@ -288,6 +294,30 @@ def quantize_rows_i8(x):
     scale = np.empty(rows, np.float32)
     lib().orc_quantize_rows_i8(xp, rows, K, out.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(f32p))
     return out, scale
+
+
+def quantize_rows_i8_asym(x, d0=0):
+    """int8 recipe, post-GELU form (flux_oracle.cpp: orc_quantize_rows_i8_asym): columns [0, d0) symmetric, [d0, K) on 256 levels over their
+    [min, max], one step per row.  Returns (codes int8, scale f32, offset f32)."""
+    x, xp = _f(x)
+    rows, K = x.shape
+    out = np.empty((rows, K), np.int8)
+    scale = np.empty(rows, np.float32)
+    off = np.empty(rows, np.float32)
+    lib().orc_quantize_rows_i8_asym(xp, rows, K, int(d0), out.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(f32p), off.ctypes.data_as(f32p))
+    return out, scale, off
+
+
+def linear_i8_asym(x, w, b=None, d0=0):
+    """y = float(q(x) q(w)^T) * (sx * sw) + offset * wsum + b with x on the post-GELU form and w symmetric per row (orc_linear_i8_asym)."""
+    x, xp = _f(x)
+    w, wp = _f(w)
+    M, K = x.shape
+    N = w.shape[0]
+    y = np.empty((M, N), np.float32)
+    b_, bp = _opt(b)
+    lib().orc_linear_i8_asym(xp, wp, bp, M, N, K, int(d0), y.ctypes.data_as(f32p))
+    return y
 
 
 def linear_i8(x, w, b=None):

@@ -4,6 +4,9 @@ Like the fp8 mode this recipe is the library's own (the reference has no 8-bit M
 oracle/flux_oracle.cpp (orc_quantize_rows_i8, orc_linear_i8, lin_blk mode 5).  Why it exists: tools/fp8_noise_study.py — an e4m3
 operand is 2.65e-2 rms from its value whatever the scale granularity, a per-row int8 one 8.5e-3, at the same matrix-pipe rate.
 
+Round 5: the operands that follow a GELU (the input of the double blocks' MLP-out, the gelu(mlp) segment of the single blocks' linear2 input) take
+256 levels over their [min, max] instead of a grid symmetric around 0 (fp8.hip's header; oracle: orc_quantize_rows_i8_asym) — same bars.
+
 Bars: quantisation bit-exact (codes and scales); the int8 MFMA's k map pinned by an EXACT integer GEMM (unit scales, sums below 256:
 every output is an integer that bf16 holds); int8 GEMM vs the oracle on the same codes rel-L2 <= 2e-3 (bf16 output rounding only —
 the sums are exact integers on both sides); model evaluation vs the int8 oracle <= 1e-2 (the bf16 path's bar), vs the f32 oracle
@@ -139,6 +142,88 @@ def test_gemm_q8_on_prequantised_operands_equals_the_linear(env, kind):
         assert torch.equal(y1.view(torch.int16), y2.view(torch.int16))
     assert lib.fmi_gemm_q8(_p(xq), _p(xs), _p(wq), _p(ws), None, _p(y2), M, N, K, 3, 0, None) < 0   # no such kind
     assert lib.fmi_gemm_q8(_p(xq), None, _p(wq), _p(ws), None, _p(y2), M, N, K, 1, 0, None) < 0
+
+
+def _post_gelu_rows(rng, rows, K, d0):
+    """rows shaped like the library's post-GELU operands: a signed segment [0, d0) (attention rows) and gelu(h), h ~ N(0, sigma_row), behind it"""
+    x = np.empty((rows, K), np.float32)
+    x[:, :d0] = 0.3 * rng.standard_normal((rows, d0))
+    h = rng.standard_normal((rows, K - d0)) * (10.0 ** rng.uniform(-1, 1, (rows, 1)))
+    x[:, d0:] = 0.5 * h * (1.0 + np.tanh(0.7978845608 * h * (1.0 + 0.044715 * h * h)))
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("rows,K,d0", [(3, 16, 0), (64, 512, 0), (300, 15360, 3072), (7, 4096, 1024), (33, 12288, 0), (5, 16384, 16)])
+def test_quantize_rows_i8_asym_bit_exact(env, rows, K, d0):
+    """The int8 recipe's post-GELU form (round 5, fp8.hip's header): codes, step and offset bit for bit against the oracle — a constant row, an
+    all-zero row, a front segment that dictates the step, ties of the rounding."""
+    torch, L, lib, orc = env["torch"], env["L"], env["lib"], env["orc"]
+    rng = np.random.default_rng(rows * 7 + K + d0)
+    x = _post_gelu_rows(rng, rows, K, d0)
+    if rows > 2:
+        x[1] = 0.0                      # all zero: step 1e-30, codes -128 behind d0 (value = lo = 0), 0 in front
+        x[2, d0:] = 0.75                # a constant offset segment: hi == lo
+    if rows > 4 and d0:
+        x[4, :d0] *= 50.0               # the front segment's absmax / 127 exceeds (hi - lo) / 255: it sets the step
+    if rows > 5:                        # ties: (x - lo) / s = n + 0.5 exactly (lo = 0, hi = 255 -> s = 1)
+        x[5, d0:] = 0.0
+        x[5, d0:d0 + 8] = [255.0, 0.5, 1.5, 2.5, 126.5, 127.5, 254.5, 3.0]
+        x[5, :d0] = 0.0
+    x = bf16_round(x)
+    xd = dev(x, torch.bfloat16)
+    q = torch.empty(rows, K, dtype=torch.int8, device="cuda")
+    sc = torch.empty(rows, dtype=torch.float32, device="cuda")
+    of = torch.empty(rows, dtype=torch.float32, device="cuda")
+    L.check(lib.fmi_quantize_rows_i8_asym(_p(xd), rows, K, d0, _p(q), _p(sc), _p(of), None))
+    torch.cuda.synchronize()
+    rq, rs, ro = orc.quantize_rows_i8_asym(x, d0)
+    np.testing.assert_array_equal(sc.cpu().numpy(), rs)
+    np.testing.assert_array_equal(of.cpu().numpy(), ro)
+    np.testing.assert_array_equal(q.cpu().numpy(), rq)
+    if rows > 5:
+        assert rq[5, d0:d0 + 8].tolist() == [127, -128, -126, -126, -2, 0, 126, -125]  # round half to even, then - 128
+    # the grid does what it is for: on post-GELU rows the reconstruction is about twice as close as the symmetric recipe's
+    deq = rq.astype(np.float32) * rs[:, None]
+    deq[:, d0:] += ro[:, None]
+    sq, ss = orc.quantize_rows_i8(x)
+    body = slice(6, None) if rows > 6 else slice(0, 1)
+    e_asym, e_sym = rel_l2(deq[body], x[body]), rel_l2(sq[body].astype(np.float32) * ss[body, None], x[body])
+    print(f"post-GELU rows {rows}x{K} (front segment {d0}): reconstruction rel-L2 {e_asym:.2e} on the offset grid, {e_sym:.2e} symmetric")
+    if d0 == 0 and rows > 6:
+        assert e_asym <= 0.65 * e_sym
+    assert lib.fmi_quantize_rows_i8_asym(_p(xd), rows, K, K, _p(q), _p(sc), _p(of), None) < 0      # no offset segment left
+    assert lib.fmi_quantize_rows_i8_asym(_p(xd), rows, K, 4, _p(q), _p(sc), _p(of), None) < 0      # d0 % 8
+
+
+@pytest.mark.parametrize("M,N,K,d0,epi", [(300, 384, 512, 128, 0), (257, 512, 15360, 3072, 0), (1024, 3072, 12288, 0, 0), (64, 260, 1280, 0, 1)])
+def test_gemm_i8_asym_matches_oracle(env, M, N, K, d0, epi):
+    """quantise (offset form) -> column sums of the weight codes -> int8 GEMM with the offset term, against orc_linear_i8_asym on the same bf16
+    inputs: the integer sums are exact on both sides, so the two differ by the bf16 rounding of the output only."""
+    torch, L, lib, orc = env["torch"], env["L"], env["lib"], env["orc"]
+    rng = np.random.default_rng(M + N + K + d0)
+    x = bf16_round(_post_gelu_rows(rng, M, K, d0))
+    w = bf16_round((rng.standard_normal((N, K)) * 0.05).astype(np.float32))
+    b = bf16_round(rng.standard_normal(N).astype(np.float32))
+    xd, wd, bd = dev(x, torch.bfloat16), dev(w, torch.bfloat16), dev(b, torch.bfloat16)
+    wq, ws = gpu_quantize(env, wd)
+    wsum = torch.empty(N, dtype=torch.float32, device="cuda")
+    L.check(lib.fmi_rowsum_i8(_p(wq), _p(ws), N, K, d0, _p(wsum), None))
+    xq = torch.empty(M, K, dtype=torch.int8, device="cuda")
+    xs, xo = torch.empty(M, dtype=torch.float32, device="cuda"), torch.empty(M, dtype=torch.float32, device="cuda")
+    L.check(lib.fmi_quantize_rows_i8_asym(_p(xd), M, K, d0, _p(xq), _p(xs), _p(xo), None))
+    y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.fmi_gemm_i8_asym(_p(xq), _p(xs), _p(xo), _p(wq), _p(ws), _p(wsum), _p(bd), _p(y), M, N, K, epi, None))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(wsum.cpu().numpy(), (ws.cpu().numpy() * wq.cpu().numpy()[:, d0:].astype(np.int64).sum(1).astype(np.float32)))
+    ref, sym, f32 = orc.linear_i8_asym(x, w, b, d0), orc.linear_i8(x, w, b), orc.linear(x, w, b)
+    if epi == 1:
+        ref, sym, f32 = orc.gelu(ref), orc.gelu(sym), orc.gelu(f32)
+    err, noise, noise_sym = rel_l2(host(y), ref), rel_l2(ref - b, f32 - b), rel_l2(sym - b, f32 - b)
+    print(f"gemm_i8_asym {M}x{N}x{K} d0={d0} epi={epi}: rel-L2 vs its oracle {err:.2e}; recipe vs f32 linear {noise:.2e} (all-symmetric rows: {noise_sym:.2e})")
+    assert err <= 2e-3
+    if epi == 0:
+        assert noise < noise_sym  # what the offset grid is for
+    assert lib.fmi_gemm_i8_asym(_p(xq), _p(xs), None, _p(wq), _p(ws), _p(wsum), _p(bd), _p(y), M, N, K, epi, None) < 0
 
 
 def test_linear_i8_rejects_bad_shapes(env):

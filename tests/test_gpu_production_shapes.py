@@ -549,6 +549,24 @@ def test_c2_int8_full_model_forward_is_within_the_8_bit_tolerance(full_models):
             e5 = rel_l2(got5, r5)
             print(f"  C5 shape (S=3600 + T=512) in int8 mode vs the f32 oracle: {e5:.3e}")
             assert np.isfinite(got5).all() and e5 <= 3e-2
+        # the other mask worth knowing at full size (round 5): with / without the double blocks' MLP-out in 8 bits — the knapsack of DESIGN 4.3c, measured
+        other = d.flux.INT8_DEFAULT_MASK ^ d.flux.Q8_DOUBLE_MLP_OUT
+        g8b = d.FluxModel(cfg)
+        try:
+            for name, shape in d.synth.flux_tensor_shapes(d.FLUX_DEV).items():
+                g8b.set_tensor(name, _seeded_weight(torch, name, shape, d))
+            g8b.quantize_int8(other)
+            eo = rel_l2(host(g8b.forward(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(t), dev(clip), dev(g))), ref)
+            line = f"  mask 0x{other:02x} on the same forward: {eo:.3e}"
+            if "c5" in full_models:
+                eo5 = rel_l2(host(g8b.forward(dev(i5), dev(d5), dev(t55, torch.bfloat16), dev(x5), dev(tt5), dev(c5), dev(g5))), r5)
+                line += f"; at the C5 shape {eo5:.3e}"
+            if "traj50" in full_models:
+                go50 = host(g8b.denoise(dev(tj["img"]), *a8, tj["ts"]))
+                line += f"; 50-step latents {rel_l2(go50, tj['ref'][50]):.3e}"
+            print(line)
+        finally:
+            g8b.close()
         # --- the GPU implements the STATED recipe: the oracle with the same mask, at a token count its weight quantisation dominates
         rng = np.random.default_rng(83)
         lat = rng.standard_normal((1, 16, 32, 48)).astype(np.float32)  # 16 x 24 = 384 tokens
