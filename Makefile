@@ -21,7 +21,7 @@ lib: $(LIB)
 oracle:
 	$(MAKE) -C oracle -s
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h $(CSRC)/attention_w4_loop.inc $(CSRC)/attention_w16.h $(CSRC)/attention_w16_loop.inc $(CSRC)/attention_w16f8_loop.inc $(CSRC)/attention_w32.h $(CSRC)/attention_w32_loop.inc $(CSRC)/attention_w16l.h $(CSRC)/attention_w16l_loop.inc $(CSRC)/attention_w16lf8_loop.inc include/flux_mi355x.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h $(CSRC)/attention_w4_loop.inc $(CSRC)/attention_w16.h $(CSRC)/attention_w16_loop.inc $(CSRC)/attention_w16f8_loop.inc $(CSRC)/attention_w32.h $(CSRC)/attention_w32_loop.inc $(CSRC)/attention_w16l.h $(CSRC)/attention_w16l_loop.inc $(CSRC)/attention_w16lf8_loop.inc $(CSRC)/attention_w16lf8pv_loop.inc include/flux_mi355x.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -Ibuild -c $< -o $@
 
@@ -53,6 +53,8 @@ $(CSRC)/attention_w16l_loop.inc: tools/gen_attention_w16l.py
 	python3 tools/gen_attention_w16l.py
 $(CSRC)/attention_w16lf8_loop.inc: tools/gen_attention_w16l.py
 	AW16L_MODE=fp8qk python3 tools/gen_attention_w16l.py
+$(CSRC)/attention_w16lf8pv_loop.inc: tools/gen_attention_w16l.py
+	AW16L_MODE=fp8pv python3 tools/gen_attention_w16l.py
 
 clean:
 	rm -rf build $(LIB)

@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--quant", choices=["none", "nf4", "fp8", "int8"], default="none",
                     help="nf4: block linears stored bitsandbytes-nf4, fused dequant-GEMM (config C3); fp8: block linears on the e4m3 MFMA path (config C5); "
                          "int8: the int8 MFMA on the default linear mask (all but the double blocks' MLP); both 8-bit modes hand q and k to the attention as e4m3 (static scales), P.V stays bf16")
+    ap.add_argument("--int8-mask", type=lambda v: int(v, 0), default=None, help="--quant int8: the FMI_Q8_* linear mask (default: the library's FMI_INT8_DEFAULT_MASK)")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU per image step (C5: 2)")
     ap.add_argument("--sequence-parallel", action="store_true",
                     help="N > 1: all ranks denoise ONE image together (token shards, two all-to-alls per block; strong scaling) instead of one image each")
@@ -274,7 +275,7 @@ def main():
     if args.quant == "fp8":
         flux.quantize_fp8()
     if args.quant == "int8":
-        flux.quantize_int8()
+        flux.quantize_int8(args.int8_mask)
     synth.fill_vae_random_device(vae, seed=1, device=dev)
     torch.cuda.synchronize()
     load_s = time.time() - t_load

@@ -166,6 +166,8 @@ def load():
     lib.fmi_sdpa_workspace_bytes.restype = C.c_size_t
     lib.fmi_sdpa_bf16_ws.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.fmi_sdpa_fp8qk_ws.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.fmi_sdpa_fp8.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    lib.fmi_sdpa_fp8_ws.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.fmi_linear_q8_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.fmi_linear_q8_workspace_bytes.restype = C.c_size_t
     lib.fmi_linear_fp8_ws.argtypes = list(lib.fmi_linear_fp8.argtypes[:-1]) + [C.c_void_p, C.c_size_t, C.c_void_p]
@@ -223,7 +225,7 @@ EXPORTED = [
     "fmi_t5_default_config", "fmi_t5_create", "fmi_t5_destroy", "fmi_t5_set_tensor", "fmi_t5_set_linear_bnb4", "fmi_t5_set_linear_int8", "fmi_t5_missing_count", "fmi_t5_missing_name",
     "fmi_t5_size_in_bytes", "fmi_t5_forward", "fmi_clip_default_config", "fmi_clip_create", "fmi_clip_destroy", "fmi_clip_set_tensor",
     "fmi_clip_missing_count", "fmi_clip_missing_name", "fmi_clip_size_in_bytes", "fmi_clip_forward", "fmi_pack_latents", "fmi_unpack_latents", "fmi_postprocess_u8",
-    "fmi_randn", "fmi_philox_u32", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_linear_int8_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_quantize_rows_i8", "fmi_linear_i8", "fmi_gemm_q8", "fmi_quantize_rows_i8_asym", "fmi_rowsum_i8", "fmi_gemm_i8_asym", "fmi_linear_q8_workspace_bytes", "fmi_linear_fp8_ws", "fmi_linear_i8_ws", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_sdpa_workspace_bytes", "fmi_sdpa_bf16_ws", "fmi_sdpa_fp8qk_ws", "fmi_set_attention_kernel", "fmi_layernorm_mod",
+    "fmi_randn", "fmi_philox_u32", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_linear_int8_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_quantize_rows_i8", "fmi_linear_i8", "fmi_gemm_q8", "fmi_quantize_rows_i8_asym", "fmi_rowsum_i8", "fmi_gemm_i8_asym", "fmi_linear_q8_workspace_bytes", "fmi_linear_fp8_ws", "fmi_linear_i8_ws", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_sdpa_workspace_bytes", "fmi_sdpa_bf16_ws", "fmi_sdpa_fp8qk_ws", "fmi_sdpa_fp8", "fmi_sdpa_fp8_ws", "fmi_set_attention_kernel", "fmi_layernorm_mod",
     "fmi_groupnorm_nhwc", "fmi_conv2d_nhwc",
     "fmi_comm_probe", "fmi_comm_unique_id", "fmi_comm_create", "fmi_comm_destroy", "fmi_comm_rank", "fmi_comm_world_size", "fmi_comm_stats", "fmi_comm_all_to_all",
     "fmi_comm_broadcast", "fmi_comm_gather",

@@ -588,7 +588,7 @@ unsigned long long attention_fp8_fallbacks() { return g_fp8_fallbacks.load(std::
 
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
                         int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8, float* lse, int k_hstride, int score_exp2,
-                        int kind) {  // (k_hstride: see the lse branch)
+                        int kind, float v_inv) {  // (k_hstride: see the lse branch)
   // which kernel: the caller's choice (a model handle's fmi_flux_set_attention_kernel, kind 0..5) or, kind < 0, the process-wide switches
   const bool g_att_w16l = kind >= 0 ? kind == 5 : (bool)fmi::g_att_w16l, g_att_w32 = kind >= 0 ? kind == 4 : (bool)fmi::g_att_w32,
              g_att_w16 = kind >= 0 ? kind >= 3 : (bool)fmi::g_att_w16, g_att_w4 = kind >= 0 ? kind >= 2 : (bool)fmi::g_att_w4,
@@ -628,6 +628,17 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
     // counted (fmi_device_info: fp8_attention_fallbacks): launches that WOULD take a one-wave stream — that kernel family is selected and
     // there is more than one KV tile — but whose factor is not a power of two.  A handle or user that picked kernel 0..2 chose the 8-wave
     // kernel; a single-tile problem has no stream to fall back from.
+    if (qk_fp8 == 2) {  // round 5: e4m3 P and V^T as well — the lock-step stream's third form, and the only kernel that reads this V^T
+      if (!(g_att_w16l && g_att_w16) || Lk <= ATT_KV || !pow2)
+        return fail(FMI_ERR_UNSUPPORTED, "attention: e4m3 P / V needs the lock-step kernel (kind 5), more than one KV tile and a power-of-two score factor");
+      const float sl2 = ldexpf(1.0f, n2);
+      if (rescale_thr_x16 == 0)
+        FMI_LAUNCH_LDS((attention_w16l_kernel<0, true, true>), 8 * 16384, grid, dim3(AW16L_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl2, v_inv);
+      else
+        FMI_LAUNCH_LDS((attention_w16l_kernel<96, true, true>), 8 * 16384, grid, dim3(AW16L_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl2, v_inv);
+      FMI_LAUNCH_CHECK();
+      return FMI_OK;
+    }
     if (g_att_w16 && Lk > ATT_KV && !pow2) g_fp8_fallbacks.fetch_add(1, std::memory_order_relaxed);
     if (g_att_w16l && g_att_w16 && Lk > ATT_KV && pow2) {  // round 4: the lock-step schedule's fp8-QK^T stream
       const float sl2 = ldexpf(1.0f, n2);
@@ -761,6 +772,53 @@ int launch_v_transpose(const bf16_t* v, int ldv, int64_t v_bstride, bf16_t* vt, 
   if (ldv % 8) return fail(FMI_ERR_INVALID, "v_transpose: ldv must be a multiple of 8");
   const int g0 = row_off / 64, g1 = (row_off + rows - 1) / 64;
   hipLaunchKernelGGL(v_transpose_kernel, dim3(g1 - g0 + 1, H, B), dim3(256), 0, stream, v, ldv, v_bstride, vt, H, rows, row_off, Lpad, g0);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
+// V (BH, Lk, 128) bf16 -> V^T (BH, 128, Lpad) e4m3: block = 64 keys of one head; thread -> (key = tid >> 2, 32 d) in, (d = tid >> 1, 32 keys) out
+__global__ __launch_bounds__(256) void v_transpose_fp8_kernel(const bf16_t* __restrict v, uint8_t* __restrict vt8, int Lk, int Lpad, float v_scale) {
+  __shared__ uint8_t tile[128][64 + 4];
+  const int bh = blockIdx.y, pos0 = blockIdx.x * 64, tid = threadIdx.x;
+  {
+    const int p = tid >> 2, dq = (tid & 3) * 32;
+    const int kv = pos0 + p;
+    if (kv < Lk) {
+      const bf16_t* src = v + ((int64_t)bh * Lk + kv) * HD + dq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint4 x = *reinterpret_cast<const uint4*>(src + i * 8);
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&x);
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float a = fminf(fmaxf(bf16_to_f32(e[j]) * v_scale, -448.f), 448.f), b = fminf(fmaxf(bf16_to_f32(e[j + 1]) * v_scale, -448.f), 448.f);
+          const int c = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+          tile[dq + i * 8 + j][p] = (uint8_t)(c & 0xff);
+          tile[dq + i * 8 + j + 1][p] = (uint8_t)((c >> 8) & 0xff);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) tile[dq + j][p] = 0;
+    }
+  }
+  __syncthreads();
+  const int d = tid >> 1, ph = (tid & 1) * 32;
+  uint8_t* dst = vt8 + ((int64_t)bh * HD + d) * Lpad + pos0 + ph;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    uint4 x;
+    uint8_t e[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) e[j] = tile[d][ph + i * 16 + j];
+    __builtin_memcpy(&x, e, 16);
+    *reinterpret_cast<uint4*>(dst + i * 16) = x;
+  }
+}
+int launch_v_transpose_fp8(const bf16_t* v, uint8_t* vt8, int BH, int Lk, int Lpad, float v_scale, hipStream_t stream) {
+  if (BH <= 0 || Lk <= 0) return FMI_OK;
+  if (Lpad % 64 || Lpad < Lk) return fail(FMI_ERR_INVALID, "v_transpose_fp8: Lpad must be a multiple of 64 and >= Lk");
+  hipLaunchKernelGGL(v_transpose_fp8_kernel, dim3(Lpad / 64, BH), dim3(256), 0, stream, v, vt8, Lk, Lpad, v_scale);
   FMI_LAUNCH_CHECK();
   return FMI_OK;
 }

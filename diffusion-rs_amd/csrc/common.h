@@ -273,7 +273,10 @@ struct AttnOut {
 constexpr int ATT_NO_EXP2 = 1 << 30;
 int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, const AttnOut& out, int B, int H, int Lq, int Lk,
                         int Lkpad, float scale, int rescale_thr_x16, hipStream_t stream, int qk_fp8 = 0, float* lse = nullptr, int nsplit = 0,
-                        int score_exp2 = ATT_NO_EXP2, int kind = -1);
+                        int score_exp2 = ATT_NO_EXP2, int kind = -1, float v_inv = 1.f);
+// qk_fp8 == 2 (round 5): vt is e4m3 as well — (B, H, 128, Lkpad) BYTES, keys in plain order, value * v_scale, zero beyond Lk — and P is rounded to e4m3:
+// both products on the fp8 MFMA (attention_w16l_kernel<.., true, true>); v_inv = 1 / v_scale.  Only the lock-step stream has this form: the call
+// needs a power-of-two score factor and more than one KV tile, anything else is an error (there is no kernel to fall back to).
 // kind: 0..5 = this kernel (fmi_set_attention_kernel's numbering: a model handle's own choice, fmi_flux_set_attention_kernel), -1 = the process-wide switches
 // score_exp2 (fp8 QK^T only): the caller KNOWS that scale * log2(e) == 2^score_exp2 exactly and says so as an integer (the model's fp8
 // mode constructs its q scale that way) -> the one-wave stream, which carries the factor in the MFMA's E8M0 block scale.  ATT_NO_EXP2 =
@@ -294,6 +297,8 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t*
 int launch_v_transpose(const bf16_t* v, int ldv, int64_t v_bstride, bf16_t* vt, int B, int H, int rows,
                        int row_off, int Lpad, hipStream_t stream);
 int launch_vt_zero_pad(bf16_t* vt, int BH, int L, int Lpad, hipStream_t stream);
+// V (BH, Lk, 128) bf16 -> V^T (BH, 128, Lpad) e4m3 bytes = e4m3(clamp(v * v_scale, +-448)), plain key order, zero from Lk on (the qk_fp8 == 2 operand)
+int launch_v_transpose_fp8(const bf16_t* v, uint8_t* vt8, int BH, int Lk, int Lpad, float v_scale, hipStream_t stream);
 // sequence-parallel exchange buffers (seq_parallel.hip): q|k|vt of the local tokens <-> all tokens of H/N heads
 size_t sp_qkv_bytes_per_peer(int Hr, int Ll);
 size_t sp_o_bytes_per_peer(int Hr, int Ll);

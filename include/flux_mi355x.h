@@ -38,6 +38,7 @@ extern "C" {
  * 5 (round 5): + the caller-owned-workspace forms fmi_sdpa_bf16_ws / fmi_sdpa_fp8qk_ws / fmi_linear_fp8_ws / fmi_linear_i8_ws and their size queries;
  *   fmi_sdpa_* / fmi_linear_fp8 / fmi_linear_i8 no longer synchronise the stream or call hipMalloc; + fmi_quantize_rows_i8_asym, fmi_rowsum_i8,
  *   fmi_gemm_i8_asym (the int8 mode's post-GELU operand form); fmi_flux_set_quant_dense_cache accepts -1 (default: by memory) and 3.
+ *   + fmi_sdpa_fp8 / fmi_sdpa_fp8_ws (e4m3 P and V as well); fmi_flux_set_fp8_attention accepts 3.
  * Additions only: a host bound against version 3 keeps working. */
 #define FMI_ABI_VERSION 5
 
@@ -575,6 +576,16 @@ int fmi_sdpa_fp8qk(const void* q, const void* k, const void* v, void* o, int B, 
 #define FMI_SDPA_NO_EXP2 (1 << 30)
 int fmi_sdpa_fp8qk_ws(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int d, float scale,
                       int score_exp2, int out_token_major, void* workspace, size_t workspace_bytes, void* stream);
+/* Round 5: every operand of both products as OCP e4m3 — q, k bytes as fmi_sdpa_fp8qk; v is handed over as bf16 (B,H,Lk,128) and enters the
+ * second product as e4m3(clamp(v * v_scale, +-448)); the probabilities exp2(s - m) are rounded to e4m3 as they are (the deferred rescale keeps them
+ * <= 64), the row sums are taken over the rounded values, and 1 / v_scale leaves with the final normalisation.  Both products run on the
+ * K = 128 / K = 64 fp8 MFMA at twice the bf16 rate (attention_w16l_kernel<.., true, true>).  Needs score_exp2 (or a `scale` that is a power of
+ * two as above) and Lk > 64 — FMI_ERR_UNSUPPORTED otherwise: no other kernel reads this V^T.  The 8-bit modes' attention when
+ * fmi_flux_set_fp8_attention(m, 3).  Workspace: fmi_sdpa_workspace_bytes (half of it is used). */
+int fmi_sdpa_fp8(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int d, float scale, int score_exp2,
+                 float v_scale, int out_token_major, void* stream);
+int fmi_sdpa_fp8_ws(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int d, float scale, int score_exp2,
+                    float v_scale, int out_token_major, void* workspace, size_t workspace_bytes, void* stream);
 /* LayerNorm(eps, no affine) then x*(1+scale)+shift: x (rows,D) f32 -> out bf16;
  * scale/shift f32 (D) (layer_norm helper model.rs:33-38 + ModulationOut::scale_shift :218-221).
  * scale/shift may be NULL (plain LN). */

@@ -368,3 +368,55 @@ def test_sdpa_fp8qk_equals_bf16_sdpa_on_the_same_codes(env, B, H, L, pow2):
         r35 = float((o83.float() - o8.float()).norm() / o8.float().norm())
         print(f"   lock-step fp8 stream vs attention_w16 QK8: {nbad} of {o8.numel()} elements differ, rel-L2 {r35:.2e}")
         assert nbad <= o8.numel() // 1000 and r35 <= 1e-4
+
+
+@pytest.mark.parametrize("B,H,L", [(1, 1, 128), (1, 2, 200), (2, 3, 333), (1, 2, 1024), (1, 24, 4608), (2, 24, 4112)])
+def test_sdpa_fp8_all_e4m3_operands(env, B, H, L):
+    """Round 5: P and V as e4m3 too (fmi_sdpa_fp8 -> attention_w16l_kernel<.., true, true>, both products on the fp8 MFMA).  Reference: f32
+    softmax on the SAME q / k codes and the same e4m3 V (torch), once with exact probabilities (what the rounding of P costs: it is the only
+    difference) and once with the recipe's statement — exp(s - max) rounded to e4m3, row sums over the rounded values (oracle/flux_oracle.cpp
+    sdpa_pv8).  The kernel rounds exp2(s - m) for a RUNNING m (deferred rescale), so the recipe is matched statistically, not bit for bit: both
+    references within the P-rounding noise.  Shapes: 2 tiles, ragged last tiles (8 / 13 / 16 keys), the C2 and C5 attention shapes."""
+    torch, L_, lib = env["torch"], env["L"], env["lib"]
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + L + 7)
+    q = torch.randn(B, H, L, 128, device="cuda", generator=g)
+    k = torch.randn(B, H, L, 128, device="cuda", generator=g)
+    v = (torch.randn(B, H, L, 128, device="cuda", generator=g) * 1.7 + 0.3).to(torch.bfloat16)
+    KS = 448.0 / (128 ** 0.5 * 1.5)
+    c0 = np.float32(1.0 / 128 ** 0.5) * np.float32(1.4426950408889634)
+    n = int(np.floor(np.log2(np.float32(KS * KS) / c0)))
+    QS = float(c0 * np.float32(2.0 ** n) / np.float32(KS))  # softmax_scale * log2(e) / (QS * KS) == 2^-n
+    q8 = (q * QS).clamp(-448, 448).to(torch.float8_e4m3fn)
+    k8 = (k * KS).clamp(-448, 448).to(torch.float8_e4m3fn)
+    VS = 16.0
+    v8 = (v.float() * VS).clamp(-448, 448).to(torch.float8_e4m3fn).float() / VS
+    scale = (1.0 / 128 ** 0.5) / (QS * KS)
+    o = torch.empty(B, L, H * 128, device="cuda", dtype=torch.bfloat16)
+    L_.check(lib.fmi_sdpa_fp8(_p(q8), _p(k8), _p(v), _p(o), B, H, L, L, 128, scale, -n, VS, 1, None))
+    torch.cuda.synchronize()
+    s = torch.einsum("bhqd,bhkd->bhqk", q8.float(), k8.float()) * scale
+    p = torch.exp(s - s.amax(-1, keepdim=True))
+    exact = (torch.einsum("bhqk,bhkd->bhqd", p, v8) / p.sum(-1, keepdim=True)).permute(0, 2, 1, 3).reshape(B, L, H * 128)
+    p8 = p.to(torch.float8_e4m3fn).float()
+    recipe = (torch.einsum("bhqk,bhkd->bhqd", p8, v8) / p8.sum(-1, keepdim=True)).permute(0, 2, 1, 3).reshape(B, L, H * 128)
+    del s, p, p8
+    got = o.float()
+    assert torch.isfinite(got).all()
+    r_exact = float((got - exact).norm() / exact.norm())
+    r_recipe = float((got - recipe).norm() / recipe.norm())
+    noise = float((recipe - exact).norm() / exact.norm())
+    print(f"sdpa all-e4m3 B={B} H={H} L={L}: vs exact softmax on the same codes {r_exact:.2e}, vs the recipe {r_recipe:.2e} (recipe vs exact {noise:.2e})")
+    if r_exact > 3e-2:  # a layout bug, not rounding: say where
+        e = (got - exact).reshape(B, L, H, 128)
+        ref = exact.reshape(B, L, H, 128)
+        for qb in range(min(8, (L + 15) // 16)):
+            blk = slice(16 * qb, 16 * qb + 16)
+            print(f"   queries {16 * qb:4d}..: " + " ".join(f"{float(e[0, blk, 0, 32 * d:32 * d + 32].norm() / ref[0, blk, 0, 32 * d:32 * d + 32].norm()):.2e}" for d in range(4)))
+    assert r_exact <= 2.5 * max(noise, 2e-3) and r_recipe <= 2.5 * max(noise, 2e-3)
+    o2 = torch.empty_like(o)
+    L_.check(lib.fmi_sdpa_fp8(_p(q8), _p(k8), _p(v), _p(o2), B, H, L, L, 128, scale, -n, VS, 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(o, o2)  # run-to-run determinism (hand-placed waitcnts)
+    # no kernel to fall back to: a single KV tile or a non-power-of-two factor is an error, not a slower path
+    assert lib.fmi_sdpa_fp8(_p(q8), _p(k8), _p(v), _p(o2), B, H, L, 64, 128, scale, -n, VS, 1, None) < 0
+    assert lib.fmi_sdpa_fp8(_p(q8), _p(k8), _p(v), _p(o2), B, H, L, L, 128, scale * 1.1, L_.SDPA_NO_EXP2, VS, 1, None) < 0
