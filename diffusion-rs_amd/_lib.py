@@ -9,6 +9,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FMI_LIB = another build of the same library (A/B of two builds on one box: tools/ab_toggle.py, DESIGN's "alternating processes"); default: in-tree
 LIB_PATH = os.environ.get("FMI_LIB") or os.path.join(_HERE, "libflux_mi355x.so")
+# the TEST build of the same sources (make alt: -DFMI_ALT_KERNELS=1, the superseded kernels compiled in as well): loaded next to the product library by the
+# bit-identity cross-checks of tests/ (load_alt / use_alt), never by the product
+ALT_LIB_PATH = os.path.join(_HERE, "libflux_mi355x_alt.so")
 
 
 class FmiError(RuntimeError):
@@ -68,12 +71,14 @@ F32, F16, BF16, U8, I8 = 0, 1, 2, 3, 4
 MODEL_AUTO, MODEL_BF16, MODEL_F16, MODEL_F32 = 0, 1, 2, 3
 
 _lib = None
+_product = None
+_alt = None
 
 
 def load():
     """Load the HIP library.  torch (if used in this process) must be imported first so that a
     single libamdhip64.so.7 serves both (same SONAME; see DESIGN.md §process model)."""
-    global _lib
+    global _lib, _product
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
@@ -82,7 +87,39 @@ def load():
         import torch  # noqa: F401  (ensures torch's HIP runtime is the one already mapped)
     except Exception:
         pass
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    _lib = _product = _declare(C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL))
+    return _lib
+
+
+def load_alt():
+    """The test build (libflux_mi355x_alt.so), as a second library in this process; FmiError if it was not built (`make alt`)."""
+    global _alt
+    if _alt is None:
+        load()
+        if not os.path.exists(ALT_LIB_PATH):
+            raise FmiError(f"{ALT_LIB_PATH} not found — build it with `make alt`")
+        _alt = _declare(C.CDLL(ALT_LIB_PATH, mode=C.RTLD_LOCAL))
+        if not _alt.fmi_has_alt_kernels():
+            raise FmiError(f"{ALT_LIB_PATH} was not compiled with -DFMI_ALT_KERNELS=1")
+    return _alt
+
+
+class use_alt:
+    """`with use_alt() as lib:` — inside the block load() returns the test build, so handles created there (FluxModel, ...) and check() bind to it."""
+
+    def __enter__(self):
+        global _lib
+        alt = load_alt()
+        self.prev, _lib = _lib, alt
+        return alt
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
+
+
+def _declare(lib):
     lib.fmi_last_error.restype = C.c_char_p
     lib.fmi_device_info.restype = C.c_char_p
     lib.fmi_build_id.restype = C.c_char_p
@@ -188,7 +225,6 @@ def load():
     lib.fmi_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     lib.fmi_event_destroy.argtypes = [C.c_void_p]
     lib.fmi_stream_synchronize.argtypes = [C.c_void_p]
-    _lib = lib
     return lib
 
 
@@ -217,7 +253,7 @@ def check(rc):
 
 # every symbol include/flux_mi355x.h declares (tests/test_host_logic.py::test_library_exports_every_header_symbol checks they are all exported)
 EXPORTED = [
-    "fmi_last_error", "fmi_abi_version", "fmi_init", "fmi_device_info", "fmi_build_id", "fmi_flux_default_config", "fmi_flux_create", "fmi_flux_destroy",
+    "fmi_last_error", "fmi_abi_version", "fmi_init", "fmi_device_info", "fmi_build_id", "fmi_has_alt_kernels", "fmi_flux_default_config", "fmi_flux_create", "fmi_flux_destroy",
     "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_set_linear_int8", "fmi_flux_set_quant_dense_cache", "fmi_flux_set_sequence_parallel", "fmi_flux_set_split_k", "fmi_set_bnb4_onewave_min_rows", "fmi_flux_set_attention_rescale_threshold", "fmi_flux_set_attention_kernel", "fmi_flux_state_buffer_count", "fmi_flux_state_export", "fmi_flux_state_adopt", "fmi_flux_state_buffer", "fmi_flux_set_modulation_gemm", "fmi_flux_quantize_fp8", "fmi_flux_quantize_int8", "fmi_flux_set_fp8_attention", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
     "fmi_flux_forward", "fmi_flux_denoise", "fmi_flux_set_profiling", "fmi_flux_set_fused_qkv_relayout", "fmi_flux_phase_count", "fmi_flux_phase_name", "fmi_flux_phase_ms",
     "fmi_vae_default_config", "fmi_vae_create", "fmi_vae_destroy", "fmi_vae_set_tensor", "fmi_vae_missing_count", "fmi_vae_missing_name",

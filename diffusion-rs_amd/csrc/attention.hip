@@ -43,6 +43,7 @@ constexpr int ATT_PF = 4;  // operand reads in flight in the ping-pong kernel's 
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+#if FMI_ALT_KERNELS  // the single-barrier 8-wave kernel (round 1): superseded by the ping-pong form below, kept in the test build as its bit-identical twin
 template <int THR_X16>  // rescale threshold in 1/16 units of log2 (0 = always rescale)
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t* __restrict Q, const bf16_t* __restrict K,
                                                                     const bf16_t* __restrict Vt, AttnOut out, int H, int Lq, int Lk,
@@ -234,6 +235,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(const bf16_t*
       }
   }
 }
+
+#endif  // FMI_ALT_KERNELS
 
 // ---------------------------------------------------------------------------------------------
 // Ping-pong variant of the kernel above (same math, same accumulation order: bit-identical output).
@@ -546,12 +549,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_pp_kernel(const bf16
 }
 
 }  // namespace fmi
-#include "attention_w4.h"
+#include "attention_w4.h"  // (product: the key-split launches of the sequence-parallel split-K mode)
+#if FMI_ALT_KERNELS
 #include "attention_w16.h"
 #include "attention_w32.h"
+#endif
 #include "attention_w16l.h"
 namespace fmi {
 
+bool alt_kernels_built() { return FMI_ALT_KERNELS != 0; }
 static std::atomic<bool> g_att_pingpong{true};  // process-wide test hooks, like the GEMM switches (gemm_bf16.hip)
 void set_attention_pingpong(bool on) { g_att_pingpong = on; }
 // bf16 operands: the one-wave-per-SIMD kernel (attention_w4.h); FMI_ATT_W4=0 / set_attention_w4(false) -> the 8-wave ping-pong kernel
@@ -595,6 +601,11 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
              g_att_pingpong = kind >= 0 ? kind >= 1 : (bool)fmi::g_att_pingpong;
   if (Lq <= 0 || Lk <= 0) return fail(FMI_ERR_INVALID, "attention: empty sequence");
   if (Lkpad % ATT_KV != 0 || Lkpad < Lk) return fail(FMI_ERR_INVALID, "attention: Lkpad must be a multiple of 64 and >= Lk");
+#if !FMI_ALT_KERNELS
+  // the product build carries the lock-step kernel (5) and the 8-wave ping-pong kernel (1: single-tile problems, fp8 factors that are no power of two)
+  if (!g_att_pingpong || g_att_w32 || (g_att_w16 != g_att_w16l) || (g_att_w4 != g_att_w16l))
+    return fail(FMI_ERR_UNSUPPORTED, "attention: this build carries kernels 5 and 1 only (the others live in the test build, libflux_mi355x_alt.so: make alt)");
+#endif
   dim3 grid(cdiv(Lq, ATT_QBLK) * B * H);
   const float sl = scale * 1.4426950408889634f;
   if (lse) {  // key-split launch (k_hstride = number of key ranges): only the one-wave kernel writes the log-sum-exp
@@ -649,6 +660,7 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
       FMI_LAUNCH_CHECK();
       return FMI_OK;
     }
+#if FMI_ALT_KERNELS
     if (g_att_w16 && Lk > ATT_KV && pow2) {
       const float sl2 = ldexpf(1.0f, n2);
       if (rescale_thr_x16 == 0)
@@ -658,6 +670,7 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
       FMI_LAUNCH_CHECK();
       return FMI_OK;
     }
+#endif
     if (rescale_thr_x16 == 0)
       hipLaunchKernelGGL((attention_pp_kernel<0, true>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
     else
@@ -667,6 +680,7 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
       FMI_LAUNCH_LDS((attention_w16l_kernel<0>), 8 * 16384, grid, dim3(AW16L_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
     else
       FMI_LAUNCH_LDS((attention_w16l_kernel<96>), 8 * 16384, grid, dim3(AW16L_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+#if FMI_ALT_KERNELS
   } else if (g_att_w32 && Lk > ATT_KV) {
     if (rescale_thr_x16 == 0)
       FMI_LAUNCH_LDS((attention_w32_kernel<0>), 8 * 16384, grid, dim3(AW32_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
@@ -682,15 +696,19 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
       FMI_LAUNCH_LDS((attention_w4_kernel<0>), 8 * 16384, grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, 0, nullptr, 1);
     else
       FMI_LAUNCH_LDS((attention_w4_kernel<96>), 8 * 16384, grid, dim3(AW4_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl, 0, nullptr, 1);
+#endif
   } else if (g_att_pingpong) {
     if (rescale_thr_x16 == 0)
       hipLaunchKernelGGL((attention_pp_kernel<0, false>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
     else
       hipLaunchKernelGGL((attention_pp_kernel<96, false>), grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
-  } else if (rescale_thr_x16 == 0)
+  }
+#if FMI_ALT_KERNELS
+  else if (rescale_thr_x16 == 0)
     hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
   else
     hipLaunchKernelGGL(attention_kernel<96>, grid, dim3(ATT_THREADS), 0, stream, q, k, vt, out, H, Lq, Lk, Lkpad, sl);
+#endif
   FMI_LAUNCH_CHECK();
   return FMI_OK;
 }

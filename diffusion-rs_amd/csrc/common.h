@@ -1,5 +1,12 @@
 // common.h — shared device/host helpers for libflux_mi355x (gfx950 / CDNA4 only).
 #pragma once
+// FMI_ALT_KERNELS = 1 (the TEST build, libflux_mi355x_alt.so: `make alt`): the superseded kernels are compiled in as well — the 8-wave single-barrier
+// attention, attention_w4 outside the key-split launches, attention_w16 / attention_w32 (bf16 and fp8-QK), the dense 4-wave GEMM and the double-buffered
+// 256 x 256 GEMM — and fmi_set_attention_kernel / FMI_GEMM_W4 select them: the bit-identity cross-checks of tests/ run against that build.  The product
+// library (0, the default) carries what the product runs: kernels 5 and 1 of fmi_set_attention_kernel, gemm_pp_kernel + the 128-wide / conv / 4-bit kernels.
+#ifndef FMI_ALT_KERNELS
+#define FMI_ALT_KERNELS 0
+#endif
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -283,6 +290,7 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
 // unknown: the launcher recognises an exact power of two itself, anything else runs on the 8-wave kernel and is COUNTED
 // (attention_fp8_fallbacks(), visible in fmi_device_info) — a silent slide to the slower, numerically different kernel was ADVICE r3's finding.
 unsigned long long attention_fp8_fallbacks();
+bool alt_kernels_built();  // attention.hip: was THIS library linked from the test build's objects (the flag differs per object: only attention.o / gemm_bf16.o)
 void set_attention_pingpong(bool on);  // 8-wave kernels: ping-pong (default) or the single-barrier one
 void set_attention_w4(bool on);        // bf16 operands: one-wave-per-SIMD kernel (default) or the 8-wave ones
 void set_attention_w16(bool on);       // bf16 operands: the 16x16x32-MFMA one-wave kernel in front of the others (default on)

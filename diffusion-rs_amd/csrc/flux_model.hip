@@ -1475,6 +1475,8 @@ extern "C" int fmi_flux_set_fused_qkv_relayout(fmi_flux* m, int enable) {
 extern "C" int fmi_flux_set_attention_kernel(fmi_flux* m, int kind) {
   if (!m) return fail(FMI_ERR_INVALID, "null handle");
   if (kind < -1 || kind > 5) return fail(FMI_ERR_INVALID, "flux_set_attention_kernel: kind must be -1 .. 5");
+  if (!alt_kernels_built() && kind != -1 && kind != 5 && kind != 1)
+    return fail(FMI_ERR_UNSUPPORTED, "flux_set_attention_kernel: this build carries kernels 5 and 1; 0, 2, 3, 4 live in the test build (libflux_mi355x_alt.so: make alt)");
   m->attn_kind = kind;
   return FMI_OK;
 }

@@ -1178,6 +1178,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmProblem& P, f32x16 (&acc)[
   }
 }
 
+#if FMI_ALT_KERNELS  // the dense 4-wave kernel (FMI_GEMM_W4=1: off by default since round 2) lives in the test build; its epilogue tail above serves gemm_w4q_kernel
 // The same tail for 16 x 16 accumulators (gemm_w4_kernel): acc[tm][tn], the half r = column tiles 4 r .. 4 r + 3.
 template <int ACT>
 __device__ __forceinline__ void w4_epilogue16(const GemmProblem& P, f32x4 (&acc)[8][8], char* smem, int m0, int n0, int wave, int wm, int wn, int lane) {
@@ -1398,6 +1399,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const GemmBatch 
   w4_epilogue16<ACT>(P, acc, smem, m0, n0, wave, wm, wn, lane);
 }
 
+#endif  // FMI_ALT_KERNELS
+
 }  // namespace fmi
 #include "gemm_w4q.h"
 namespace fmi {
@@ -1545,12 +1548,19 @@ int launch_gemm(const GemmProblem* probs, int nprob, hipStream_t stream) {
     else hipLaunchKernelGGL((gemm_w4q_kernel<3>), g4, b4, 0, stream, b);
   } else if (quant)
     FMI_GEMM_LAUNCH(1);
+#if FMI_ALT_KERNELS
   else if (bn == 256 && g_w4 && w4_pays)
     FMI_ACT_LAUNCH(gemm_w4_kernel, false, W4_THREADS);
-  else if (bn == 256 && g_pingpong)
+  else if (bn == 256 && !g_pingpong)
+    FMI_GEMM_LAUNCH(0);  // (the double-buffered 256 x 256 kernel: gemm_pp_kernel's bit-identical predecessor)
+#else
+  else if (bn == 256 && ((g_w4 && w4_pays) || !g_pingpong))
+    return fail(FMI_ERR_UNSUPPORTED, "launch_gemm: the dense 4-wave / double-buffered 256-wide kernels live in the test build (libflux_mi355x_alt.so: make alt)");
+#endif
+  else if (bn == 256)
     FMI_ACT_LAUNCH(gemm_pp_kernel, 0, GEMM_THREADS);
   else
-    FMI_GEMM_LAUNCH(0);
+    hipLaunchKernelGGL((gemm_bf16_kernel<0, 1>), grid, blk, 0, stream, b);  // N <= 128: the 256 x 128 double-buffered kernel
 #undef FMI_GEMM_LAUNCH
 #undef FMI_ACT_LAUNCH
   FMI_LAUNCH_CHECK();

@@ -78,6 +78,10 @@ const char* fmi_device_info(void);
  * (sorted by path, concatenated) at build time.  __graft_entry__.build() recomputes it from the tree and rebuilds on a mismatch,
  * so a stale prebuilt .so cannot stand in for the sources next to it. */
 const char* fmi_build_id(void);
+/* 1 = this is the TEST build (libflux_mi355x_alt.so, `make alt`: compiled with -DFMI_ALT_KERNELS=1), which carries the superseded kernels as well —
+ * attention kernels 0, 2, 3, 4 of fmi_set_attention_kernel, the dense 4-wave GEMM (FMI_GEMM_W4=1) — for the bit-identity cross-checks of tests/.
+ * The product library returns 0, carries kernels 5 and 1, and answers a request for another with FMI_ERR_UNSUPPORTED. */
+int fmi_has_alt_kernels(void);
 
 /* ------------------------------------------------------------------------------------
  * FLUX DiT — replaces diffusion_rs_core::models::flux::Flux (model.rs:709-838)

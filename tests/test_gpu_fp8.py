@@ -352,18 +352,20 @@ def test_sdpa_fp8qk_equals_bf16_sdpa_on_the_same_codes(env, B, H, L, pow2):
     L_.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o8b), B, H, L, L, 128, scale, 1, None))
     torch.cuda.synchronize()
     assert torch.equal(o8, o8b)
-    if pow2 and L > 64:  # round 4's lock-step fp8 stream (the default, kernel 5) against round 3's (kernel 3): same arithmetic, same bits
+    alt = None
+    if pow2 and L > 64:
         try:
-            L_.check(lib.fmi_set_attention_kernel(3))
+            alt = L_.load_alt()  # kernel 3 lives in the test build (libflux_mi355x_alt.so)
+        except L_.FmiError:
+            alt = None
+    if alt is not None:  # round 4's lock-step fp8 stream (the default, kernel 5) against round 3's (kernel 3): same arithmetic, same bits
+        try:
+            L_.check(alt.fmi_set_attention_kernel(3))
             o83 = torch.empty_like(o8)
-            L_.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o83), B, H, L, L, 128, scale, 1, None))
+            L_.check(alt.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o83), B, H, L, L, 128, scale, 1, None))
             torch.cuda.synchronize()
         finally:
-            L_.check(lib.fmi_set_attention_kernel(5))
-        # same arithmetic; the deferred-rescale decision is taken per 64 queries in the lock-step stream and per 32 in attention_w16, so
-        # where a tile pushes one half of a wave over the threshold and not the other, a row's accumulator is rescaled at different
-        # tiles: last-bit differences in a few rows (seen: 513 of 14e6 elements at L = 4608 with N(0,1) scores), nothing more.
-        # Bit-identity with every tile rescaling: tests/test_gpu_fuzz.py::test_lockstep_attention_is_bit_identical_...
+            L_.check(alt.fmi_set_attention_kernel(5))
         nbad = int((o83.view(torch.int16) != o8.view(torch.int16)).sum())
         r35 = float((o83.float() - o8.float()).norm() / o8.float().norm())
         print(f"   lock-step fp8 stream vs attention_w16 QK8: {nbad} of {o8.numel()} elements differ, rel-L2 {r35:.2e}")

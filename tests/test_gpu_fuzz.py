@@ -20,6 +20,13 @@ def env():
     return torch, L, L.load()
 
 
+def _alt_or_skip(L):
+    try:
+        return L.load_alt()
+    except L.FmiError as e:
+        pytest.skip(f"the test build of the library is not there: {e}")
+
+
 def test_linear_bf16_random_shapes(env):
     torch, L, lib = env
     rng = np.random.default_rng(2024)
@@ -117,7 +124,8 @@ def test_attention_kernels_agree_on_random_shapes(env):
     schedules, one arithmetic — a hazard in either hand-scheduled stream shows up as a difference), equal to the first family to
     rounding (rel-L2 <= 6e-3, the oracle tolerance of a single attention), and every kernel reproduces itself from run to run.
     Shapes: ragged, exact multiples of 64 / 256, long KV (many loop iterations), batch > 1."""
-    torch, L, lib = env
+    torch, L, product = env
+    lib = _alt_or_skip(L)  # the superseded kernels live in the TEST build (libflux_mi355x_alt.so, -DFMI_ALT_KERNELS=1), loaded next to the product library
     rng = np.random.default_rng(2024)
     g = torch.Generator(device="cuda").manual_seed(11)
     shapes = [(1, 2, 128, 128), (1, 1, 192, 192), (2, 2, 1000, 1000), (1, 3, 2048, 2048), (1, 2, 300, 4608), (1, 1, 4608, 4608), (1, 2, 65, 129)]
@@ -152,6 +160,11 @@ def test_attention_kernels_agree_on_random_shapes(env):
             # last bit of some rows, nothing more: rel-L2 well under the family distance), reproducible run to run, and as close to the
             # round-2 family as w16 is.  Bit-identity with w16 when every tile rescales: test_lockstep_attention_... below.
             assert int((bits[8] != bits[9]).sum()) == 0, (B, H, Lq, Lk, "w16l rerun")
+            # ... and the PRODUCT library's default kernel is that very stream: same bits from the other binary
+            op = torch.full((B, Lq, H * 128), float("nan"), device="cuda", dtype=torch.bfloat16)
+            L.check(product.fmi_sdpa_bf16(_p(q), _p(k), _p(v), _p(op), B, H, Lq, Lk, 128, 1.0 / 128 ** 0.5, 1, None))
+            torch.cuda.synchronize()
+            assert int((op.view(torch.int16).cpu().numpy() != bits[8]).sum()) == 0, (B, H, Lq, Lk, "product w16l vs test-build w16l")
             e16 = float((outs[8].float() - outs[0].float()).norm() / outs[0].float().norm())
             worst_l = max(worst_l, e16)
             assert e16 <= 2e-3, (B, H, Lq, Lk, e16)
@@ -167,7 +180,15 @@ def test_lockstep_attention_is_bit_identical_to_w16_when_every_tile_rescales(env
     every key tile that raises a maximum rescales, in both kernels) a model forward through either must give the same bits.  A hazard in
     the new hand-scheduled stream (a stale fragment, a pack overtaking its exponential, a rescale applied to the wrong tile) shows up
     here as a difference.  Joint attention with ragged token counts, 5 .. 70 KV tiles."""
-    torch, L, lib = env
+    torch, L, product = env
+    _alt_or_skip(L)
+    with L.use_alt() as lib:  # the model handle below is created on the test build (kernels 3 and 4 are not in the product library)
+        _lockstep_body(torch, L, lib)
+    # the product library refuses what it does not carry, loudly
+    assert product.fmi_set_attention_kernel(3) < 0 and product.fmi_set_attention_kernel(5) == 0 and product.fmi_has_alt_kernels() == 0
+
+
+def _lockstep_body(torch, L, lib):
     import diffusion_rs_amd as d
     from tests.util import SMALL_FLUX, dev, flux_inputs
     cfg = dict(SMALL_FLUX, num_attention_heads=4)

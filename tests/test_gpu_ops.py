@@ -410,9 +410,15 @@ np.savez(sys.argv[1], **out)
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
+    from diffusion_rs_amd import _lib as L
+    if not os.path.exists(L.ALT_LIB_PATH):
+        pytest.skip("the test build of the library (libflux_mi355x_alt.so, make alt) is not there: the 4-wave kernel lives in it")
     for v in ("0", "1"):
         path = str(tmp_path / f"w4_{v}.npz")
+        # "0": the PRODUCT library (8-wave ping-pong kernel); "1": the test build with the 4-wave kernel switched on — two binaries, the same bits
         env = dict(os.environ, FMI_GEMM_W4=v)
+        if v == "1":
+            env["FMI_LIB"] = L.ALT_LIB_PATH
         subprocess.run([sys.executable, "-c", script, path], check=True, cwd=root, env=env, timeout=600)
         res[v] = np.load(path)
     for k in res["0"].files:

@@ -66,7 +66,7 @@ def test_attention_and_gemm_reproduce_their_idle_results_while_another_process_u
     torch, L, lib = env["torch"], env["L"], env["lib"]
     g = torch.Generator(device="cuda").manual_seed(5)
     cases = []
-    for kind in (5, 3, 4, 2, 1, 0):  # every attention kernel: round 4's lock-step stream, the two generated round-3 streams, the round-2 one-wave kernel, the 8-wave ones
+    for kind in (5, 1):  # the product library's attention kernels: the lock-step stream and the 8-wave ping-pong kernel (the superseded ones live in the test build)
         for (H, Lq) in ((24, 4608), (96, 1024), (512, 128), (24, 4550)):
             q, k, v = (torch.randn((1, H, Lq, 128), generator=g, device="cuda").to(torch.bfloat16) for _ in range(3))
 
@@ -146,7 +146,6 @@ def test_attention_and_gemm_reproduce_their_idle_results_while_another_process_u
         L.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o), 1, H, Lq, Lq, 128, sc17, 1, None))
         return o
     cases.append(("sdpa fp8 QK one-wave lock-step (attention_w16l QK8)", lambda: run_fp8_attn_onewave(5)))
-    cases.append(("sdpa fp8 QK one-wave (attention_w16 QK8)", lambda: run_fp8_attn_onewave(3)))
     try:
         idle = []
         for name, run in cases:

@@ -30,6 +30,30 @@ def test_library_exports_every_header_symbol():
     assert lib.fmi_abi_version() == 5
 
 
+def test_product_and_test_build_of_the_library():
+    """The shipped library carries what the product runs; the superseded kernels sit behind ONE build flag (-DFMI_ALT_KERNELS=1) that only the test
+    build sets (libflux_mi355x_alt.so, `make alt`).  Both export the whole header, carry the same source id, and say which they
+    are; the product library answers a request for a kernel it does not carry with an error, not with another kernel (no GPU needed: the
+    switch is checked before any launch)."""
+    lib = L.load()
+    assert lib.fmi_has_alt_kernels() == 0
+    assert lib.fmi_set_attention_kernel(3) == L.ERR_UNSUPPORTED and b"test build" in lib.fmi_last_error()
+    assert lib.fmi_set_attention_kernel(5) == 0 and lib.fmi_set_attention_kernel(1) == 0 and lib.fmi_set_attention_kernel(5) == 0
+    alt = L.load_alt()
+    assert alt.fmi_has_alt_kernels() == 1 and L.load() is lib  # (loading the test build does not replace the product library)
+    assert not [s for s in L.EXPORTED if not hasattr(alt, s)]
+    assert alt.fmi_build_id() == lib.fmi_build_id() == L.tree_build_id(ROOT).encode()
+    for kind in range(6):
+        assert alt.fmi_set_attention_kernel(kind) == 0
+    assert alt.fmi_set_attention_kernel(5) == 0
+    with L.use_alt() as a:
+        assert L.load() is a
+    assert L.load() is lib
+    so, so_alt = os.path.getsize(L.LIB_PATH), os.path.getsize(L.ALT_LIB_PATH)
+    print(f"product library {so / 2**20:.1f} MiB, test build {so_alt / 2**20:.1f} MiB")
+    assert so < so_alt
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

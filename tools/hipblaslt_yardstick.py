@@ -11,7 +11,9 @@ from diffusion_rs_amd import _lib as L  # noqa: E402
 
 lib = L.load()
 shapes = [(4608, 21504, 3072, "single linear1"), (4608, 3072, 15360, "single linear2"), (4096, 9216, 3072, "double qkv img"),
-          (4096, 12288, 3072, "double mlp1 img"), (4096, 3072, 12288, "double mlp2 img"), (4096, 4096, 15360, "256 tiles"), (8192, 8192, 8192, "8k cube")]
+          (4096, 12288, 3072, "double mlp1 img"), (4096, 3072, 12288, "double mlp2 img"), (4096, 4096, 15360, "256 tiles"), (8192, 8192, 8192, "8k cube"),
+          # round 5: the launches the MODEL issues group the image and text streams — 4608 rows, 18 row tiles — not the 4096 of the image stream alone
+          (4608, 9216, 3072, "double qkv img+txt"), (4608, 12288, 3072, "double mlp1 img+txt"), (4608, 3072, 12288, "double mlp2 img+txt")]
 p = lambda t: C.c_void_p(t.data_ptr())
 
 
