@@ -290,6 +290,8 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
 // unknown: the launcher recognises an exact power of two itself, anything else runs on the 8-wave kernel and is COUNTED
 // (attention_fp8_fallbacks(), visible in fmi_device_info) — a silent slide to the slower, numerically different kernel was ADVICE r3's finding.
 unsigned long long attention_fp8_fallbacks();
+// the op-level entries' scratch: a grow-only block per (device, stream) the library holds (capi.hip: ScratchCache) — no allocation, no wait in the steady state
+int op_scratch(hipStream_t s, size_t bytes, void** out);
 bool alt_kernels_built();  // attention.hip: was THIS library linked from the test build's objects (the flag differs per object: only attention.o / gemm_bf16.o)
 void set_attention_pingpong(bool on);  // 8-wave kernels: ping-pong (default) or the single-barrier one
 void set_attention_w4(bool on);        // bf16 operands: one-wave-per-SIMD kernel (default) or the 8-wave ones

@@ -58,7 +58,21 @@ static inline int gn_pix_per_block(int HW) {
 static inline int gn_chunks(int HW) { return cdiv(HW, gn_pix_per_block(HW)); }
 static inline int gn_max_chunks(int HW) { return std::max(2048, cdiv(HW, 1024)); }  // bound of gn_chunks over every HW' <= HW
 // partial[(b*nchunks + chunk)*G + g] = {sum, sumsq} over the chunk's pixels; requires C%8==0, cpg%4==0
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict x, float2* __restrict partial, int HW, int C, int G, int ppb) {
+// T = bf16_t (activations inside a block) or float (the f32 trunk, round 5): 8 channels per thread either way
+template <typename T>
+__device__ __forceinline__ void gn_load8(const T* p, float (&v)[8]) {
+  if constexpr (sizeof(T) == 4) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+  } else {
+    const uint4 raw = *reinterpret_cast<const uint4*>(p);
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = bf16_to_f32(e[i]);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict x, float2* __restrict partial, int HW, int C, int G, int ppb) {
   __shared__ float4 part[256];  // per-thread {sum_lo, sumsq_lo, sum_hi, sumsq_hi} (channels 0-3 / 4-7 of its 8)
   const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
   const int tpp = C >> 3;  // threads per pixel
@@ -71,17 +85,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict 
   if ((int)threadIdx.x < nact) {
 #pragma unroll 4  // four 16-byte loads in flight per thread (one per iteration left the kernel latency-bound at 1.5 TB/s)
     for (int p = p0 + threadIdx.x / tpp; p < p1; p += pstep) {
-      const uint4 raw = *reinterpret_cast<const uint4*>(x + ((int64_t)b * HW + p) * C + c8 * 8);
-      const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw);
+      float e[8];
+      gn_load8(x + ((int64_t)b * HW + p) * C + c8 * 8, e);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float v = bf16_to_f32(e[i]);
+        const float v = e[i];
         s0 += v;
         q0 += v * v;
       }
 #pragma unroll
       for (int i = 4; i < 8; ++i) {
-        const float v = bf16_to_f32(e[i]);
+        const float v = e[i];
         s1 += v;
         q1 += v * v;
       }
@@ -138,9 +152,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float2* __restri
     stats[b * G + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
   }
 }
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict x, const float2* __restrict stats, const float* __restrict w,
-                                                       const float* __restrict bia, bf16_t* __restrict out, int HW, int C, int G, int silu_on,
-                                                       int64_t nvec) {
+// raw != nullptr: x itself leaves as bf16 too (the operand copy of the f32 trunk that a ResnetBlock's 1 x 1 shortcut convolution reads)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict x, const float2* __restrict stats, const float* __restrict w,
+                                                       const float* __restrict bia, bf16_t* __restrict out, bf16_t* __restrict raw_out, int HW, int C, int G,
+                                                       int silu_on, int64_t nvec) {
   const int tpp = C >> 3, cpg = C / G;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -160,33 +176,56 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict 
     const int c8 = (int)(i % tpp);
     const int64_t p = i / tpp;
     const int b = (int)(p / HW);
-    const uint4 raw = *reinterpret_cast<const uint4*>(x + i * 8);
-    const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw);
+    float e[8];
+    gn_load8(x + i * 8, e);
     const float2 st0 = stats[b * G + (c8 * 8) / cpg], st1 = stats[b * G + (c8 * 8 + 4) / cpg];
     if (!fixed) load_affine(c8);
+    if (raw_out)
+      *reinterpret_cast<uint4*>(raw_out + i * 8) = make_uint4(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7]));
     float v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float2 st = k < 4 ? st0 : st1;
-      float y = (bf16_to_f32(e[k]) - st.x) * st.y * ww[k] + bb[k];
+      float y = (e[k] - st.x) * st.y * ww[k] + bb[k];
       v[k] = silu_on ? silu(y) : y;
     }
     *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
   }
 }
 
-int launch_groupnorm_nhwc(const bf16_t* x, const float* w, const float* b, bf16_t* out, int B, int HW, int C, int G, float eps, int silu_on,
-                          float2* partial, float2* stats, hipStream_t s) {
+template <typename T>
+static int launch_groupnorm_nhwc_t(const T* x, const float* w, const float* b, bf16_t* out, bf16_t* raw_out, int B, int HW, int C, int G, float eps,
+                                   int silu_on, float2* partial, float2* stats, hipStream_t s) {
   if (C % 8 || C % G || (C / G) % 4) return fail(FMI_ERR_UNSUPPORTED, "groupnorm: needs C % 8 == 0 and (C/groups) % 4 == 0");
   if (C / 8 > 256) return fail(FMI_ERR_UNSUPPORTED, "groupnorm: C > 2048 not supported");
   const int nchunks = gn_chunks(HW);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, x, partial, HW, C, G, gn_pix_per_block(HW));
+  hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunks, B), dim3(256), 0, s, x, partial, HW, C, G, gn_pix_per_block(HW));
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, s, partial, stats, nchunks, G, (double)HW * (C / G), eps);
   const int64_t nvec = (int64_t)B * HW * (C / 8);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(nvec, 256), 256 * 16)), dim3(256), 0, s, x, stats, w, b, out, HW, C, G,
-                     silu_on, nvec);
+  hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)std::min<int64_t>(cdiv64(nvec, 256), 256 * 16)), dim3(256), 0, s, x, stats, w, b, out, raw_out, HW, C,
+                     G, silu_on, nvec);
   FMI_LAUNCH_CHECK();
   return FMI_OK;
+}
+int launch_groupnorm_nhwc(const bf16_t* x, const float* w, const float* b, bf16_t* out, int B, int HW, int C, int G, float eps, int silu_on,
+                          float2* partial, float2* stats, hipStream_t s) {
+  return launch_groupnorm_nhwc_t<bf16_t>(x, w, b, out, nullptr, B, HW, C, G, eps, silu_on, partial, stats, s);
+}
+// bf16 -> f32 widening / f32 -> bf16 rounding of an activation (the f32 trunk's operand copies and the op-level AttnBlock entry)
+__global__ void widen_bf16_kernel(const bf16_t* __restrict x, float* __restrict out, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float e[8];
+    gn_load8(x + i * 8, e);
+    *reinterpret_cast<float4*>(out + i * 8) = make_float4(e[0], e[1], e[2], e[3]);
+    *reinterpret_cast<float4*>(out + i * 8 + 4) = make_float4(e[4], e[5], e[6], e[7]);
+  }
+}
+__global__ void round_bf16_kernel(const float* __restrict x, bf16_t* __restrict out, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float e[8];
+    gn_load8(x + i * 8, e);
+    *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7]));
+  }
 }
 
 // row softmax, bf16 in place, f32 math (softmax_last_dim, nn/ops.rs:419-448)
@@ -239,6 +278,15 @@ GemmProblem conv_problem(const bf16_t* x, const bf16_t* w, const bf16_t* bias, c
   p.epi = resid ? EPI_RESID_ADD_BF16 : EPI_STORE_BF16;
   p.alpha = 1.f;
   p.cv_ks = ks, p.cv_h = in_h, p.cv_w = in_w, p.cv_cin = cin_pad, p.cv_up = up, p.cv_zero = zero;
+  return p;
+}
+// the same convolution writing the f32 trunk: trunk = conv + bias (add == false) or trunk += conv + bias (the gated-residual epilogue with a gate of ones)
+GemmProblem conv_problem_f32(const bf16_t* x, const bf16_t* w, const bf16_t* bias, float* trunk, bool add, const float* ones, int B, int in_h, int in_w,
+                             int cin_pad, int cout, int ks, int up, const bf16_t* zero) {
+  GemmProblem p = conv_problem(x, w, bias, nullptr, nullptr, B, in_h, in_w, cin_pad, cout, ks, up, zero);
+  p.out = trunk;
+  p.epi = add ? EPI_RESID_GATE_F32 : EPI_STORE_F32;
+  p.gate = ones;
   return p;
 }
 
@@ -296,7 +344,11 @@ struct fmi_vae {
   int wB = 0, wh = 0, ww = 0;
   char* ws = nullptr;
   size_t ws_bytes = 0;
-  bf16_t *bx = nullptr, *bt1 = nullptr, *bt2 = nullptr, *bsc = nullptr, *scores = nullptr;
+  // fx / fx2: the TRUNK (what ResnetBlocks, the AttnBlock and the samplers add to) in f32 since round 5 — its bf16 rounding after every block was what
+  // cost the decoder its u8 agreement (tools/vae_rounding_study.py: all activations bf16 99.54 % within 2; trunk f32, everything else bf16: 100 %);
+  // bt1 / bt2 / bsc: bf16 activations inside a block (every MFMA operand); ones: the gate of the f32 read-modify-write epilogue
+  float *fx = nullptr, *fx2 = nullptr, *ones = nullptr;
+  bf16_t *bt1 = nullptr, *bt2 = nullptr, *bsc = nullptr, *scores = nullptr;
   float2 *partial = nullptr, *stats = nullptr;
 };
 
@@ -366,7 +418,8 @@ int vae_workspace(fmi_vae* v, int B, int h, int w) {
   const int G = c.norm_num_groups;
   const size_t part_bytes = ((size_t)B * gn_max_chunks((int)((size_t)H * W)) * G * sizeof(float2) + 255) / 256 * 256;
   const size_t stat_bytes = ((size_t)B * G * sizeof(float2) + 255) / 256 * 256;
-  const size_t total = 4 * act_bytes + score_bytes + part_bytes + stat_bytes;
+  const size_t ones_bytes = 4096 * sizeof(float);
+  const size_t total = 7 * act_bytes + score_bytes + part_bytes + stat_bytes + ones_bytes;
   if (v->ws) {
     FMI_HIP_TRY(hipDeviceSynchronize());
     FMI_HIP_TRY(hipFree(v->ws));
@@ -374,13 +427,19 @@ int vae_workspace(fmi_vae* v, int B, int h, int w) {
   }
   FMI_HIP_TRY(hipMalloc((void**)&v->ws, total));
   char* p = v->ws;
-  v->bx = (bf16_t*)p, p += act_bytes;
+  v->fx = (float*)p, p += 2 * act_bytes;
+  v->fx2 = (float*)p, p += 2 * act_bytes;
   v->bt1 = (bf16_t*)p, p += act_bytes;
   v->bt2 = (bf16_t*)p, p += act_bytes;
   v->bsc = (bf16_t*)p, p += act_bytes;
   v->scores = (bf16_t*)p, p += score_bytes;
   v->partial = (float2*)p, p += part_bytes;
-  v->stats = (float2*)p;
+  v->stats = (float2*)p, p += stat_bytes;
+  v->ones = (float*)p;
+  {
+    std::vector<float> one(4096, 1.0f);
+    FMI_HIP_TRY(hipMemcpy(v->ones, one.data(), ones_bytes, hipMemcpyHostToDevice));
+  }
   v->ws_bytes = total;
   v->wB = B, v->wh = h, v->ww = w;
   return FMI_OK;
@@ -390,21 +449,35 @@ int run_conv(fmi_vae* v, const Conv& c, const bf16_t* x, const bf16_t* resid, bf
   GemmProblem p = conv_problem(x, c.w, c.b, resid, out, B, H, W, c.cin_pad, c.cout, c.ks, up, v->zero);
   return launch_gemm(&p, 1, s);
 }
+// trunk = conv(x) + bias (add == false) / trunk += conv(x) + bias
+int run_conv_trunk(fmi_vae* v, const Conv& c, const bf16_t* x, float* trunk, bool add, int B, int H, int W, int up, hipStream_t s) {
+  if (c.cout > 4096) return fail(FMI_ERR_UNSUPPORTED, "vae: more than 4096 channels");
+  GemmProblem p = conv_problem_f32(x, c.w, c.b, trunk, add, v->ones, B, H, W, c.cin_pad, c.cout, c.ks, up, v->zero);
+  return launch_gemm(&p, 1, s);
+}
 int run_gn(fmi_vae* v, const GN& g, const bf16_t* x, bf16_t* out, int B, int HW, int silu_on, hipStream_t s) {
   return launch_groupnorm_nhwc(x, g.w, g.b, out, B, HW, g.c, v->cfg.norm_num_groups, 1e-6f, silu_on, v->partial, v->stats, s);
 }
-// ResnetBlock::forward (vae.rs:157-172): x <- shortcut(x) + conv2(silu(gn2(conv1(silu(gn1(x))))))
+int run_gn_trunk(fmi_vae* v, const GN& g, const float* x, bf16_t* out, bf16_t* raw_out, int B, int HW, int silu_on, hipStream_t s) {
+  return launch_groupnorm_nhwc_t<float>(x, g.w, g.b, out, raw_out, B, HW, g.c, v->cfg.norm_num_groups, 1e-6f, silu_on, v->partial, v->stats, s);
+}
+int trunk_to_bf16(fmi_vae* v, bf16_t* out, int64_t n, hipStream_t s) {  // the operand copy a sampler's convolution reads
+  if (n % 8) return fail(FMI_ERR_UNSUPPORTED, "vae: activation size must be a multiple of 8");
+  hipLaunchKernelGGL(round_bf16_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n / 8, 256), 8192)), dim3(256), 0, s, v->fx, out, n / 8);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+// ResnetBlock::forward (vae.rs:157-172): x <- shortcut(x) + conv2(silu(gn2(conv1(silu(gn1(x)))))), x = the f32 trunk
 int run_resnet(fmi_vae* v, const Resnet& r, int B, int H, int W, hipStream_t s) {
-  FMI_TRY(run_gn(v, r.n1, v->bx, v->bt1, B, H * W, 1, s));
+  const bool sc = r.cin != r.cout;
+  FMI_TRY(run_gn_trunk(v, r.n1, v->fx, v->bt1, sc ? v->bsc : nullptr, B, H * W, 1, s));
   FMI_TRY(run_conv(v, r.c1, v->bt1, nullptr, v->bt2, B, H, W, 0, s));
   FMI_TRY(run_gn(v, r.n2, v->bt2, v->bt1, B, H * W, 1, s));
-  const bf16_t* resid = v->bx;
-  if (r.cin != r.cout) {
-    FMI_TRY(run_conv(v, r.sc, v->bx, nullptr, v->bsc, B, H, W, 0, s));
-    resid = v->bsc;
+  if (sc) {  // the 1 x 1 shortcut starts the new trunk (another channel count), conv2 adds to it
+    FMI_TRY(run_conv_trunk(v, r.sc, v->bsc, v->fx2, false, B, H, W, 0, s));
+    std::swap(v->fx, v->fx2);
   }
-  FMI_TRY(run_conv(v, r.c2, v->bt1, resid, v->bt2, B, H, W, 0, s));
-  std::swap(v->bx, v->bt2);
+  FMI_TRY(run_conv_trunk(v, r.c2, v->bt1, v->fx, true, B, H, W, 0, s));
   return FMI_OK;
 }
 // AttnBlock::forward (vae.rs:95-111) with the model-dtype sdpa of vae.rs:28-33
@@ -415,7 +488,7 @@ struct AttnW {
 int run_attn(fmi_vae* v, const AttnW& a, int B, int H, int W, hipStream_t s) {
   const int C = a.q.cout, HW = H * W;
   if (HW % 64) return fail(FMI_ERR_UNSUPPORTED, "vae attention: latent h*w must be a multiple of 64");
-  FMI_TRY(run_gn(v, a.gn, v->bx, v->bt1, B, HW, 0, s));
+  FMI_TRY(run_gn_trunk(v, a.gn, v->fx, v->bt1, nullptr, B, HW, 0, s));
   const float scale = (float)(1.0 / sqrt((double)C));
   for (int b = 0; b < B; ++b) {
     const bf16_t* xn = v->bt1 + (size_t)b * HW * C;
@@ -442,9 +515,8 @@ int run_attn(fmi_vae* v, const AttnW& a, int B, int H, int W, hipStream_t s) {
     po.A = v->scores, po.W = vt, po.bias = a.v.b, po.out = o, po.M = HW, po.N = C, po.K = HW, po.lda = HW, po.ldw = HW, po.ldo = C, po.epi = EPI_STORE_BF16,
     po.alpha = 1.f;
     FMI_TRY(launch_gemm(&po, 1, s));
-    // x[b] = to_out(o) + x[b]   (in place on the trunk)
-    bf16_t* xb = v->bx + (size_t)b * HW * C;
-    GemmProblem pf = conv_problem(o, a.o.w, a.o.b, xb, xb, 1, H, W, C, C, 1, 0, v->zero);
+    // x[b] += to_out(o)   (in place on the f32 trunk)
+    GemmProblem pf = conv_problem_f32(o, a.o.w, a.o.b, v->fx + (size_t)b * HW * C, true, v->ones, 1, H, W, C, C, 1, 0, v->zero);
     FMI_TRY(launch_gemm(&pf, 1, s));
   }
   return FMI_OK;
@@ -646,19 +718,20 @@ extern "C" int fmi_vae_encode(fmi_vae* v, const float* image, int B, int H, int 
     hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, s, image, v->bt1, c.in_channels, cp, H * W, n);
     FMI_LAUNCH_CHECK();
   }
-  FMI_TRY(run_conv(v, v->e_conv_in, v->bt1, nullptr, v->bx, B, H, W, 0, s));
+  FMI_TRY(run_conv_trunk(v, v->e_conv_in, v->bt1, v->fx, false, B, H, W, 0, s));
   for (int lvl = 0; lvl < c.n_blocks; ++lvl) {
     for (auto& r : v->down[lvl]) FMI_TRY(run_resnet(v, r, B, H, W, s));
     if (v->downconv[lvl].cout) {  // Downsample::forward (vae.rs:194-201): stride 2, zero column/row on the right/bottom
-      FMI_TRY(run_conv(v, v->downconv[lvl], v->bx, nullptr, v->bt2, B, H, W, -1, s));
-      std::swap(v->bx, v->bt2);
+      FMI_TRY(trunk_to_bf16(v, v->bt1, (int64_t)B * H * W * v->downconv[lvl].cin_pad, s));
+      FMI_TRY(run_conv_trunk(v, v->downconv[lvl], v->bt1, v->fx2, false, B, H, W, -1, s));
+      std::swap(v->fx, v->fx2);
       H /= 2, W /= 2;
     }
   }
   FMI_TRY(run_resnet(v, v->e_mid1, B, H, W, s));
   if (c.mid_block_add_attention) FMI_TRY(run_attn(v, AttnW{v->e_attn_gn, v->e_aq, v->e_ak, v->e_av, v->e_ao}, B, H, W, s));
   FMI_TRY(run_resnet(v, v->e_mid2, B, H, W, s));
-  FMI_TRY(run_gn(v, v->e_norm_out, v->bx, v->bt1, B, H * W, 1, s));
+  FMI_TRY(run_gn_trunk(v, v->e_norm_out, v->fx, v->bt1, nullptr, B, H * W, 1, s));
   FMI_TRY(run_conv(v, v->e_conv_out, v->bt1, nullptr, v->bt2, B, H, W, 0, s));
   const bf16_t* mom = v->bt2;
   if (c.use_quant_conv) {
@@ -666,8 +739,8 @@ extern "C" int fmi_vae_encode(fmi_vae* v, const float* image, int B, int H, int 
     const int L2 = 2 * c.latent_channels, cp = v->quant_conv.cin_pad;
     FMI_HIP_TRY(hipMemsetAsync(v->bt1, 0, (size_t)B * H * W * cp * 2, s));
     FMI_HIP_TRY(hipMemcpy2DAsync(v->bt1, (size_t)cp * 2, v->bt2, (size_t)L2 * 2, (size_t)L2 * 2, (size_t)B * H * W, hipMemcpyDeviceToDevice, s));
-    FMI_TRY(run_conv(v, v->quant_conv, v->bt1, nullptr, v->bx, B, H, W, 0, s));
-    mom = v->bx;
+    FMI_TRY(run_conv(v, v->quant_conv, v->bt1, nullptr, v->bsc, B, H, W, 0, s));
+    mom = v->bsc;
   }
   const int64_t n = (int64_t)B * c.latent_channels * H * W;
   hipLaunchKernelGGL(diag_gaussian_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, s, mom, noise, z_out, moments_out, c.latent_channels,
@@ -692,19 +765,20 @@ extern "C" int fmi_vae_decode(fmi_vae* v, const float* z, int B, int h, int w, f
                        H * W, n);
     FMI_LAUNCH_CHECK();
   }
-  FMI_TRY(run_conv(v, v->conv_in, v->bt1, nullptr, v->bx, B, H, W, 0, s));  // vae.rs:438
+  FMI_TRY(run_conv_trunk(v, v->conv_in, v->bt1, v->fx, false, B, H, W, 0, s));  // vae.rs:438
   FMI_TRY(run_resnet(v, v->mid1, B, H, W, s));
   if (c.mid_block_add_attention) FMI_TRY(run_attn(v, AttnW{v->attn_gn, v->aq, v->ak, v->av, v->ao}, B, H, W, s));
   FMI_TRY(run_resnet(v, v->mid2, B, H, W, s));
   for (int lvl = 0; lvl < c.n_blocks; ++lvl) {
     for (auto& r : v->up[lvl]) FMI_TRY(run_resnet(v, r, B, H, W, s));
     if (v->upconv[lvl].cout) {  // Upsample::forward: nearest 2x folded into the conv gather (vae.rs:223-229)
-      FMI_TRY(run_conv(v, v->upconv[lvl], v->bx, nullptr, v->bt2, B, H, W, 1, s));
-      std::swap(v->bx, v->bt2);
+      FMI_TRY(trunk_to_bf16(v, v->bt1, (int64_t)B * H * W * v->upconv[lvl].cin_pad, s));
+      FMI_TRY(run_conv_trunk(v, v->upconv[lvl], v->bt1, v->fx2, false, B, H, W, 1, s));
+      std::swap(v->fx, v->fx2);
       H *= 2, W *= 2;
     }
   }
-  FMI_TRY(run_gn(v, v->norm_out, v->bx, v->bt1, B, H * W, 1, s));
+  FMI_TRY(run_gn_trunk(v, v->norm_out, v->fx, v->bt1, nullptr, B, H * W, 1, s));
   FMI_TRY(run_conv(v, v->conv_out, v->bt1, nullptr, v->bt2, B, H, W, 0, s));
   {
     const int64_t n = (int64_t)B * c.out_channels * H * W;
@@ -726,25 +800,25 @@ extern "C" int fmi_vae_mid_attention(fmi_vae* v, const void* x_bf16_nhwc, int B,
   FMI_TRY(check_part(v, true));
   hipStream_t s = (hipStream_t)stream;
   FMI_TRY(vae_workspace(v, B, H, W));
-  const size_t bytes = (size_t)B * H * W * v->aq.cout * sizeof(bf16_t);
-  FMI_HIP_TRY(hipMemcpyAsync(v->bx, x_bf16_nhwc, bytes, hipMemcpyDeviceToDevice, s));
+  const int64_t n = (int64_t)B * H * W * v->aq.cout;
+  if (n % 8) return fail(FMI_ERR_UNSUPPORTED, "vae_mid_attention: activation size must be a multiple of 8");
+  hipLaunchKernelGGL(widen_bf16_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n / 8, 256), 8192)), dim3(256), 0, s, (const bf16_t*)x_bf16_nhwc, v->fx, n / 8);
+  FMI_LAUNCH_CHECK();
   FMI_TRY(run_attn(v, AttnW{v->attn_gn, v->aq, v->ak, v->av, v->ao}, B, H, W, s));
-  FMI_HIP_TRY(hipMemcpyAsync(out_bf16_nhwc, v->bx, bytes, hipMemcpyDeviceToDevice, s));
-  return FMI_OK;
+  return trunk_to_bf16(v, (bf16_t*)out_bf16_nhwc, n, s);
 }
 
 extern "C" int fmi_groupnorm_nhwc(const void* x_bf16, const float* weight, const float* bias, void* out_bf16, int B, int HW, int C, int groups, float eps,
                                   int fuse_silu, void* stream) {
   if (!x_bf16 || !weight || !bias || !out_bf16) return fail(FMI_ERR_INVALID, "groupnorm_nhwc: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  float2* tmp = nullptr;
+  // the partial sums and statistics live in the library's per-stream op scratch: stream-ordered, nothing allocated or waited for per call
+  void* scratch = nullptr;
   const int nchunks = gn_chunks(HW);
-  FMI_HIP_TRY(hipMalloc((void**)&tmp, ((size_t)B * nchunks * groups + (size_t)B * groups) * sizeof(float2)));
-  int rc = launch_groupnorm_nhwc((const bf16_t*)x_bf16, weight, bias, (bf16_t*)out_bf16, B, HW, C, groups, eps, fuse_silu, tmp,
-                                 tmp + (size_t)B * nchunks * groups, s);
-  hipStreamSynchronize(s);
-  hipFree(tmp);
-  return rc;
+  FMI_TRY(op_scratch(s, ((size_t)B * nchunks * groups + (size_t)B * groups) * sizeof(float2), &scratch));
+  float2* tmp = static_cast<float2*>(scratch);
+  return launch_groupnorm_nhwc((const bf16_t*)x_bf16, weight, bias, (bf16_t*)out_bf16, B, HW, C, groups, eps, fuse_silu, tmp,
+                               tmp + (size_t)B * nchunks * groups, s);
 }
 
 extern "C" int fmi_conv2d_nhwc(const void* x_bf16, const void* w_bf16, const void* bias_bf16, const void* residual_bf16, void* out_bf16, int B, int in_h,

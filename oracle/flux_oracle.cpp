@@ -1461,8 +1461,17 @@ extern "C" int orc_vae_set_tensor(orc_vae* v, const char* name, const float* dat
   v->t[name] = std::vector<float>(data, data + numel);
   return 0;
 }
+// STUDY ONLY (tools/vae_rounding_study.py; not a recipe of the reference): which of the HIP decoder's bf16 roundings cost its u8 agreement with this f32 decoder?
+// bit 0: conv outputs inside a ResnetBlock (the input of norm2) rounded to bf16; bit 1: GroupNorm(+SiLU) outputs (the conv operands: what an MFMA needs anyway);
+// bit 2: the residual stream x (every ResnetBlock / AttnBlock / upsampler output); bit 3: the mid attention's q, k, v and output operands; bit 4: the final image.
+static int g_vae_study_round = 0;
+extern "C" void orc_vae_set_study_rounding(int mask) { g_vae_study_round = mask; }
 namespace {
 typedef std::vector<float> F;
+inline void v_round(F& x, int bit) {
+  if (!((g_vae_study_round >> bit) & 1)) return;
+  for (size_t i = 0; i < x.size(); ++i) x[i] = orc_round_bf16(x[i]);
+}
 bool v_conv(const orc_vae* v, const std::string& p, const F& x, int B, int Cin, int H, int W, int Cout, int k, F& out) {
   const float* w = v->get(p + ".weight", (int64_t)Cout * Cin * k * k);
   const float* b = v->get(p + ".bias", Cout);
@@ -1478,6 +1487,7 @@ bool v_gn(const orc_vae* v, const std::string& p, const F& x, int B, int C, int 
   out.resize(x.size());
   orc_group_norm(x.data(), w, b, B, C, HW, v->groups, 1e-6f, out.data());
   if (silu) orc_silu(out.data(), (int64_t)out.size(), out.data());
+  v_round(out, 1);
   return true;
 }
 // ResnetBlock::forward, vae.rs:157-172
@@ -1485,6 +1495,7 @@ bool v_resnet(const orc_vae* v, const std::string& p, F& x, int B, int Cin, int 
   F h, h2;
   if (!v_gn(v, p + ".norm1", x, B, Cin, H * W, h, true)) return false;
   if (!v_conv(v, p + ".conv1", h, B, Cin, H, W, Cout, 3, h2)) return false;
+  v_round(h2, 0);
   if (!v_gn(v, p + ".norm2", h2, B, Cout, H * W, h, true)) return false;
   if (!v_conv(v, p + ".conv2", h, B, Cout, H, W, Cout, 3, h2)) return false;
   if (Cin != Cout) {
@@ -1493,6 +1504,7 @@ bool v_resnet(const orc_vae* v, const std::string& p, F& x, int B, int Cin, int 
     x.swap(sc);
   }
   for (size_t i = 0; i < x.size(); ++i) x[i] += h2[i];
+  v_round(x, 2);
   return true;
 }
 // AttnBlock::forward, vae.rs:95-111 with the local sdpa vae.rs:28-33 (model dtype = f32 here).
@@ -1514,12 +1526,15 @@ bool v_attn(const orc_vae* v, const std::string& p, F& x, int B, int C, int H, i
     gemm_nt(tok.data(), C, wq, C, bq, HW, C, C, q.data(), C, 1.f);
     gemm_nt(tok.data(), C, wk, C, bk, HW, C, C, k.data(), C, 1.f);
     gemm_nt(tok.data(), C, wv, C, bv, HW, C, C, vv.data(), C, 1.f);
+    v_round(q, 3), v_round(k, 3), v_round(vv, 3);
     float scale = (float)(1.0 / sqrt((double)C));
     orc_sdpa(q.data(), k.data(), vv.data(), 1, 1, HW, HW, C, scale, o.data());
+    v_round(o, 3);
     gemm_nt(o.data(), C, wo, C, bo, HW, C, C, oo.data(), C, 1.f);
     for (int c = 0; c < C; ++c)
       for (int i = 0; i < HW; ++i) x[((size_t)b * C + c) * HW + i] += oo[(size_t)i * C + c];
   }
+  v_round(x, 2);
   return true;
 }
 }  // namespace
@@ -1541,6 +1556,7 @@ extern "C" int orc_vae_decode(orc_vae* v, const float* z, int B, int h, int w, f
   F x(z, z + (size_t)B * v->latent * h * w), y;
   if (!v_conv(v, "decoder.conv_in", x, B, v->latent, H, W, block_in, 3, y)) return -1;
   x.swap(y);
+  v_round(x, 2);
   if (!v_resnet(v, "decoder.mid_block.resnets.0", x, B, block_in, block_in, H, W)) return -1;
   if (v->mid_attn && !v_attn(v, "decoder.mid_block.attentions.0", x, B, block_in, H, W)) return -1;
   if (!v_resnet(v, "decoder.mid_block.resnets.1", x, B, block_in, block_in, H, W)) return -1;
@@ -1557,6 +1573,7 @@ extern "C" int orc_vae_decode(orc_vae* v, const float* z, int B, int h, int w, f
       H *= 2;
       W *= 2;
       if (!v_conv(v, p + ".upsamplers.0.conv", up, B, block_in, H, W, block_in, 3, x)) return -1;
+      v_round(x, 2);
     }
   }
   F n;
@@ -1569,6 +1586,7 @@ extern "C" int orc_vae_decode(orc_vae* v, const float* z, int B, int h, int w, f
     fprintf(stderr, "[oracle] use_post_quant_conv=true is a shape error in the reference\n");
     return -2;
   }
+  v_round(y, 4);
   memcpy(out, y.data(), sizeof(float) * y.size());
   return 0;
 }

@@ -175,3 +175,33 @@ def test_fp8qk_and_q8_linears_are_stream_ordered_and_equal_their_workspace_forms
         rel = float((y_ws.float() - ref).norm() / ref.norm())
         assert rel <= (6e-2 if kind == 1 else 2e-2), rel
     del keep
+
+
+def test_groupnorm_op_is_stream_ordered(env):
+    """fmi_groupnorm_nhwc (nn/group_norm.rs:39-74 as one op) took its partial-sum scratch from hipMalloc, waited for the stream and freed it on every call until
+    round 5; it now uses the same per-stream scratch as the attention / linear entries: 40 calls behind ~60 ms of other work return while that work is running,
+    and the result is the idle-stream result."""
+    import time
+    torch, L, lib = env["torch"], env["L"], env["lib"]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, HW, Cc, G = 1, 128 * 128, 512, 32
+    x = torch.randn(B, HW, Cc, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn(Cc, device="cuda", generator=g)
+    b = torch.randn(Cc, device="cuda", generator=g)
+    lib.fmi_groupnorm_nhwc.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]
+    ref = torch.empty_like(x)
+    L.check(lib.fmi_groupnorm_nhwc(_p(x), _p(w), _p(b), _p(ref), B, HW, Cc, G, 1e-6, 1, None))
+    torch.cuda.synchronize()
+    go, keep, ms = _busy(torch, 60)
+    outs = [torch.empty_like(x) for _ in range(40)]
+    ev = go()
+    t0 = time.perf_counter()
+    for o in outs:
+        L.check(lib.fmi_groupnorm_nhwc(_p(x), _p(w), _p(b), _p(o), B, HW, Cc, G, 1e-6, 1, None))
+    host_ms = (time.perf_counter() - t0) * 1e3
+    still_running = not ev.query()
+    torch.cuda.synchronize()
+    print(f"40 x fmi_groupnorm_nhwc (128x128x512) behind {ms:.0f} ms of matmuls: host back in {host_ms:.2f} ms, earlier work still running: {still_running}")
+    assert still_running and host_ms < 0.5 * ms
+    for o in outs:
+        assert torch.equal(o, ref)
