@@ -70,8 +70,9 @@ def test_vae_decode_flux_config_matches_oracle(h):
     mx, frac = _u8_agreement(d, orc, got, ref)
     print(f"VAE decode at the FLUX config, latent {h}x{h} -> {8 * h}^2: rel-L2 {err:.3e}, u8 max |d| {mx}, frac<=2 {frac:.5f} "
           f"(oracle {t_or:.1f} s, ref range [{ref.min():.2f},{ref.max():.2f}])")
-    assert err <= 2e-2
-    assert frac >= 0.99
+    # round 5: the decoder's trunk is f32 (GroupNorm reads it, the convolutions' epilogues add to it): 1.19e-2 / 99.41 % before, SURVEY 8(d)'s starting bar now
+    assert err <= 1.2e-2
+    assert frac >= 0.999
     gv.close()
 
 
@@ -381,7 +382,7 @@ def test_c2_fifty_step_trajectory_of_the_full_model_matches_oracle(full_models):
     sat = float(((u_ref == 0) | (u_ref == 255)).mean())
     print(f"  u8 image after 50 steps + VAE (192 x 256): max |d| {mx}, within 2 on {frac:.4%} (the VAE alone on the oracle's latents: max {mx_v}, {frac_v:.4%}; "
           f"{sat:.1%} of the oracle's values saturated)")
-    assert frac >= 0.99
+    assert frac >= 0.999  # (the decoder's f32 trunk, round 5)
     full_models["traj50"] = dict(img=img, ids=ids, t5=t5, txt_ids=txt_ids, clip=clip, g=g, ts=ts, ref=ref, hw=(h, w), gv=gv, ov=ov, bf16=drift)
 
 

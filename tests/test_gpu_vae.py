@@ -33,7 +33,7 @@ def test_vae_decode_matches_oracle(B, h, w):
     diff = np.abs(u_ref.astype(np.int32) - u_got.astype(np.int32))
     frac = float((diff <= 2).mean())
     print(f"u8: max |d| {diff.max()}, frac<=2 {frac:.4f}")
-    assert frac >= 0.99
+    assert frac >= 0.999  # (f32 trunk since round 5: 0.9993-0.9995 here)
 
 
 def test_vae_encode_matches_oracle():
