@@ -27,14 +27,14 @@ alt: $(ALT_LIB)
 oracle:
 	$(MAKE) -C oracle -s
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h $(CSRC)/attention_w4_loop.inc $(CSRC)/attention_w16.h $(CSRC)/attention_w16_loop.inc $(CSRC)/attention_w16f8_loop.inc $(CSRC)/attention_w32.h $(CSRC)/attention_w32_loop.inc $(CSRC)/attention_w16l.h $(CSRC)/attention_w16l_loop.inc $(CSRC)/attention_w16lf8_loop.inc $(CSRC)/attention_w16lf8pv_loop.inc include/flux_mi355x.h
+HDRS := $(CSRC)/common.h $(CSRC)/gemm_w4q.h $(CSRC)/attention_w4.h $(CSRC)/attention_w4_loop.inc $(CSRC)/attention_w16.h $(CSRC)/attention_w16_loop.inc $(CSRC)/attention_w16f8_loop.inc $(CSRC)/attention_w32.h $(CSRC)/attention_w32_loop.inc $(CSRC)/attention_w16l.h $(CSRC)/attention_w16l_loop.inc $(CSRC)/attention_w16lf8_loop.inc $(CSRC)/attention_w16lf8pv_loop.inc include/flux_mi355x.h
+build/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -Ibuild -c $< -o $@
 
-build/alt/%.o: $(CSRC)/%.hip build/%.o
+build/alt/%.o: $(CSRC)/%.hip $(HDRS) build/build_id.h
 	@mkdir -p build/alt
 	$(HIPCC) $(HIPFLAGS) -DFMI_ALT_KERNELS=1 -Ibuild -c $< -o $@
-# (the prerequisite build/%.o carries the header / generated-stream dependencies of the pattern rule above)
 
 build/build_id.h: FORCE
 	@mkdir -p build
