@@ -1465,6 +1465,7 @@ extern "C" int orc_vae_set_tensor(orc_vae* v, const char* name, const float* dat
 // bit 0: conv outputs inside a ResnetBlock (the input of norm2) rounded to bf16; bit 1: GroupNorm(+SiLU) outputs (the conv operands: what an MFMA needs anyway);
 // bit 2: the residual stream x (every ResnetBlock / AttnBlock / upsampler output); bit 3: the mid attention's q, k, v and output operands; bit 4: the final image.
 static int g_vae_study_round = 0;
+static bool g_vae_last_level = false;  // (bit 5: the residual stream rounded at the LAST resolution level only)
 extern "C" void orc_vae_set_study_rounding(int mask) { g_vae_study_round = mask; }
 namespace {
 typedef std::vector<float> F;
@@ -1505,6 +1506,7 @@ bool v_resnet(const orc_vae* v, const std::string& p, F& x, int B, int Cin, int 
   }
   for (size_t i = 0; i < x.size(); ++i) x[i] += h2[i];
   v_round(x, 2);
+  if (g_vae_last_level) v_round(x, 5);
   return true;
 }
 // AttnBlock::forward, vae.rs:95-111 with the local sdpa vae.rs:28-33 (model dtype = f32 here).
@@ -1563,6 +1565,7 @@ extern "C" int orc_vae_decode(orc_vae* v, const float* z, int B, int h, int w, f
   for (int lvl = 0; lvl < nb; ++lvl) {
     const int block_out = v->boc[nb - 1 - lvl];
     const std::string p = "decoder.up_blocks." + std::to_string(lvl);
+    g_vae_last_level = lvl == nb - 1;
     for (int i = 0; i <= v->layers_per_block; ++i) {
       if (!v_resnet(v, p + ".resnets." + std::to_string(i), x, B, block_in, block_out, H, W)) return -1;
       block_in = block_out;
@@ -1576,6 +1579,7 @@ extern "C" int orc_vae_decode(orc_vae* v, const float* z, int B, int h, int w, f
       v_round(x, 2);
     }
   }
+  g_vae_last_level = false;
   F n;
   if (!v_gn(v, "decoder.conv_norm_out", x, B, block_in, H * W, n, true)) return -1;
   if (!v_conv(v, "decoder.conv_out", n, B, block_in, H, W, v->out_ch, 3, y)) return -1;
