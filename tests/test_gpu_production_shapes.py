@@ -328,7 +328,7 @@ def _decode_u8(d, orc, gv, ov, lat_gpu, lat_ref, h, w):
 TRAJ_MARKS = (10, 25, 50)
 # what the int8 mode is held to over the 50 steps (stated after measuring): the bar of the 8-bit modes on the latents at every mark
 INT8_TRAJ_BAR = 3e-2
-INT8_TRAJ_U8_BAR = 0.95
+INT8_TRAJ_U8_BAR = 0.98  # (99.06 % measured with the decoder's f32 trunk; 97.5 % before it)
 
 
 def test_c2_fifty_step_trajectory_of_the_full_model_matches_oracle(full_models):
