@@ -113,7 +113,7 @@ struct fmi_flux {
     int B = 0, S = 0, T = 0;
     char* base = nullptr;
     size_t bytes = 0;
-    float *x_img, *x_txt, *x, *vec, *mod, *temb, *h1, *yf, *pe, *img_f32, *pred_tmp, *tv;
+    float *x_img, *x_txt, *x_txt0, *x, *vec, *mod, *temb, *h1, *yf, *pe, *img_f32, *pred_tmp, *tv;  // x_txt0: txt_in(txt), the same at every step of an image
     bf16_t *img_bf, *txt_bf, *xm, *qkv_img, *qkv_txt, *big, *Qh, *Kh, *Vt, *attn_img, *attn_txt, *hid, *vec_bf;
     uint8_t* a8 = nullptr;  // fp8 mode: the current GEMM input, rows [txt | img], (B*L, <= D+M) e4m3
     float* a8s = nullptr;   //           its per-token scales (B*L)
@@ -425,6 +425,7 @@ int ensure_workspace(fmi_flux* m, int B, int S, int T) {
   auto add = [&](void** p, size_t bytes) { items.push_back({p, bytes, take(bytes)}); };
   add((void**)&w.x_img, (size_t)B * S * D * 4);
   add((void**)&w.x_txt, (size_t)B * T * D * 4);
+  add((void**)&w.x_txt0, (size_t)B * T * D * 4);
   add((void**)&w.x, (size_t)B * L * D * 4);
   add((void**)&w.vec, (size_t)B * D * 4);
   add((void**)&w.mod, (size_t)B * m->n_mod * 4);
@@ -826,8 +827,9 @@ int compute_vec(fmi_flux* m, const fmi_flux_inputs* in, const float* timesteps_d
 
 // One model evaluation given prepared static inputs; img_f32 (B,S,C) -> pred (B,S,C) f32.
 // mod_pre: this step's (B, n_mod) modulation vectors if the caller precomputed them (fmi_flux_denoise), else null.
+// txt_pre: txt_in(txt) if the caller computed it once for all steps (fmi_flux_denoise: it does not depend on the latent or on t), else null.
 int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, const float* timesteps_dev, float* pred, hipStream_t s,
-                 const float* mod_pre = nullptr) {
+                 const float* mod_pre = nullptr, const float* txt_pre = nullptr) {
   auto& w = m->ws;
   const fmi_flux_config& c = m->cfg;
   const int B = in->B, S = in->S, T = in->T, L = S + T;
@@ -855,7 +857,12 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
     p[0] = make_problem(m->img_in, w.img_bf, C, B * S, w.x_img, D, EPI_STORE_F32);
     p[1] = make_problem(m->txt_in, w.txt_bf, c.joint_attention_dim, B * T, w.x_txt, D, EPI_STORE_F32);
     Dense* dn[2] = {&m->img_in, &m->txt_in};
-    FMI_TRY(gemm2(m, p, dn, 2, s));
+    if (txt_pre) {  // the text stream starts every step from the same values: a 6 MB copy instead of a 13-GFLOP GEMM per step (same bits)
+      FMI_HIP_TRY(hipMemcpyAsync(w.x_txt, txt_pre, (size_t)B * T * D * 4, hipMemcpyDeviceToDevice, s));
+      FMI_TRY(gemm1(m, p[0], m->img_in, s));
+    } else {
+      FMI_TRY(gemm2(m, p, dn, 2, s));
+    }
   }
   if (!mod_pre) {
     // every Modulation1/2 + LastLayer.ada_ln of the model in one GEMV: lin(silu(vec)) (model.rs:244-299,695-698)
@@ -1443,8 +1450,15 @@ extern "C" int fmi_flux_denoise(fmi_flux* m, const fmi_flux_inputs* in, float* i
     }
     mod_steps = m->mod_steps;
   }
+  const float* txt_pre = nullptr;
+  if (n_steps > 1) {  // txt = txt_in(txt) (model.rs:812) depends on the prompt only: once per image
+    PhaseTimer pt(m, s, PH_EMBED);
+    GemmProblem p = make_problem(m->txt_in, m->ws.txt_bf, m->cfg.joint_attention_dim, B * in->T, m->ws.x_txt0, m->D, EPI_STORE_F32);
+    FMI_TRY(gemm1(m, p, m->txt_in, s));
+    txt_pre = m->ws.x_txt0;
+  }
   for (int i = 0; i < n_steps; ++i) {
-    FMI_TRY(forward_core(m, in, img_inout, m->ws.tv + (size_t)i * B, m->ws.pred_tmp, s, mod_steps ? mod_steps + (size_t)i * B * nmod : nullptr));
+    FMI_TRY(forward_core(m, in, img_inout, m->ws.tv + (size_t)i * B, m->ws.pred_tmp, s, mod_steps ? mod_steps + (size_t)i * B * nmod : nullptr, txt_pre));
     // img = img + pred * (t_prev - t_curr)  (sampling.rs:43), scalar rounded to f32 like candle's affine
     const float dt = (float)(timesteps_host[i + 1] - timesteps_host[i]);
     FMI_TRY(launch_euler_update(img_inout, m->ws.pred_tmp, dt, n, s));
