@@ -463,6 +463,12 @@ int ensure_workspace(fmi_flux* m, int B, int S, int T) {
   FMI_HIP_TRY(hipMalloc((void**)&w.base, total));
   FMI_HIP_TRY(hipMemset(w.base, 0, total));  // also zeroes the Vt pad columns once
   for (auto& it : items) *it.p = w.base + it.o;
+  if (B == 1) {
+    // one sample: the two streams of the double blocks ARE the halves of the joint stream the single blocks read — cat([txt, img], 1) (model.rs:827)
+    // is then no copy at all (with B > 1 the streams are (B*T, D) / (B*S, D) row blocks for the grouped GEMMs and the concat interleaves them per sample)
+    w.x_txt = w.x;
+    w.x_img = w.x + (size_t)T * D;
+  }
   w.bytes = total;
   w.B = B, w.S = S, w.T = T, w.Lpad = Lpad;
   return FMI_OK;
@@ -1011,7 +1017,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
   }
 
   // ---------------- cat([txt, img], 1) (model.rs:827) then single-stream blocks (model.rs:638-662)
-  for (int b = 0; b < B; ++b) {
+  for (int b = 0; b < B && w.x_txt != w.x; ++b) {  // (B == 1: the streams alias the joint buffer, ensure_workspace)
     FMI_HIP_TRY(hipMemcpyAsync(w.x + (size_t)b * L * D, w.x_txt + (size_t)b * T * D, (size_t)T * D * 4, hipMemcpyDeviceToDevice, s));
     FMI_HIP_TRY(hipMemcpyAsync(w.x + ((size_t)b * L + T) * D, w.x_img + (size_t)b * S * D, (size_t)S * D * 4, hipMemcpyDeviceToDevice, s));
   }
