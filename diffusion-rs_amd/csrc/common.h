@@ -359,6 +359,7 @@ int launch_cast_to_bf16(const void* src, fmi_dtype dt, bf16_t* dst, int64_t n, h
 int launch_cast_to_f32(const void* src, fmi_dtype dt, float* dst, int64_t n, hipStream_t stream);
 int launch_silu_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t stream);
 int launch_euler_update(float* img, const float* pred, float dt, int64_t n, hipStream_t stream);
+int launch_add2_rows(float* y, const float* g, const float* v, int R, int B, int N, hipStream_t stream);  // y[r] = (y[r] + g[r % B]) + v[r % B] (g may be null)
 // split-K reduce: out[m][n] += gate_b[n] * (part_0 + part_1 + ... + part_{S-1} + bias[n]), the parts added in index order
 // (f32 (S, M, N) contiguous); the EPI_RESID_GATE_F32 epilogue for a launch whose K range was cut into S problems
 int launch_splitk_resid_gate(const float* parts, int S, const bf16_t* bias, const float* gate, int rows_per_batch, int gate_bstride, float* out, int ldo,

@@ -133,7 +133,7 @@ struct fmi_flux {
   int attn_kind = -1;  // fmi_flux_set_attention_kernel: 0..5 = this handle's attention kernel, -1 = follow the process-wide switch
   // 4-bit weights, large-M regime: per-layer streaming dequant into a reusable bf16 scratch
   // all denoise steps' modulation vectors (n_steps*B, n_mod) and vec (n_steps*B, D), see fmi_flux_denoise
-  float *mod_steps = nullptr, *vec_steps = nullptr;
+  float *mod_steps = nullptr, *vec_steps = nullptr, *temb_steps = nullptr, *h1_steps = nullptr;
   bf16_t* vec_steps_bf = nullptr;  // silu(vec_steps) in bf16: A operand of the modulation GEMM
   size_t mod_steps_rows = 0;
   int mod_gemm = 1;  // fmi_flux_denoise: 1 = all steps' modulation vectors in one MFMA GEMM when there are more than 4 rows (else GEMV passes of 4 rows), 0 = always GEMV, 2 = always the GEMM
@@ -831,6 +831,30 @@ int compute_vec(fmi_flux* m, const fmi_flux_inputs* in, const float* timesteps_d
   return FMI_OK;
 }
 
+// The same for all R = n_steps * B rows of an image at once (fmi_flux_denoise; row i*B + b = step i, sample b): the guidance and pooled-text terms do not
+// depend on the step — computed once —, the timestep term runs as row passes over its two matrices (each output row depends on its own input row only),
+// and the three are added in compute_vec's order ((time + guidance) + pooled): the same f32 operations, hence the same bits, in 32 launches instead of 350.
+int compute_vec_steps(fmi_flux* m, const fmi_flux_inputs* in, const float* tv_dev, int n_steps, float* vec_steps, float* temb_steps, float* h1_steps, hipStream_t s) {
+  auto& w = m->ws;
+  const fmi_flux_config& c = m->cfg;
+  const int B = in->B, D = m->D, R = n_steps * B;
+  FMI_TRY(launch_timestep_embedding(tv_dev, R, 256, temb_steps, s));
+  FMI_TRY(launch_gemv(temb_steps, m->time1.w, m->time1.b, h1_steps, R, D, 256, 0, 0, s));
+  FMI_TRY(launch_gemv(h1_steps, m->time2.w, m->time2.b, vec_steps, R, D, D, 1, 0, s));
+  float* gterm = nullptr;
+  if (c.guidance_embeds) {
+    if (!in->guidance) return fail(FMI_ERR_INVALID, "flux: guidance_embeds model needs a guidance vector");
+    gterm = h1_steps;  // (free again: rows 0 .. B-1 hold the guidance term, rows B .. 2B-1 the pooled-text term)
+    FMI_TRY(launch_timestep_embedding(in->guidance, B, 256, w.temb, s));
+    FMI_TRY(launch_gemv(w.temb, m->guid1.w, m->guid1.b, w.h1, B, D, 256, 0, 0, s));
+    FMI_TRY(launch_gemv(w.h1, m->guid2.w, m->guid2.b, gterm, B, D, D, 1, 0, s));
+  }
+  float* vterm = h1_steps + (size_t)B * D;
+  FMI_TRY(launch_gemv(w.yf, m->vecin1.w, m->vecin1.b, w.h1, B, D, c.pooled_projection_dim, 0, 0, s));
+  FMI_TRY(launch_gemv(w.h1, m->vecin2.w, m->vecin2.b, vterm, B, D, D, 1, 0, s));
+  return launch_add2_rows(vec_steps, gterm, vterm, R, B, D, s);
+}
+
 // One model evaluation given prepared static inputs; img_f32 (B,S,C) -> pred (B,S,C) f32.
 // mod_pre: this step's (B, n_mod) modulation vectors if the caller precomputed them (fmi_flux_denoise), else null.
 // txt_pre: txt_in(txt) if the caller computed it once for all steps (fmi_flux_denoise: it does not depend on the latent or on t), else null.
@@ -1153,6 +1177,8 @@ extern "C" void fmi_flux_destroy(fmi_flux* m) {
   if (m->mod_steps) hipFree(m->mod_steps);
   if (m->vec_steps) hipFree(m->vec_steps);
   if (m->vec_steps_bf) hipFree(m->vec_steps_bf);
+  if (m->temb_steps) hipFree(m->temb_steps);
+  if (m->h1_steps) hipFree(m->h1_steps);
   if (m->fp8_arena) hipFree(m->fp8_arena);
   for (Dense* d : m->fused)
     if (d->q_own) {
@@ -1429,15 +1455,19 @@ extern "C" int fmi_flux_denoise(fmi_flux* m, const fmi_flux_inputs* in, float* i
       if (m->mod_steps) FMI_HIP_TRY(hipFree(m->mod_steps));
       if (m->vec_steps) FMI_HIP_TRY(hipFree(m->vec_steps));
       if (m->vec_steps_bf) FMI_HIP_TRY(hipFree(m->vec_steps_bf));
-      m->mod_steps = m->vec_steps = nullptr, m->vec_steps_bf = nullptr, m->mod_steps_rows = 0;
+      if (m->temb_steps) FMI_HIP_TRY(hipFree(m->temb_steps));
+      if (m->h1_steps) FMI_HIP_TRY(hipFree(m->h1_steps));
+      m->mod_steps = m->vec_steps = nullptr, m->vec_steps_bf = nullptr, m->temb_steps = m->h1_steps = nullptr, m->mod_steps_rows = 0;
       FMI_HIP_TRY(hipMalloc((void**)&m->mod_steps, R * nmod * 4));
       FMI_HIP_TRY(hipMalloc((void**)&m->vec_steps, R * (size_t)m->D * 4));
       FMI_HIP_TRY(hipMalloc((void**)&m->vec_steps_bf, R * (size_t)m->D * 2));
+      FMI_HIP_TRY(hipMalloc((void**)&m->temb_steps, R * (size_t)256 * 4));
+      FMI_HIP_TRY(hipMalloc((void**)&m->h1_steps, std::max<size_t>(R, 2 * (size_t)B) * (size_t)m->D * 4));
       m->mod_steps_rows = R;
     }
     {
       PhaseTimer pt(m, s, PH_EMBED);
-      for (int i = 0; i < n_steps; ++i) FMI_TRY(compute_vec(m, in, m->ws.tv + (size_t)i * B, m->vec_steps + (size_t)i * B * m->D, s));
+      FMI_TRY(compute_vec_steps(m, in, m->ws.tv, n_steps, m->vec_steps, m->temb_steps, m->h1_steps, s));
     }
     {
       PhaseTimer pt(m, s, PH_MOD);

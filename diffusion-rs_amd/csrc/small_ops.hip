@@ -150,6 +150,21 @@ int launch_euler_update(float* img, const float* pred, float dt, int64_t n, hipS
   return FMI_OK;
 }
 
+// y[r][n] = (y[r][n] + g[r % B][n]) + v[r % B][n]: the step-invariant terms of `vec` added in the order the accumulating GEMVs added them
+int launch_add2_rows(float* y, const float* g, const float* v, int R, int B, int N, hipStream_t stream) {
+  const int64_t n = (int64_t)R * N;
+  if (n <= 0) return FMI_OK;
+  if (g && v)
+    hipLaunchKernelGGL(map_kernel, map_grid(n), dim3(256), 0, stream, n, [=] __device__(int64_t i) {
+      const int64_t o = ((i / N) % B) * N + i % N;
+      y[i] = (y[i] + g[o]) + v[o];
+    });
+  else
+    hipLaunchKernelGGL(map_kernel, map_grid(n), dim3(256), 0, stream, n, [=] __device__(int64_t i) { y[i] = y[i] + v[((i / N) % B) * N + i % N]; });
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+
 // dst (B, rows, D) <- src (B, rows_src_per_b, D)[:, row_off:row_off+rows, :]  (or the reverse by swapping roles)
 int launch_split_rows_f32(const float* src, float* dst, int B, int rows_src_per_b, int row_off, int rows, int D, hipStream_t stream) {
   for (int b = 0; b < B; ++b)
