@@ -417,8 +417,9 @@ def plan_y(ph, buf, uid):
     t + 1 in S^T buffer `buf`, which the X phase in front of this one completed (its last MFMAs are >= 4 slots behind gap 4)."""
     n, plan = ph.n, ph.valu
     plan[4] += rare("nomask", uid, "s_cbranch_scc1", "s_cbranch_scc0", mask_block(buf), [f"s_cmp_eq_u32 {S_FLAG}, 0"])
-    spread(plan, max_tree(buf), 5, TREE_END)
-    plan[TREE_END + 2] += rare("skip", uid, "s_cbranch_vccz", "s_cbranch_vccnz", rescale_s(buf, True), [f"v_cmp_lt_f32 vcc, %[thr], {PMAX}"])
+    if not ("halftree" in XS and uid == "yo"):  # (timing experiment: the maximum taken on every other tile only)
+        spread(plan, max_tree(buf), 5, TREE_END)
+        plan[TREE_END + 2] += rare("skip", uid, "s_cbranch_vccz", "s_cbranch_vccnz", rescale_s(buf, True), [f"v_cmp_lt_f32 vcc, %[thr], {PMAX}"])
     spread(plan, [i for (a, q) in UNITS[:EY] for i in exps(buf, a, q)], TREE_END + 3, n - 1)
 
 

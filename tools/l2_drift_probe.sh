@@ -6,7 +6,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
 mkdir -p build gpurun_out/l2_drift
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result $PROBE_DEFS tools/gemm_bench.hip -o build/gemm_bench
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -DFMI_ALT_KERNELS=1 $PROBE_DEFS tools/gemm_bench.hip -o build/gemm_bench
 cd /tmp && export TMPDIR=/tmp
 for S in ${SHAPES:-4096,4096,3072 8192,8192,3072 4096,12288,3072 4608,21504,3072 4608,3072,15360}; do
   T=$(echo $S | tr , x)

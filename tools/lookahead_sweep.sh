@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 mkdir -p build
 for la in ${LAS:-6 8 10 12}; do
   AW16_X=la$la AW16_LOOKAHEAD=$la python3 tools/gen_attention_w16.py 2> /dev/null
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -DFMI_ALT_KERNELS=1 \
     -DFMI_AW16_LOOP_INC="\"../../build/attention_w16_loop_la$la.inc\"" tools/attn_bench.hip -o build/attn_bench_w16_la$la &
 done
 wait

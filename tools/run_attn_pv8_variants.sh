@@ -9,7 +9,7 @@ for spec in "$@"; do
   tag=${spec%%:*}; envs=${spec#*:}
   [ "$envs" = "$spec" ] && envs=""
   ( env $(echo "$envs" | tr ',' ' ') AW16L_MODE=fp8pv AW16L_TAG=$tag python3 tools/gen_attention_w16l.py 2> /dev/null
-    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -Ibuild \
+    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -DFMI_ALT_KERNELS=1 -Ibuild \
       -DFMI_AW16LF8PV_LOOP_INC="\"../../build/attention_w16lf8pv_loop_$tag.inc\"" tools/attn_bench.hip -o tools/bin/attn_pv8_$tag ) &
   while [ "$(jobs -r | wc -l)" -ge 7 ]; do sleep 1; done
 done

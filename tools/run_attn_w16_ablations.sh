@@ -10,7 +10,7 @@ K=${K:-w16}
 UP=$(echo $K | tr a-z A-Z)
 for v in ${VARIANTS:-novalu noexp nodma nobarrier halfreads nomfma nowait}; do
   env A${UP}_X=$v python3 tools/gen_attention_$K.py
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -DFMI_ALT_KERNELS=1 \
     -DFMI_A${UP}_LOOP_INC="\"../../build/attention_${K}_loop_$v.inc\"" tools/attn_bench.hip -o build/attn_bench_${K}_$v &
 done
 wait

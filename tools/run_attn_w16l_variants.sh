@@ -8,7 +8,7 @@ mkdir -p build tools/bin
 for spec in "$@"; do
   tag=${spec%%:*}; envs=${spec#*:}
   ( env $(echo "$envs" | tr ',' ' ') AW16L_TAG=$tag python3 tools/gen_attention_w16l.py 2> /dev/null
-    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -Ibuild \
+    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -DFMI_ALT_KERNELS=1 -Ibuild \
       -DFMI_AW16L_LOOP_INC="\"../../build/attention_w16l_loop_$tag.inc\"" tools/attn_bench.hip -o tools/bin/attn_w16l_$tag ) &
   while [ "$(jobs -r | wc -l)" -ge 7 ]; do sleep 1; done
 done
