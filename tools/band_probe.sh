@@ -6,7 +6,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
 mkdir -p build gpurun_out/band
-F="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -DFMI_ALT_KERNELS=1 -DFMI_ALT_KERNELS=1"
+F="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -DFMI_ALT_KERNELS=1"
 SH="${SHAPES:-4608,21504,3072;4608,3072,15360;4608,12288,3072;4608,3072,3072}"
 /opt/rocm/bin/hipcc $F tools/gemm_bench.hip -o build/gemm_bench
 pin() { if [ "$1" = auto ]; then env -u FMI_GEMM_BAND "${@:2}"; else env FMI_GEMM_BAND=$1 "${@:2}"; fi; }

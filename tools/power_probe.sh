@@ -4,7 +4,7 @@
 #   tools/power_probe.sh            (on the GPU box; builds what it needs into build/)
 cd "$(dirname "$0")/.."
 mkdir -p build
-F="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -DFMI_ALT_KERNELS=1 -DFMI_ALT_KERNELS=1"
+F="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -DFMI_ALT_KERNELS=1"
 [ -x build/gemm_bench ] || /opt/rocm/bin/hipcc $F tools/gemm_bench.hip -o build/gemm_bench
 [ -x build/mfma_peak ] || /opt/rocm/bin/hipcc $F tools/mfma_peak.hip -o build/mfma_peak
 [ -x build/load_rate ] || /opt/rocm/bin/hipcc $F tools/load_rate.hip -o build/load_rate

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build gpurun_out
-F="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -DFMI_ALT_KERNELS=1 -DFMI_ALT_KERNELS=1"
+F="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=on -Wno-unused-value -Wno-unused-result -DFMI_ALT_KERNELS=1"
 for v in ${VARIANTS:-full}; do
   echo "=== variant: $v"
   [ "$v" = full ] && v=""
