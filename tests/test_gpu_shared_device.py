@@ -146,6 +146,21 @@ def test_attention_and_gemm_reproduce_their_idle_results_while_another_process_u
         L.check(lib.fmi_sdpa_fp8qk(_p(q8), _p(k8), _p(v), _p(o), 1, H, Lq, Lq, 128, sc17, 1, None))
         return o
     cases.append(("sdpa fp8 QK one-wave lock-step (attention_w16l QK8)", lambda: run_fp8_attn_onewave(5)))
+
+    def run_fp8_attn_all(q8=q8, k8=k8, v=v, H=H, Lq=Lq):  # round 5: e4m3 P and V too (attention_w16l_kernel<.., true, true>: its own hand-placed waits and barriers)
+        o = torch.full((1, Lq, H * 128), float("nan"), dtype=torch.bfloat16, device="cuda")
+        L.check(lib.fmi_sdpa_fp8(_p(q8), _p(k8), _p(v), _p(o), 1, H, Lq, Lq, 128, sc17, -17, 16.0, 1, None))
+        return o
+    cases.append(("sdpa all-e4m3 lock-step (attention_w16l PV8)", run_fp8_attn_all))
+    for (H2, L2) in ((96, 1024), (24, 4550)):  # many short streams / a ragged last tile
+        qs, ks = (torch.randint(0, 0x48, (1, H2, L2, 128), generator=g, device="cuda", dtype=torch.uint8) for _ in range(2))
+        vs = torch.randn((1, H2, L2, 128), generator=g, device="cuda").to(torch.bfloat16)
+
+        def run_pv8_shape(qs=qs, ks=ks, vs=vs, H2=H2, L2=L2):
+            o = torch.full((1, L2, H2 * 128), float("nan"), dtype=torch.bfloat16, device="cuda")
+            L.check(lib.fmi_sdpa_fp8(_p(qs), _p(ks), _p(vs), _p(o), 1, H2, L2, L2, 128, sc17, -17, 16.0, 1, None))
+            return o
+        cases.append((f"sdpa all-e4m3 H={H2} L={L2}", run_pv8_shape))
     try:
         idle = []
         for name, run in cases:
