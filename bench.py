@@ -565,7 +565,7 @@ def main():
         out = {
             "metric": "images/sec, FLUX.1-dev 1024x1024 50-step" if (H, W, NS) == (1024, 1024, 50) else f"images/sec, FLUX.1-dev {W}x{H} {NS}-step",
             "value": total_images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "strong" if spg is not None else "weak", "vs_baseline": None, "dtype": {"none": "bf16", "nf4": "bf16 MFMA on nf4 weights (fused dequant-GEMM, packed weights only)",
+            "ms_per_step": ms_per_image, "higher_is_better": True, "scaling": "strong" if spg is not None else "weak", "vs_baseline": None, "dtype": {"none": "bf16", "nf4": "bf16 MFMA on nf4 weights (default policy: block matrices expanded once when HBM allows, modulation / small launches fused dequant-GEMM on the packed codes)",
                                                                                                                  "fp8": "fp8 e4m3 block linears (per-channel weight / per-token activation scales, f32 accumulate); attention: e4m3 q / k operands with static per-block scales (QK^T on the fp8 MFMA), bf16 P.V; f32 residual stream",
                                                                                                                  "int8": "int8 block linears on the default mask (per-channel / per-token scales, exact int32 accumulate); attention: e4m3 q / k operands with static per-block scales (QK^T on the fp8 MFMA), bf16 P.V; the double blocks' MLP and everything else bf16, f32 residual stream"}[args.quant],
             "data": "synthetic (random-init FLUX.1-dev + FLUX VAE weights, N(0,1) embeddings, Philox latents)",

@@ -134,6 +134,11 @@ def _declare(lib):
     lib.fmi_unpack_latents.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     lib.fmi_randn.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
     lib.fmi_philox_u32.argtypes = lib.fmi_randn.argtypes
+    lib.fmi_release_scratch.argtypes = [C.POINTER(C.c_size_t)]
+    lib.fmi_timestep_embedding.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.fmi_rope_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p]
+    lib.fmi_rmsnorm_rope.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p]
     lib.fmi_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.fmi_free.argtypes = [C.c_void_p]
     lib.fmi_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -246,9 +251,11 @@ def tree_build_id(root=None):
     return h.hexdigest()[:16]
 
 
-def check(rc):
+def check(rc, lib=None):
+    """`lib`: the library the failing call went to (a handle created under use_alt() keeps calling the test build after the block has ended:
+    its error string lives in THAT library's thread-local, not in the one load() returns now)."""
     if rc != 0:
-        raise FmiError(f"fmi status {rc}: {load().fmi_last_error().decode(errors='replace')}", code=int(rc))
+        raise FmiError(f"fmi status {rc}: {(lib or load()).fmi_last_error().decode(errors='replace')}", code=int(rc))
 
 
 # every symbol include/flux_mi355x.h declares (tests/test_host_logic.py::test_library_exports_every_header_symbol checks they are all exported)
@@ -262,6 +269,7 @@ EXPORTED = [
     "fmi_t5_size_in_bytes", "fmi_t5_forward", "fmi_clip_default_config", "fmi_clip_create", "fmi_clip_destroy", "fmi_clip_set_tensor",
     "fmi_clip_missing_count", "fmi_clip_missing_name", "fmi_clip_size_in_bytes", "fmi_clip_forward", "fmi_pack_latents", "fmi_unpack_latents", "fmi_postprocess_u8",
     "fmi_randn", "fmi_philox_u32", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_linear_int8_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_quantize_rows_i8", "fmi_linear_i8", "fmi_gemm_q8", "fmi_quantize_rows_i8_asym", "fmi_rowsum_i8", "fmi_gemm_i8_asym", "fmi_linear_q8_workspace_bytes", "fmi_linear_fp8_ws", "fmi_linear_i8_ws", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_sdpa_workspace_bytes", "fmi_sdpa_bf16_ws", "fmi_sdpa_fp8qk_ws", "fmi_sdpa_fp8", "fmi_sdpa_fp8_ws", "fmi_set_attention_kernel", "fmi_layernorm_mod",
+    "fmi_release_scratch", "fmi_timestep_embedding", "fmi_rope_table", "fmi_rmsnorm_rope",
     "fmi_groupnorm_nhwc", "fmi_conv2d_nhwc",
     "fmi_comm_probe", "fmi_comm_unique_id", "fmi_comm_create", "fmi_comm_destroy", "fmi_comm_rank", "fmi_comm_world_size", "fmi_comm_stats", "fmi_comm_all_to_all",
     "fmi_comm_broadcast", "fmi_comm_gather",

@@ -290,8 +290,20 @@ int launch_attention_ex(const bf16_t* q, const bf16_t* k, const bf16_t* vt, cons
 // unknown: the launcher recognises an exact power of two itself, anything else runs on the 8-wave kernel and is COUNTED
 // (attention_fp8_fallbacks(), visible in fmi_device_info) — a silent slide to the slower, numerically different kernel was ADVICE r3's finding.
 unsigned long long attention_fp8_fallbacks();
-// the op-level entries' scratch: a grow-only block per (device, stream) the library holds (capi.hip: ScratchCache) — no allocation, no wait in the steady state
-int op_scratch(hipStream_t s, size_t bytes, void** out);
+// the op-level entries' scratch: a grow-only block per (device, stream) the library holds (capi.hip: ScratchCache) — no allocation, no wait in the steady
+// state.  The guard keeps the cache locked from get() until it goes out of scope at the end of the entry, so the op's launches are enqueued as one unit.
+struct OpScratch {
+  explicit OpScratch(hipStream_t stream);
+  ~OpScratch();
+  OpScratch(const OpScratch&) = delete;
+  OpScratch& operator=(const OpScratch&) = delete;
+  int get(size_t bytes);
+  void* p = nullptr;
+
+ private:
+  hipStream_t s_;
+  bool locked_ = false;
+};
 bool alt_kernels_built();  // attention.hip: was THIS library linked from the test build's objects (the flag differs per object: only attention.o / gemm_bf16.o)
 void set_attention_pingpong(bool on);  // 8-wave kernels: ping-pong (default) or the single-barrier one
 void set_attention_w4(bool on);        // bf16 operands: one-wave-per-SIMD kernel (default) or the 8-wave ones
@@ -324,6 +336,8 @@ int launch_sp_merge_splits(const bf16_t* parts, const float* lse, int S, bf16_t*
 int launch_qk_norm_rope(const bf16_t* q, const bf16_t* k, int ld, int64_t in_bstride, const bf16_t* wq,
                         const bf16_t* wk, const float* pe, int64_t pe_bstride, bf16_t* qo, bf16_t* ko,
                         int B, int H, int rows, int row_off, int Ltot, hipStream_t stream);
+int launch_qk_norm_rope_f32(const bf16_t* q, const bf16_t* k, int ld, int64_t in_bstride, const bf16_t* wq, const bf16_t* wk, const float* pe,
+                            int64_t pe_bstride, float* qo, float* ko, int B, int H, int rows, int row_off, int Ltot, hipStream_t stream);
 int launch_rope_table(const float* txt_ids, const float* img_ids, int B, int T, int S, const int* axes,
                       int theta, float* pe, hipStream_t stream);
 // LayerNorm(no affine) * (1+scale) + shift; x f32 (rows, D) -> bf16. scale/shift per batch

@@ -148,6 +148,7 @@ struct fmi_flux {
   // expanded once); 2: always fused; 3: by size like 0, but a matrix that 0 would expand per call is expanded ONCE into its dense slot
   // (the small launches keep multiplying from the packed codes: the 50-row modulation GEMM reads 1.8 GB instead of 6.5)
   int quant_mode = -1;
+  bool quant_auto = true;  // quant_mode was (or will be) chosen from the free memory: an arena that then cannot be had demotes it to 0 instead of failing every forward
   std::set<const void*> dense_ready;
   bf16_t* wscratch[2] = {nullptr, nullptr};  // per-call expansion of quantised matrices at large M (densify)
   size_t wscratch_elems = 0;
@@ -586,7 +587,16 @@ int densify(fmi_flux* m, GemmProblem* p, Dense* const* dn, int n, hipStream_t s)
     if (!d || !p[i].q_type) continue;
     if (!m->dense_cache && !scratch) continue;  // fused paths (launch_gemm picks the kernel)
     const size_t elems = (size_t)p[i].N * p[i].K;
-    const bool once = m->dense_cache || (scratch && resolve_quant_mode(m) == 3);
+    bool once = m->dense_cache || (scratch && resolve_quant_mode(m) == 3);
+    if (once && !m->dense_cache && m->quant_auto && !m->arena[d->ar].base) {
+      // the "by memory" policy decided on ONE hipMemGetInfo snapshot: if the arena cannot be had after all — memory taken since, or a
+      // later arena of the same model — fall back to the packed-only policy for good instead of answering every forward with FMI_ERR_NOMEM
+      if (ensure_arena(m, d->ar) == FMI_ERR_NOMEM) {
+        (void)hipGetLastError();
+        m->quant_mode = 0;
+        once = false;
+      }
+    }
     if (once) {
       FMI_TRY(ensure_arena(m, d->ar));
       if (!m->dense_ready.count(d)) {
@@ -1558,6 +1568,7 @@ extern "C" int fmi_flux_set_quant_dense_cache(fmi_flux* m, int mode) {
     return fail(FMI_ERR_INVALID, "set_quant_dense_cache: mode must be -1 (by memory), 0 (packed only, by size), 1 (dense cache), 2 (always fused) or 3 (by size, large launches expanded once)");
   m->dense_cache = mode == 1;
   m->quant_mode = mode;
+  m->quant_auto = mode < 0;
   m->dense_ready.clear();
   return FMI_OK;
 }

@@ -286,7 +286,7 @@ int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* 
 int launch_quantize_rows_i8_asym(const bf16_t* x, int ld, int rows, int K, int d0, uint8_t* out, float* scale, float* offset, hipStream_t stream) {
   if (rows <= 0) return FMI_OK;
   if (K <= 0 || K % 8 || ld % 8 || K > 256 * 8 * QR_MAXC) return fail(FMI_ERR_INVALID, "quantize_rows_i8_asym: K and ld must be multiples of 8, K <= 16384");
-  if (d0 < 0 || d0 >= K || d0 % 8) return fail(FMI_ERR_INVALID, "quantize_rows_i8_asym: the offset segment starts at a multiple of 8 below K");
+  if (d0 < 0 || d0 >= K || d0 % 16) return fail(FMI_ERR_INVALID, "quantize_rows_i8_asym: the offset segment starts at a multiple of 16 below K (fmi_rowsum_i8's rule)");
   hipLaunchKernelGGL(quantize_rows_i8_asym_kernel, dim3(rows), dim3(256), 0, stream, x, ld, K, d0 >> 3, out, scale, offset);
   FMI_LAUNCH_CHECK();
   return FMI_OK;

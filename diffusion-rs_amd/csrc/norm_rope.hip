@@ -123,10 +123,13 @@ int launch_layernorm_mod(const float* x, const float* scale, const float* shift,
 
 // 16 lanes per (row, head) vector of 128; each lane owns 8 elements = 4 rope pairs.
 // grid.x covers B*rows*H/16 groups of 16 head-rows; q and k handled by the same lane.
+// F32OUT (the op-level seam fmi_rmsnorm_rope with an f32 result): the same arithmetic, the final rounding to bf16 left out — what the
+// tight (1e-6) comparison with the oracle's rms_norm + apply_rope reads; qo / ko then point to float.
+template <bool F32OUT>
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restrict q, const bf16_t* __restrict k, int ld,
                                                            int64_t in_bstride, const bf16_t* __restrict wq,
                                                            const bf16_t* __restrict wk, const float* __restrict pe,
-                                                           int64_t pe_bstride, bf16_t* __restrict qo, bf16_t* __restrict ko, int B,
+                                                           int64_t pe_bstride, void* __restrict qo, void* __restrict ko, int B,
                                                            int H, int rows, int row_off, int Ltot) {
   const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // head-row index
   const int sub = threadIdx.x & 15;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
   for (int which = 0; which < 2; ++which) {
     const bf16_t* src = (which ? k : q) + (int64_t)b * in_bstride + (int64_t)r * ld + h * 128 + sub * 8;
     const bf16_t* wv = (which ? wk : wq) + sub * 8;
-    bf16_t* dst = (which ? ko : qo) + (((int64_t)b * H + h) * Ltot + pos) * 128 + sub * 8;
+    const int64_t doff = (((int64_t)b * H + h) * Ltot + pos) * 128 + sub * 8;
     const uint4 raw = *reinterpret_cast<const uint4*>(src);
     const uint4 wraw = *reinterpret_cast<const uint4*>(wv);
     const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw);
@@ -160,13 +163,21 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
     ss = row16_sum(ss);
     const float inv = rms_inv128(ss);
     uint32_t o[4];
+    float of[8];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const float x0 = v[2 * p] * inv * bf16_to_f32(we[2 * p]);
       const float x1 = v[2 * p + 1] * inv * bf16_to_f32(we[2 * p + 1]);
-      o[p] = pack_bf16x2(cs[p] * x0 - sn[p] * x1, sn[p] * x0 + cs[p] * x1);
+      of[2 * p] = cs[p] * x0 - sn[p] * x1, of[2 * p + 1] = sn[p] * x0 + cs[p] * x1;
+      o[p] = pack_bf16x2(of[2 * p], of[2 * p + 1]);
     }
-    *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+    if (F32OUT) {
+      float4* d4 = reinterpret_cast<float4*>(static_cast<float*>(which ? ko : qo) + doff);
+      d4[0] = make_float4(of[0], of[1], of[2], of[3]);
+      d4[1] = make_float4(of[4], of[5], of[6], of[7]);
+    } else {
+      *reinterpret_cast<uint4*>(static_cast<bf16_t*>(which ? ko : qo) + doff) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
@@ -176,8 +187,19 @@ int launch_qk_norm_rope(const bf16_t* q, const bf16_t* k, int ld, int64_t in_bst
   if (rows <= 0) return FMI_OK;
   if (ld % 8) return fail(FMI_ERR_INVALID, "qk_norm_rope: ld must be a multiple of 8");
   const int64_t total = (int64_t)B * rows * H;
-  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)cdiv64(total, 16)), dim3(256), 0, stream, q, k, ld, in_bstride, wq, wk, pe,
-                     pe_bstride, qo, ko, B, H, rows, row_off, Ltot);
+  hipLaunchKernelGGL(qk_norm_rope_kernel<false>, dim3((unsigned)cdiv64(total, 16)), dim3(256), 0, stream, q, k, ld, in_bstride, wq, wk, pe,
+                     pe_bstride, (void*)qo, (void*)ko, B, H, rows, row_off, Ltot);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+int launch_qk_norm_rope_f32(const bf16_t* q, const bf16_t* k, int ld, int64_t in_bstride, const bf16_t* wq, const bf16_t* wk,
+                            const float* pe, int64_t pe_bstride, float* qo, float* ko, int B, int H, int rows, int row_off, int Ltot,
+                            hipStream_t stream) {
+  if (rows <= 0) return FMI_OK;
+  if (ld % 8) return fail(FMI_ERR_INVALID, "qk_norm_rope: ld must be a multiple of 8");
+  const int64_t total = (int64_t)B * rows * H;
+  hipLaunchKernelGGL(qk_norm_rope_kernel<true>, dim3((unsigned)cdiv64(total, 16)), dim3(256), 0, stream, q, k, ld, in_bstride, wq, wk, pe,
+                     pe_bstride, (void*)qo, (void*)ko, B, H, rows, row_off, Ltot);
   FMI_LAUNCH_CHECK();
   return FMI_OK;
 }

@@ -813,10 +813,10 @@ extern "C" int fmi_groupnorm_nhwc(const void* x_bf16, const float* weight, const
   if (!x_bf16 || !weight || !bias || !out_bf16) return fail(FMI_ERR_INVALID, "groupnorm_nhwc: null pointer");
   hipStream_t s = (hipStream_t)stream;
   // the partial sums and statistics live in the library's per-stream op scratch: stream-ordered, nothing allocated or waited for per call
-  void* scratch = nullptr;
   const int nchunks = gn_chunks(HW);
-  FMI_TRY(op_scratch(s, ((size_t)B * nchunks * groups + (size_t)B * groups) * sizeof(float2), &scratch));
-  float2* tmp = static_cast<float2*>(scratch);
+  OpScratch scratch(s);  // (holds the cache's lock until the three kernels below are enqueued)
+  FMI_TRY(scratch.get(((size_t)B * nchunks * groups + (size_t)B * groups) * sizeof(float2)));
+  float2* tmp = static_cast<float2*>(scratch.p);
   return launch_groupnorm_nhwc((const bf16_t*)x_bf16, weight, bias, (bf16_t*)out_bf16, B, HW, C, groups, eps, fuse_silu, tmp,
                                tmp + (size_t)B * nchunks * groups, s);
 }

@@ -160,7 +160,7 @@ class RcclComm:
         err = None
         try:  # stage 1: can this rank take part at all?  (no collective inside)
             with torch.cuda.device(self.device):
-                L.check(self.lib.fmi_comm_probe())
+                L.check(self.lib.fmi_comm_probe(), self.lib)
         except Exception as e:
             err = e
         agree_or_raise(err, "RCCL availability probe", group)
@@ -168,7 +168,7 @@ class RcclComm:
         if self.rank == 0:
             buf = (C.c_uint8 * 128)()
             try:
-                L.check(self.lib.fmi_comm_unique_id(buf))
+                L.check(self.lib.fmi_comm_unique_id(buf), self.lib)
                 ident = [bytes(buf)]
             except Exception as e:
                 err = e
@@ -180,7 +180,7 @@ class RcclComm:
         agree_or_raise(err, "RCCL id creation", group)  # stage 2: nobody enters ncclCommInitRank unless everybody holds the id
         try:
             with torch.cuda.device(self.device):
-                L.check(self.lib.fmi_comm_create((C.c_uint8 * 128).from_buffer_copy(ident[0]), self.rank, self.world_size, C.byref(h)))
+                L.check(self.lib.fmi_comm_create((C.c_uint8 * 128).from_buffer_copy(ident[0]), self.rank, self.world_size, C.byref(h)), self.lib)
         except Exception as e:
             err = e
         agree_or_raise(err, "RCCL communicator creation", group)
@@ -193,7 +193,7 @@ class RcclComm:
     def broadcast(self, ptr: int, nbytes: int, root: int = 0, stream=None):
         import ctypes as C
         from . import _lib as L
-        L.check(self.lib.fmi_comm_broadcast(self.h, C.c_void_p(ptr), nbytes, root, self._stream(stream)))
+        L.check(self.lib.fmi_comm_broadcast(self.h, C.c_void_p(ptr), nbytes, root, self._stream(stream)), self.lib)
 
     def gather(self, send: torch.Tensor, recv: Optional[torch.Tensor], root: int = 0, stream=None):
         import ctypes as C
@@ -207,7 +207,7 @@ class RcclComm:
         from . import _lib as L
         n = send.numel() * send.element_size()
         assert n % self.world_size == 0 and recv.numel() * recv.element_size() == n
-        L.check(self.lib.fmi_comm_all_to_all(self.h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), n // self.world_size, self._stream(stream)))
+        L.check(self.lib.fmi_comm_all_to_all(self.h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), n // self.world_size, self._stream(stream)), self.lib)
 
     def stats(self) -> Tuple[int, int]:
         import ctypes as C

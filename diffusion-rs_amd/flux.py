@@ -76,11 +76,11 @@ class FluxModel:
     def __init__(self, cfg: dict, device: int = 0):
         self.lib = L.load()
         self.cfg = dict(cfg)
-        L.check(self.lib.fmi_init(device))
+        L.check(self.lib.fmi_init(device), self.lib)
         c = L.FluxConfig(cfg["in_channels"], cfg["pooled_projection_dim"], cfg["joint_attention_dim"], cfg["num_attention_heads"],
                          cfg["num_layers"], cfg["num_single_layers"], int(cfg["guidance_embeds"]), (C.c_int * 3)(*cfg["axes_dim"]), cfg["theta"])
         h = C.c_void_p()
-        L.check(self.lib.fmi_flux_create(C.byref(c), L.MODEL_BF16, C.byref(h)))
+        L.check(self.lib.fmi_flux_create(C.byref(c), L.MODEL_BF16, C.byref(h)), self.lib)
         self.h = h
         self.hidden = cfg["num_attention_heads"] * 128
         self.device = torch.device("cuda", device)
@@ -102,7 +102,7 @@ class FluxModel:
     def set_tensor(self, name: str, t):
         p, dt, shape, keep = _tensor_arg(t)
         sh = (C.c_int64 * len(shape))(*shape)
-        L.check(self.lib.fmi_flux_set_tensor(self.h, name.encode(), p, dt, sh, len(shape)))
+        L.check(self.lib.fmi_flux_set_tensor(self.h, name.encode(), p, dt, sh, len(shape)), self.lib)
 
     def load_state_dict(self, tensors: dict):
         for k, v in tensors.items():
@@ -119,7 +119,7 @@ class FluxModel:
             pk = np.ascontiguousarray(packed, np.uint8)
             am = np.ascontiguousarray(absmax, np.float32)
             pp, ap = C.c_void_p(pk.ctypes.data), C.c_void_p(am.ctypes.data)
-        L.check(self.lib.fmi_flux_set_linear_bnb4(self.h, prefix.encode(), pp, ap, blocksize, q, out_features, in_features))
+        L.check(self.lib.fmi_flux_set_linear_bnb4(self.h, prefix.encode(), pp, ap, blocksize, q, out_features, in_features), self.lib)
 
     def set_linear_int8(self, prefix: str, weight, scb, out_features: int, in_features: int):
         """LLM.int8 linear (BnbLinear::Int8): weight int8 (out,in), SCB f32 (out)."""
@@ -131,12 +131,12 @@ class FluxModel:
             w = np.ascontiguousarray(weight, np.int8)
             sc = np.ascontiguousarray(scb, np.float32)
             wp, sp = C.c_void_p(w.ctypes.data), C.c_void_p(sc.ctypes.data)
-        L.check(self.lib.fmi_flux_set_linear_int8(self.h, prefix.encode(), wp, sp, out_features, in_features))
+        L.check(self.lib.fmi_flux_set_linear_int8(self.h, prefix.encode(), wp, sp, out_features, in_features), self.lib)
 
     def quantize_fp8(self, stream=None):
         """Switch the DiT block linears to the fp8 (OCP e4m3) MFMA path: weights quantised once per output
         channel from the loaded bf16 values, activations per token on the fly (BASELINE configs[4])."""
-        L.check(self.lib.fmi_flux_quantize_fp8(self.h, stream))
+        L.check(self.lib.fmi_flux_quantize_fp8(self.h, stream), self.lib)
 
     def quantize_int8(self, mask: int = None, stream=None):
         """Switch the DiT block linears named by `mask` (Q8_* bits; default INT8_DEFAULT_MASK) to the int8 MFMA path: symmetric per-row
@@ -144,12 +144,12 @@ class FluxModel:
         linears and everything else stay on the bf16 path — except the attention operands: as in the fp8 mode (set_fp8_attention, default
         on) the blocks whose q|k|v linear is in the mask hand q and k to the attention as e4m3 with static scales (QK^T on the fp8
         MFMA; P.V stays bf16).  set_fp8_attention(0) keeps bf16 operands."""
-        L.check(self.lib.fmi_flux_quantize_int8(self.h, INT8_DEFAULT_MASK if mask is None else int(mask), stream))
+        L.check(self.lib.fmi_flux_quantize_int8(self.h, INT8_DEFAULT_MASK if mask is None else int(mask), stream), self.lib)
 
     def set_fp8_attention(self, mode: int):
         """q and k of the attention as e4m3 with static scales, QK^T on the fp8 MFMA: 0 never, 1 (default) in the 8-bit modes, 2 in every
         mode — the bf16 block linears included (opt-in: a reduced-precision attention operand, not the reference's semantics)."""
-        L.check(self.lib.fmi_flux_set_fp8_attention(self.h, int(mode)))
+        L.check(self.lib.fmi_flux_set_fp8_attention(self.h, int(mode)), self.lib)
 
     def missing(self) -> List[str]:
         n = self.lib.fmi_flux_missing_count(self.h)
@@ -168,13 +168,13 @@ class FluxModel:
         -1 (default) = by memory: 3 when the device has the room, else 0; 0 / False = packed only: per-call expansion into a 264 MB
         scratch + dense GEMM; 1 / True = every matrix expanded once into the bf16 arenas; 2 = always the fused kernels; 3 = the matrices
         of the large launches expanded once.  Same bits in every mode."""
-        L.check(self.lib.fmi_flux_set_quant_dense_cache(self.h, int(mode)))
+        L.check(self.lib.fmi_flux_set_quant_dense_cache(self.h, int(mode)), self.lib)
 
     def set_split_k(self, on: bool):
         """Latency mode for launches of few rows (sequence-parallel shards): residual projections with fewer than 128 tiles are
         split along K and reduced in a fixed order, and the sequence-parallel attention of few heads walks key ranges in parallel
         (log-sum-exp merge) — deterministic, equal to the unsplit result to rounding (not bit for bit)."""
-        L.check(self.lib.fmi_flux_set_split_k(self.h, int(bool(on))))
+        L.check(self.lib.fmi_flux_set_split_k(self.h, int(bool(on))), self.lib)
 
     def set_sequence_parallel(self, rank: int, world_size: int, all_to_all=None):
         """Single-image sequence parallelism (fmi_flux_set_sequence_parallel): from now on forward / denoise take THIS rank's
@@ -195,7 +195,7 @@ class FluxModel:
                 return 1
 
         self._sp_cb = L.ALL_TO_ALL_FN(_cb) if world_size > 1 else L.ALL_TO_ALL_FN()  # keep the thunk alive with the model
-        L.check(self.lib.fmi_flux_set_sequence_parallel(self.h, int(rank), int(world_size), self._sp_cb, None))
+        L.check(self.lib.fmi_flux_set_sequence_parallel(self.h, int(rank), int(world_size), self._sp_cb, None), self.lib)
 
     def set_sequence_parallel_native(self, rank: int, world_size: int, comm):
         """The same with the exchange done by the library's own RCCL communicator (dist.RcclComm / fmi_comm): the callback is the C
@@ -203,26 +203,26 @@ class FluxModel:
         between two kernels of a block."""
         fn = C.cast(self.lib.fmi_comm_all_to_all, L.ALL_TO_ALL_FN)
         self._sp_cb, self._sp_comm = fn, comm  # keep both alive with the model
-        L.check(self.lib.fmi_flux_set_sequence_parallel(self.h, int(rank), int(world_size), fn, comm.h))
+        L.check(self.lib.fmi_flux_set_sequence_parallel(self.h, int(rank), int(world_size), fn, comm.h), self.lib)
 
     # ---- the weights as flat device buffers (multi-GPU broadcast, dist.broadcast_state)
     def state_export(self) -> bytes:
         n = C.c_size_t()
-        L.check(self.lib.fmi_flux_state_export(self.h, None, 0, C.byref(n)))
+        L.check(self.lib.fmi_flux_state_export(self.h, None, 0, C.byref(n)), self.lib)
         buf = (C.c_uint8 * n.value)()
-        L.check(self.lib.fmi_flux_state_export(self.h, buf, n.value, C.byref(n)))
+        L.check(self.lib.fmi_flux_state_export(self.h, buf, n.value, C.byref(n)), self.lib)
         return bytes(buf)
 
     def state_adopt(self, blob: bytes):
         buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
-        L.check(self.lib.fmi_flux_state_adopt(self.h, buf, len(blob)))
+        L.check(self.lib.fmi_flux_state_adopt(self.h, buf, len(blob)), self.lib)
 
     def state_buffers(self):
         """[(device pointer, bytes)] of the weight arenas (pointer 0 / 0 bytes for an arena not in use)."""
         out = []
         for i in range(self.lib.fmi_flux_state_buffer_count()):
             p, n = C.c_void_p(), C.c_size_t()
-            L.check(self.lib.fmi_flux_state_buffer(self.h, i, C.byref(p), C.byref(n)))
+            L.check(self.lib.fmi_flux_state_buffer(self.h, i, C.byref(p), C.byref(n)), self.lib)
             out.append((p.value or 0, n.value))
         return out
 
@@ -249,7 +249,7 @@ class FluxModel:
         """== Flux::forward (model.rs:790-833).  Returns the velocity (B,S,C) f32."""
         inp, keep = self._inputs(img, img_ids, txt, txt_ids, timesteps, y, guidance)
         pred = torch.empty(img.shape, dtype=torch.float32, device=img.device)
-        L.check(self.lib.fmi_flux_forward(self.h, C.byref(inp), _ptr(pred), _stream()))
+        L.check(self.lib.fmi_flux_forward(self.h, C.byref(inp), _ptr(pred), _stream()), self.lib)
         return pred
 
     def denoise(self, img, img_ids, txt, txt_ids, y, guidance, timesteps: List[float]):
@@ -257,16 +257,16 @@ class FluxModel:
         img = img.to(torch.float32).clone().contiguous()
         inp, keep = self._inputs(None, img_ids, txt, txt_ids, None, y, guidance)
         ts = (C.c_double * len(timesteps))(*timesteps)
-        L.check(self.lib.fmi_flux_denoise(self.h, C.byref(inp), _ptr(img), ts, len(timesteps) - 1, _stream()))
+        L.check(self.lib.fmi_flux_denoise(self.h, C.byref(inp), _ptr(img), ts, len(timesteps) - 1, _stream()), self.lib)
         return img
 
     def set_profiling(self, on: bool):
-        L.check(self.lib.fmi_flux_set_profiling(self.h, int(on)))
+        L.check(self.lib.fmi_flux_set_profiling(self.h, int(on)), self.lib)
 
     def phase_ms(self) -> dict:
         n = self.lib.fmi_flux_phase_count()
         out = (C.c_float * n)()
-        L.check(self.lib.fmi_flux_phase_ms(self.h, out))
+        L.check(self.lib.fmi_flux_phase_ms(self.h, out), self.lib)
         return {self.lib.fmi_flux_phase_name(i).decode(): out[i] for i in range(n)}
 
 
@@ -274,7 +274,7 @@ class AutoEncoderKl:
     def __init__(self, cfg: dict, device: int = 0):
         self.lib = L.load()
         self.cfg = dict(cfg)
-        L.check(self.lib.fmi_init(device))
+        L.check(self.lib.fmi_init(device), self.lib)
         boc = list(cfg["block_out_channels"])
         if len(boc) != 4:
             raise L.FmiError("block_out_channels must have 4 entries (the reference hard-codes i_level != 3, vae.rs:412)")
@@ -282,7 +282,7 @@ class AutoEncoderKl:
                         cfg["norm_num_groups"], int(cfg["mid_block_add_attention"]), int(cfg.get("use_post_quant_conv", False)),
                         cfg["scaling_factor"], cfg["shift_factor"], int(cfg.get("use_quant_conv", False)))
         h = C.c_void_p()
-        L.check(self.lib.fmi_vae_create(C.byref(c), L.MODEL_BF16, C.byref(h)))
+        L.check(self.lib.fmi_vae_create(C.byref(c), L.MODEL_BF16, C.byref(h)), self.lib)
         self.h = h
 
     def close(self):
@@ -299,7 +299,7 @@ class AutoEncoderKl:
     def set_tensor(self, name, t):
         p, dt, shape, keep = _tensor_arg(t)
         sh = (C.c_int64 * len(shape))(*shape)
-        L.check(self.lib.fmi_vae_set_tensor(self.h, name.encode(), p, dt, sh, len(shape)))
+        L.check(self.lib.fmi_vae_set_tensor(self.h, name.encode(), p, dt, sh, len(shape)), self.lib)
 
     def missing(self):
         n = self.lib.fmi_vae_missing_count(self.h)
@@ -342,7 +342,7 @@ class AutoEncoderKl:
         x = x_nhwc.contiguous()
         assert x.dtype == torch.bfloat16 and x.dim() == 4
         out = torch.empty_like(x)
-        L.check(self.lib.fmi_vae_mid_attention(self.h, _ptr(x), x.shape[0], x.shape[1], x.shape[2], _ptr(out), _stream()))
+        L.check(self.lib.fmi_vae_mid_attention(self.h, _ptr(x), x.shape[0], x.shape[1], x.shape[2], _ptr(out), _stream()), self.lib)
         return out
 
     def decode(self, z):
@@ -350,7 +350,7 @@ class AutoEncoderKl:
         z = z.to(torch.float32).contiguous()
         B, _, h, w = z.shape
         out = torch.empty((B, self.cfg["out_channels"], 8 * h, 8 * w), dtype=torch.float32, device=z.device)
-        L.check(self.lib.fmi_vae_decode(self.h, _ptr(z), B, h, w, _ptr(out), _stream()))
+        L.check(self.lib.fmi_vae_decode(self.h, _ptr(z), B, h, w, _ptr(out), _stream()), self.lib)
         return out
 
 

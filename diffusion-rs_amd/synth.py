@@ -205,6 +205,85 @@ def fill_vae_random_device(vae, seed=0, device="cuda", encoder=False):
     return vae
 
 
+# ------------------------------------------------------------------------------- exact synthetic tensors
+# Synthetic tensors that are the SAME BITS wherever they are generated (the build container's CPU, the GPU box's device): a committed
+# fixture computed by the CPU oracle in one place can then be compared with the HIP path in another without shipping 24 GB of weights.
+# Element e of tensor `name` = offset + scale * z_e, z_e = (b0 + b1 + b2 + b3 - 510) / sqrt(21845) from the four bytes of word e of the
+# Philox4x32-10 stream seeded by the tensor's name (integer work: bit-exact on every machine; the sum of four uniform bytes has mean 510,
+# variance 4 (256^2 - 1) / 12 = 21845 and is Gaussian to ~3.4 sigma), evaluated as ONE f32 multiply by f32(scale / sqrt(21845)) and one f32
+# add, then rounded to bf16 (RNE).  The raw words come from the caller: the library's fmi_philox_u32 on the device, the oracle's
+# restatement on the CPU (tests/ only) — tests/test_gpu_philox.py holds them bit-equal.
+EXACT_SALT = 0x46495854  # "FIXT"
+_IH_VAR = 21845.0
+
+
+def exact_seed(name, salt=0):
+    import zlib
+    return (((EXACT_SALT + int(salt)) & 0xFFFFFFFF) << 32) | zlib.crc32(name.encode())
+
+
+def exact_rule(name, shape, family="flux", w_std=0.02, mod_std=0.01):
+    """(offset, scale) of a tensor of the synthetic checkpoint, the rules of flux_state_dict_numpy / vae_state_dict_numpy."""
+    if family == "flux":
+        if name.endswith(("norm_q.weight", "norm_k.weight", "norm_added_q.weight", "norm_added_k.weight")):
+            return 1.0, 0.1
+        if name.endswith(".bias"):
+            return 0.0, 0.02
+        return 0.0, _std_for(name, w_std, mod_std)
+    if family == "vae":
+        if len(shape) in (2, 4):
+            return 0.0, 1.0 / float(np.sqrt(int(np.prod(shape[1:]))))
+        if "norm" in name and name.endswith(".weight"):
+            return 1.0, 0.1
+        return 0.0, (0.1 if "norm" in name else 0.02)
+    if family == "input":  # N(0, 1) activations (latent noise, text embeddings)
+        return 0.0, 1.0
+    raise ValueError(family)
+
+
+def exact_coeff(scale):
+    return np.float32(float(scale) / float(np.sqrt(_IH_VAR)))
+
+
+def exact_values_np(words, offset, scale):
+    """u32 words -> f32 values that are bf16-representable (numpy side of the definition above)."""
+    w = np.ascontiguousarray(words, np.uint32)
+    s = ((w & np.uint32(0xFF)) + ((w >> np.uint32(8)) & np.uint32(0xFF)) + ((w >> np.uint32(16)) & np.uint32(0xFF)) + (w >> np.uint32(24))).astype(np.int32)
+    v = (s - np.int32(510)).astype(np.float32) * exact_coeff(scale)
+    if offset:
+        v = v + np.float32(offset)
+    return to_bf16_f32(v)
+
+
+def exact_tensor_np(name, shape, raw_u32, family="flux", salt=0, **kw):
+    """raw_u32(n, seed) -> (n,) u32 (tests pass the oracle's Philox).  Returns f32 of `shape`, every value bf16-representable."""
+    n = int(np.prod(shape))
+    off, sc = exact_rule(name, shape, family, **kw)
+    return exact_values_np(raw_u32(n, exact_seed(name, salt)), off, sc).reshape(shape)
+
+
+def exact_tensor_device(name, shape, family="flux", salt=0, device="cuda", **kw):
+    """The same tensor on the GPU as bf16: words from fmi_philox_u32, the byte sum / multiply / add as separate torch ops (no contraction)."""
+    import ctypes as C
+    import torch
+    from . import _lib as L
+    lib = L.load()
+    n = 1
+    for d in shape:
+        n *= int(d)
+    off, sc = exact_rule(name, shape, family, **kw)
+    w = torch.empty(n, dtype=torch.int32, device=device)
+    L.check(lib.fmi_philox_u32(C.c_void_p(w.data_ptr()), n, 1, exact_seed(name, salt), 0, None))
+    s = (w & 0xFF) + ((w >> 8) & 0xFF) + ((w >> 16) & 0xFF) + ((w >> 24) & 0xFF)
+    del w
+    v = (s - 510).to(torch.float32)
+    del s
+    v.mul_(float(exact_coeff(sc)))
+    if off:
+        v.add_(float(np.float32(off)))
+    return v.to(torch.bfloat16).reshape(tuple(shape))
+
+
 NF4_CODE = [-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635, -0.18477343022823334,
             -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725, 0.24611230194568634, 0.33791524171829224,
             0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0]

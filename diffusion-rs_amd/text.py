@@ -75,7 +75,7 @@ class T5EncoderModel(_Encoder):
 
     def __init__(self, cfg: dict = None, device: int = 0):
         self.lib = L.load()
-        L.check(self.lib.fmi_init(device))
+        L.check(self.lib.fmi_init(device), self.lib)
         self.device = torch.device("cuda", device)
         cfg = dict(T5_XXL if cfg is None else cfg)
         # `quantization_config` (bitsandbytes nf4 / fp4 / LLM.int8, t5/mod.rs:85-90): the quantised Linears arrive through
@@ -84,7 +84,7 @@ class T5EncoderModel(_Encoder):
         c = L.T5Config(cfg["vocab_size"], cfg["d_model"], cfg["d_kv"], cfg["d_ff"], cfg["num_layers"], cfg["num_heads"], cfg["relative_attention_num_buckets"],
                        cfg.get("relative_attention_max_distance", 128), cfg["layer_norm_epsilon"], _T5_ACT[cfg.get("feed_forward_proj", "relu")])
         h = C.c_void_p()
-        L.check(self.lib.fmi_t5_create(C.byref(c), C.byref(h)))
+        L.check(self.lib.fmi_t5_create(C.byref(c), C.byref(h)), self.lib)
         self.h = h
 
     def tensor_names(self):
@@ -104,14 +104,14 @@ class T5EncoderModel(_Encoder):
         """An LLM.int8 Linear (BnbLinear::Int8, bitsandbytes/mod.rs:104-134): int8 weight (out, in) + f32 SCB (out)."""
         w = weight.to(device=self.device, dtype=torch.int8).contiguous()
         sc = scb.to(device=self.device, dtype=torch.float32).contiguous()
-        L.check(self.lib.fmi_t5_set_linear_int8(self.h, prefix.encode(), _ptr(w), _ptr(sc), int(out_features), int(in_features)))
+        L.check(self.lib.fmi_t5_set_linear_int8(self.h, prefix.encode(), _ptr(w), _ptr(sc), int(out_features), int(in_features)), self.lib)
 
     def forward(self, input_ids, dtype=torch.bfloat16):
         """== T5EncoderModel::forward: ids (B,T) -> hidden states (B,T,d_model) in the model dtype."""
         ids = self._ids(input_ids, self.device)
         B, T = ids.shape
         out = torch.empty((B, T, self.cfg["d_model"]), dtype=dtype, device=self.device)
-        L.check(self.lib.fmi_t5_forward(self.h, _ptr(ids), B, T, _ptr(out), L.BF16 if dtype == torch.bfloat16 else L.F32, _stream()))
+        L.check(self.lib.fmi_t5_forward(self.h, _ptr(ids), B, T, _ptr(out), L.BF16 if dtype == torch.bfloat16 else L.F32, _stream()), self.lib)
         return out
 
 
@@ -120,14 +120,14 @@ class ClipTextTransformer(_Encoder):
 
     def __init__(self, cfg: dict = None, device: int = 0):
         self.lib = L.load()
-        L.check(self.lib.fmi_init(device))
+        L.check(self.lib.fmi_init(device), self.lib)
         self.device = torch.device("cuda", device)
         cfg = dict(CLIP_L if cfg is None else cfg)
         self.cfg = cfg
         c = L.ClipConfig(cfg["vocab_size"], cfg["projection_dim"], cfg["intermediate_size"], cfg["max_position_embeddings"], cfg["num_hidden_layers"],
                          cfg["num_attention_heads"])
         h = C.c_void_p()
-        L.check(self.lib.fmi_clip_create(C.byref(c), C.byref(h)))
+        L.check(self.lib.fmi_clip_create(C.byref(c), C.byref(h)), self.lib)
         self.h = h
 
     def tensor_names(self):
@@ -141,7 +141,7 @@ class ClipTextTransformer(_Encoder):
         D = self.cfg["projection_dim"]
         pooled = torch.empty((B, D), dtype=torch.float32, device=self.device)
         hid = torch.empty((B, T, D), dtype=torch.float32, device=self.device) if return_hidden else None
-        L.check(self.lib.fmi_clip_forward(self.h, _ptr(ids), B, T, _ptr(pooled), L.F32, _ptr(hid) if hid is not None else None, _stream()))
+        L.check(self.lib.fmi_clip_forward(self.h, _ptr(ids), B, T, _ptr(pooled), L.F32, _ptr(hid) if hid is not None else None, _stream()), self.lib)
         return (pooled, hid) if return_hidden else pooled
 
 

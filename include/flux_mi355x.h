@@ -38,9 +38,12 @@ extern "C" {
  * 5 (round 5): + the caller-owned-workspace forms fmi_sdpa_bf16_ws / fmi_sdpa_fp8qk_ws / fmi_linear_fp8_ws / fmi_linear_i8_ws and their size queries;
  *   fmi_sdpa_* / fmi_linear_fp8 / fmi_linear_i8 no longer synchronise the stream or call hipMalloc; + fmi_quantize_rows_i8_asym, fmi_rowsum_i8,
  *   fmi_gemm_i8_asym (the int8 mode's post-GELU operand form); fmi_flux_set_quant_dense_cache accepts -1 (default: by memory) and 3.
- *   + fmi_sdpa_fp8 / fmi_sdpa_fp8_ws (e4m3 P and V as well); fmi_flux_set_fp8_attention accepts 3.
+ *   + fmi_sdpa_fp8 / fmi_sdpa_fp8_ws (e4m3 P and V as well; op-level only: fmi_flux_set_fp8_attention still accepts 0..2).
+ * 6 (round 6): + fmi_release_scratch; + the small f32 seams fmi_timestep_embedding, fmi_rope_table, fmi_rmsnorm_rope.  The op-level entries that use
+ *   the library's per-stream scratch (fmi_sdpa_*, fmi_linear_fp8 / _i8, fmi_groupnorm_nhwc) now enqueue their kernels under one lock: host threads
+ *   may share a stream.
  * Additions only: a host bound against version 3 keeps working. */
-#define FMI_ABI_VERSION 5
+#define FMI_ABI_VERSION 6
 
 typedef enum fmi_status {
   FMI_OK = 0,
@@ -557,6 +560,12 @@ int fmi_sdpa_bf16(const void* q, const void* k, const void* v, void* o, int B, i
  * without ever waiting —; the *_ws forms take it from the caller
  * (fmi_sdpa_workspace_bytes(B, H, Lk) bytes, 16-byte aligned, untouched until the call's work has run on `stream`). */
 size_t fmi_sdpa_workspace_bytes(int B, int H, int Lk);
+/* Threads (ABI 6): an entry that uses the library-held block takes one lock from the moment it picks the block until its last kernel is enqueued, so
+ * host threads that share a stream cannot interleave their launches around it; the block is keyed by (device, stream), NULL and hipStreamLegacy being
+ * one stream and hipStreamPerThread one stream PER calling thread.  fmi_release_scratch returns every such block to the driver: it drains the
+ * devices that hold one first (the only op-level entry that waits; for teardown or memory pressure) and reports the bytes freed
+ * (`freed_bytes` may be NULL).  The next op-level call allocates again. */
+int fmi_release_scratch(size_t* freed_bytes);
 int fmi_sdpa_bf16_ws(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int d, float scale,
                      int out_token_major, void* workspace, size_t workspace_bytes, void* stream);
 /* Process-wide choice of the bf16 attention kernel (test / benchmark hook):
@@ -584,8 +593,9 @@ int fmi_sdpa_fp8qk_ws(const void* q, const void* k, const void* v, void* o, int 
  * second product as e4m3(clamp(v * v_scale, +-448)); the probabilities exp2(s - m) are rounded to e4m3 as they are (the deferred rescale keeps them
  * <= 64), the row sums are taken over the rounded values, and 1 / v_scale leaves with the final normalisation.  Both products run on the
  * K = 128 / K = 64 fp8 MFMA at twice the bf16 rate (attention_w16l_kernel<.., true, true>).  Needs score_exp2 (or a `scale` that is a power of
- * two as above) and Lk > 64 — FMI_ERR_UNSUPPORTED otherwise: no other kernel reads this V^T.  The 8-bit modes' attention when
- * fmi_flux_set_fp8_attention(m, 3).  Workspace: fmi_sdpa_workspace_bytes (half of it is used). */
+ * two as above) and Lk > 64 — FMI_ERR_UNSUPPORTED otherwise: no other kernel reads this V^T.  An OP-LEVEL entry only: the model's 8-bit modes keep
+ * bf16 P and V (the stream is issue-bound, the e4m3 second product buys no time: DESIGN 4.4), and fmi_flux_set_fp8_attention rejects 3.
+ * Workspace: fmi_sdpa_workspace_bytes (half of it is used). */
 int fmi_sdpa_fp8(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int d, float scale, int score_exp2,
                  float v_scale, int out_token_major, void* stream);
 int fmi_sdpa_fp8_ws(const void* q, const void* k, const void* v, void* o, int B, int H, int Lq, int Lk, int d, float scale, int score_exp2,
@@ -595,6 +605,19 @@ int fmi_sdpa_fp8_ws(const void* q, const void* k, const void* v, void* o, int B,
  * scale/shift may be NULL (plain LN). */
 int fmi_layernorm_mod(const float* x, const float* scale, const float* shift, void* out_bf16,
                       int rows, int D, float eps, void* stream);
+/* The small f32 pieces of Flux::forward, one at a time (ABI 6; the kernels the model itself launches):
+ * timestep_embedding (model.rs:104-122): t (B) f32 -> out (B, dim) f32 = [cos(1000 t f_i), sin(1000 t f_i)], f_i = exp(-ln(1e4) i / (dim/2)) in f32. */
+int fmi_timestep_embedding(const float* t, int B, int dim, float* out, void* stream);
+/* EmbedNd / rope (model.rs:65-102, 124-163): ids (B,T,3) and (B,S,3) f32 (either count may be 0) -> pe (B, T+S, sum(axes_dim)/2, 2) f32 = {cos, sin} of
+ * pos * inv_freq, text rows first; inv_freq = 1f32 / f32(theta^(2j/dim) evaluated in f64) as model.rs:71-74.  (The reference materialises the 2x2
+ * rotation [cos, -sin, sin, cos]; this table keeps its two distinct entries.) */
+int fmi_rope_table(const float* txt_ids, const float* img_ids, int B, int T, int S, const int* axes_dim /*[3]*/, int theta, float* pe, void* stream);
+/* QkNorm (RmsNorm over the head dim, eps 1e-6, model.rs:186-209) + apply_rope (model.rs:52-63) in front of the attention: q, k (B, L, ld >= H*128)
+ * bf16 token-major (head h at columns h*128..), weights (128) bf16, pe (B, L, 64, 2) f32 from fmi_rope_table -> q_out, k_out (B, H, L, 128)
+ * head-major, bf16 (out_dtype FMI_BF16: the operands the attention reads; the q|k|v GEMM's fused epilogue produces the same bits) or f32
+ * (FMI_F32: the same arithmetic without the final rounding).  d must be 128; every pointer 16-byte aligned. */
+int fmi_rmsnorm_rope(const void* q, const void* k, int ld, const void* q_weight, const void* k_weight, const float* pe, void* q_out, void* k_out,
+                     int B, int H, int L, int d, fmi_dtype out_dtype, void* stream);
 /* GroupNorm (+optional SiLU) on NHWC bf16 activations, f32 two-pass statistics
  * (nn/group_norm.rs:39-74): x (B,HW,C). */
 int fmi_groupnorm_nhwc(const void* x_bf16, const float* weight, const float* bias, void* out_bf16,

@@ -691,6 +691,67 @@ extern "C" void orc_postprocess_u8(const float* x, int64_t n, uint8_t* out) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Philox4x32-10 raw stream (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123 known-answer vectors pin
+// it, tests/golden/philox_kat.json) with the indexing of the library's fmi_philox_u32 / fmi_randn: element e of sample b = word e % 4 of
+// philox(counter = (q lo, q hi, s lo, s hi), key = (seed lo, seed hi)), q = e / 4, s = first_sample + b.  The reference's get_noise
+// (pipelines/flux/sampling.rs:8-20) is an unseedable randn: the seeded stream is this library's extension.  oracle.py holds the
+// same function in numpy (the independent statement the KATs are checked on); this one exists because the full-size fixtures draw 12e9 words.
+// ---------------------------------------------------------------------------------------
+extern "C" void orc_philox_u32(uint32_t* out, int64_t n_per_sample, int B, uint64_t seed, uint64_t first_sample) {
+  const int64_t quads = (n_per_sample + 3) / 4;
+  for (int b = 0; b < B; ++b) {
+    const uint64_t s = first_sample + (uint64_t)b;
+    uint32_t* o = out + (int64_t)b * n_per_sample;
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < quads; ++q) {
+      uint32_t c0 = (uint32_t)q, c1 = (uint32_t)((uint64_t)q >> 32), c2 = (uint32_t)s, c3 = (uint32_t)(s >> 32);
+      uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+      for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+      }
+      const uint32_t w[4] = {c0, c1, c2, c3};
+      for (int j = 0; j < 4 && 4 * q + j < n_per_sample; ++j) o[4 * q + j] = w[j];
+    }
+  }
+}
+
+static inline void philox_block(uint64_t q, uint64_t s, uint64_t seed, uint32_t w[4]) {
+  uint32_t c0 = (uint32_t)q, c1 = (uint32_t)(q >> 32), c2 = (uint32_t)s, c3 = (uint32_t)(s >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+  w[0] = c0, w[1] = c1, w[2] = c2, w[3] = c3;
+}
+// The "exact synthetic tensor" of diffusion-rs_amd/synth.py (exact_values_np is the definition; tests/test_oracle_philox.py holds this equal to it):
+// value e = bf16_rne(f32(b0 + b1 + b2 + b3 - 510) * coeff [+ offset]) from the four bytes of word e of the stream above (sample 0), as bf16 bits.
+// One pass, no temporaries: the full-size fixtures draw 12e9 of them.
+extern "C" void orc_exact_bf16(uint16_t* out, int64_t n, uint64_t seed, float offset, float coeff) {
+  const int64_t quads = (n + 3) / 4;
+#pragma omp parallel for schedule(static)
+  for (int64_t q = 0; q < quads; ++q) {
+    uint32_t w[4];
+    philox_block((uint64_t)q, 0, seed, w);
+    for (int j = 0; j < 4 && 4 * q + j < n; ++j) {
+      const int sum = (int)(w[j] & 0xFF) + (int)((w[j] >> 8) & 0xFF) + (int)((w[j] >> 16) & 0xFF) + (int)(w[j] >> 24);
+      volatile float v = (float)(sum - 510) * coeff;  // (volatile: the product is rounded to f32 before the add — no fused multiply-add)
+      float r = v;
+      if (offset != 0.f) r = r + offset;
+      uint32_t u;
+      memcpy(&u, &r, 4);
+      u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+      out[4 * q + j] = (uint16_t)u;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) recipe of BASELINE.json configs[4].  PARITY UNPINNED: the reference has no fp8 path
 // ("our recipe; no reference"), so there is no reference file:line to follow and no
 // golden vector; this is the definition the HIP path (csrc/fp8.hip, gemm_pp_kernel<true>) is tested

@@ -51,6 +51,8 @@ void orc_get_timesteps(int num_steps, int use_dynamic_shifting, double mu, doubl
 void orc_pack_latents(const float* latent, int B, int C, int h, int w, float* img, float* img_ids);
 void orc_unpack_latents(const float* img, int B, int C, int h, int w, float* out);
 void orc_postprocess_u8(const float* x, int64_t n, uint8_t* out);
+void orc_exact_bf16(uint16_t* out, int64_t n, uint64_t seed, float offset, float coeff);
+void orc_philox_u32(uint32_t* out, int64_t n_per_sample, int B, uint64_t seed, uint64_t first_sample);
 
 /* ---- FLUX model ---- */
 typedef struct orc_flux orc_flux;

@@ -429,6 +429,23 @@ def philox_u32(n_per_sample, B, seed, first_sample=0):
     return out[:, :n_per_sample]
 
 
+def philox_u32_c(n_per_sample, B, seed, first_sample=0):
+    """The same stream from the C restatement (flux_oracle.cpp: orc_philox_u32; OpenMP): what the full-size fixtures draw their 12e9 words from.
+    tests/test_oracle_philox.py holds it equal to the numpy statement above."""
+    out = np.empty((B, n_per_sample), np.uint32)
+    lib().orc_philox_u32(out.ctypes.data_as(C.c_void_p), C.c_int64(n_per_sample), C.c_int(B), C.c_uint64(seed), C.c_uint64(first_sample))
+    return out
+
+
+def exact_bf16(n, seed, offset, coeff, out=None):
+    """bf16 bits of an "exact synthetic tensor" (diffusion-rs_amd/synth.py: exact_values_np is the definition) in one C pass; `out` = a reusable
+    uint16 buffer of >= n elements."""
+    if out is None:
+        out = np.empty(n, np.uint16)
+    lib().orc_exact_bf16(out.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_uint64(seed), C.c_float(float(offset)), C.c_float(float(coeff)))
+    return out[:n]
+
+
 def randn(n_per_sample, B, seed, first_sample=0):
     """N(0,1) f32 (B, n_per_sample): per counter, words (0,1) and (2,3) each give a Box-Muller pair.
     u = f32(f32(w >> 8) + 0.5f) * 2^-24 with the device's f32 roundings (for w >> 8 >= 2^23 the + 0.5 rounds to even:

@@ -27,7 +27,7 @@ def test_library_exports_every_header_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert set(L.EXPORTED) == declared
-    assert lib.fmi_abi_version() == 5
+    assert lib.fmi_abi_version() == 6
 
 
 def test_product_and_test_build_of_the_library():
@@ -251,7 +251,7 @@ def test_bench_as_rank_hook_is_validated():
 
 
 def test_committed_attention_streams_are_what_their_generators_emit(tmp_path):
-    """The six generated instruction streams under csrc/ (`*_loop.inc`: the hand-scheduled KV loops of the attention kernels) are committed
+    """The seven generated instruction streams under csrc/ (`*_loop.inc`: the hand-scheduled KV loops of the attention kernels) are committed
     files; each must be byte for byte what its generator in tools/ emits — a stream edited by hand, or a generator changed without
     regenerating, would otherwise ship unnoticed (the generators also assert their own invariants — rule 3, read order, wait counts — while
     they run).  The generators write relative to their own location, so they run from a scratch copy of tools/."""
@@ -262,7 +262,8 @@ def test_committed_attention_streams_are_what_their_generators_emit(tmp_path):
     (tmp_path / "diffusion-rs_amd" / "csrc").mkdir(parents=True)
     jobs = [("gen_attention_w4_loop.py", {}, "attention_w4_loop.inc"), ("gen_attention_w16.py", {}, "attention_w16_loop.inc"),
             ("gen_attention_w16.py", {"AW16_MODE": "fp8qk"}, "attention_w16f8_loop.inc"), ("gen_attention_w32.py", {}, "attention_w32_loop.inc"),
-            ("gen_attention_w16l.py", {}, "attention_w16l_loop.inc"), ("gen_attention_w16l.py", {"AW16L_MODE": "fp8qk"}, "attention_w16lf8_loop.inc")]
+            ("gen_attention_w16l.py", {}, "attention_w16l_loop.inc"), ("gen_attention_w16l.py", {"AW16L_MODE": "fp8qk"}, "attention_w16lf8_loop.inc"),
+            ("gen_attention_w16l.py", {"AW16L_MODE": "fp8pv"}, "attention_w16lf8pv_loop.inc")]
     for gen, env, out in jobs:
         shutil.copy(os.path.join(ROOT, "tools", gen), tmp_path / "tools" / gen)
         clean = {k: v for k, v in os.environ.items() if not k.startswith(("AW16", "AW32", "AW4"))}
@@ -280,7 +281,9 @@ def test_no_entry_point_of_the_op_seam_synchronises_or_allocates_in_source():
     import re
     src = open(os.path.join(ROOT, "diffusion-rs_amd", "csrc", "capi.hip")).read()
     code = re.sub(r"//[^\n]*", "", src)
-    assert len(re.findall(r"\bhipStreamSynchronize\s*\(", code)) == 1 and "hipDeviceSynchronize" not in code
+    assert len(re.findall(r"\bhipStreamSynchronize\s*\(", code)) == 1
+    # the one hipDeviceSynchronize is fmi_release_scratch's (ABI 6: blocks go back to the driver only behind a drained device), in front of the op entries
+    assert code.count("hipDeviceSynchronize") == 1 and code.index("hipDeviceSynchronize") < code.index('extern "C" size_t fmi_linear_q8_workspace_bytes')
     assert len(re.findall(r"\bhipMalloc\s*\(", code)) == 2
     ops = code[code.index('extern "C" size_t fmi_linear_q8_workspace_bytes'):code.index('extern "C" int fmi_set_attention_kernel')]
     for banned in ("hipMalloc", "hipFree", "Synchronize", "hipMemcpy("):
