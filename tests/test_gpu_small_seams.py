@@ -1,0 +1,238 @@
+"""The small f32 pieces of `Flux::forward` as op-level seams (ABI 6; SURVEY 8(b)'s proposal, VERDICT r5 "missing" 4): rows a10 / a11 / a15 / a16 of
+SURVEY 8(a) compared with the oracle ONE AT A TIME at f32 precision, instead of only through a bf16 model output with a 2e-3 tolerance.
+
+* fmi_timestep_embedding  vs orc_timestep_embedding (model.rs:104-122)
+* fmi_rope_table          vs orc_rope_table (EmbedNd / rope, model.rs:65-102, 124-163)
+* fmi_rmsnorm_rope        vs orc_rms_norm_slow (QkNorm, model.rs:186-209) + orc_apply_rope (model.rs:52-63), f32 result; and its bf16 result
+  (the operands the attention reads: the kernel the q|k|v GEMM's fused epilogue is held bit-identical to) = the f32 result rounded once.
+
+Also here: the library-held op scratch under two host threads that share ONE stream, hipStreamPerThread, and
+fmi_release_scratch.
+
+Bars: every output is an f32 evaluation of a few operations on f32 inputs, so the bar is a few f32 ulps of the result — stated per test together
+with the one place where conditioning matters (cos / sin of an angle of ~1000 rad amplifies one ulp of the frequency to 6e-5).
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from tests.util import bf16_round, dev, host, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from diffusion_rs_amd import _lib as L
+    from oracle import oracle as orc
+    lib = L.load()
+    L.check(lib.fmi_init(0))
+    return dict(torch=torch, L=L, lib=lib, orc=orc)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def test_timestep_embedding_matches_oracle_at_f32(env):
+    torch, L, lib, orc = (env[k] for k in ("torch", "L", "lib", "orc"))
+    # the 51 timesteps of the headline schedule, the guidance values a host passes (the guidance embedder reads the same function), 0 and 1
+    ts = np.array(list(orc.get_timesteps(50, True, orc.calculate_shift(4096), 1.0)) + [3.5, 1.0, 0.0, 7.0, 1e-3], np.float32)
+    for dim in (256, 64):
+        out = torch.full((len(ts), dim), float("nan"), device="cuda")
+        L.check(lib.fmi_timestep_embedding(_p(dev(ts)), len(ts), dim, _p(out), None))
+        got, ref = host(out), orc.timestep_embedding(ts, dim)
+        # |d cos(a)| <= |da|: the angle a = 1000 t f_i carries the f32 roundings of exp() (<= 1 ulp here and in glibc), of i * c and of the product:
+        # 3 ulps of an angle of up to 7000 rad; the cos / sin evaluations themselves are good to ~1e-7
+        half = dim // 2
+        freq = np.exp(-np.log(10000.0) * np.arange(half) / half)
+        ang = np.abs(1000.0 * ts[:, None] * freq[None, :])
+        bound = 1e-6 + 3 * 2.0 ** -23 * np.concatenate([ang, ang], 1)
+        err = np.abs(got - ref)
+        print(f"timestep_embedding dim {dim}: max |d| {err.max():.2e} (bound there {bound.flat[err.argmax()]:.2e}); rows with t <= 1: max {err[:53].max():.2e}; rel-L2 {rel_l2(got, ref):.2e}")
+        assert np.isfinite(got).all() and (err <= bound).all()
+        assert rel_l2(got, ref) <= 2e-5
+    assert lib.fmi_timestep_embedding(_p(dev(ts)), len(ts), 255, _p(out), None) == -1  # odd dim
+
+
+def test_rope_table_matches_oracle_at_f32(env):
+    torch, L, lib, orc = (env[k] for k in ("torch", "L", "lib", "orc"))
+    axes = (C.c_int * 3)(16, 56, 56)
+    rng = np.random.default_rng(11)
+    for B, T, (h2, w2) in ((1, 512, (64, 64)), (2, 7, (45, 80)), (1, 0, (5, 3))):
+        S = h2 * w2
+        img_ids = np.zeros((B, S, 3), np.float32)
+        img_ids[:, :, 1] = np.repeat(np.arange(h2), w2)[None]
+        img_ids[:, :, 2] = np.tile(np.arange(w2), h2)[None]
+        txt_ids = np.zeros((B, T, 3), np.float32)
+        if B == 2:  # ids the reference never produces but the function must handle: non-integer positions, a non-zero first axis, per-sample ids
+            img_ids[1] += rng.uniform(0, 3, (S, 3)).astype(np.float32)
+            txt_ids[1, :, 0] = 2.0
+        pe = torch.full((B, T + S, 64, 2), float("nan"), device="cuda")
+        L.check(lib.fmi_rope_table(_p(dev(txt_ids)) if T else None, _p(dev(img_ids)), B, T, S, axes, 10000, _p(pe), None))
+        got = host(pe)
+        ref4 = orc.rope_table(np.concatenate([txt_ids, img_ids], 1), [16, 56, 56], 10000)  # (B, L, 64, 2, 2) = [[cos, -sin], [sin, cos]]
+        ref = np.stack([ref4[..., 0, 0], ref4[..., 1, 0]], -1)
+        assert np.array_equal(ref4[..., 0, 1], -ref4[..., 1, 0]) and np.array_equal(ref4[..., 1, 1], ref4[..., 0, 0])
+        err = np.abs(got - ref)
+        # angle = pos * inv_freq <= 83 rad (one f32 product of identical inputs on both sides unless pow() differs in its last f64 bit): cos / sin to a few 1e-7
+        print(f"rope_table B={B} T={T} S={S}: max |d| {err.max():.2e}, rel-L2 {rel_l2(got, ref):.2e}")
+        assert np.isfinite(got).all() and err.max() <= 1e-6
+    assert lib.fmi_rope_table(None, None, 1, 0, 0, axes, 10000, _p(pe), None) == -1  # empty
+
+
+@pytest.mark.parametrize("B,H,L,ld", [(1, 24, 4608, 24 * 128), (2, 3, 100, 9 * 128 + 64), (1, 24, 4112, 24 * 128)])
+def test_rmsnorm_rope_matches_oracle_at_f32_and_bf16_is_its_single_rounding(env, B, H, L, ld):
+    torch, Lb, lib, orc = (env[k] for k in ("torch", "L", "lib", "orc"))
+    rng = np.random.default_rng(B * 1000 + L)
+    q = bf16_round(rng.standard_normal((B, L, ld)).astype(np.float32) * (10.0 ** rng.uniform(-2, 1, (B, L, 1))).astype(np.float32))
+    k = bf16_round(rng.standard_normal((B, L, ld)).astype(np.float32))
+    q[0, 1, :128] = 0.0  # an all-zero head row: rsqrt(eps) * 0
+    wq = bf16_round((1.0 + 0.1 * rng.standard_normal(128)).astype(np.float32))
+    wk = bf16_round((1.0 + 0.1 * rng.standard_normal(128)).astype(np.float32))
+    ids = np.zeros((B, L, 3), np.float32)
+    ids[:, :, 1] = (np.arange(L) // 64)[None]
+    ids[:, :, 2] = (np.arange(L) % 80)[None]
+    axes = (C.c_int * 3)(16, 56, 56)
+    pe = torch.empty((B, L, 64, 2), device="cuda")
+    Lb.check(lib.fmi_rope_table(None, _p(dev(ids)), B, 0, L, axes, 10000, _p(pe), None))
+    qd, kd, wqd, wkd = dev(q, torch.bfloat16), dev(k, torch.bfloat16), dev(wq, torch.bfloat16), dev(wk, torch.bfloat16)
+    of = [torch.full((B, H, L, 128), float("nan"), device="cuda") for _ in range(2)]
+    ob = [torch.full((B, H, L, 128), float("nan"), device="cuda", dtype=torch.bfloat16) for _ in range(2)]
+    Lb.check(lib.fmi_rmsnorm_rope(_p(qd), _p(kd), ld, _p(wqd), _p(wkd), _p(pe), _p(of[0]), _p(of[1]), B, H, L, 128, 0, None))  # FMI_F32
+    Lb.check(lib.fmi_rmsnorm_rope(_p(qd), _p(kd), ld, _p(wqd), _p(wkd), _p(pe), _p(ob[0]), _p(ob[1]), B, H, L, 128, 2, None))  # FMI_BF16
+    torch.cuda.synchronize()
+    pe4 = orc.rope_table(ids, [16, 56, 56], 10000)
+    n_flip = 0
+    for which, (x, w) in enumerate(((q, wq), (k, wk))):
+        got = host(of[which])
+        assert np.isfinite(got).all()
+        # the bf16 form = the f32 form rounded once (same kernel, same arithmetic)
+        assert np.array_equal(host(ob[which]), bf16_round(got))
+        worst = 0.0
+        for b in range(B):
+            xh = x[b, :, :H * 128].reshape(L, H, 128).transpose(1, 0, 2)  # (H, L, 128)
+            ref = orc.apply_rope(orc.rms_norm_slow(xh, w, 1e-6), pe4[b])
+            e = rel_l2(got[b], ref)
+            worst = max(worst, e)
+            # v_rsq_f32 (1 ulp) against sqrt + divide, fused multiply-adds against separate roundings: a few f32 ulps of the row's scale
+            assert e <= 1e-6, (which, b, e)
+            assert np.abs(got[b] - ref).max() <= 4e-6 * max(1.0, float(np.abs(ref).max()))
+            n_flip += int((bf16_round(ref) != host(ob[which])[b]).sum())
+        print(f"rmsnorm_rope {'qk'[which]} B={B} H={H} L={L} ld={ld}: f32 rel-L2 vs oracle {worst:.2e}")
+    frac = n_flip / (2 * B * H * L * 128)
+    print(f"  bf16 result vs bf16(oracle): {n_flip} of {2 * B * H * L * 128} values differ ({frac:.2e}) — f32 values within an ulp of a bf16 rounding boundary")
+    assert frac <= 2e-4
+    # argument checks
+    assert lib.fmi_rmsnorm_rope(_p(qd), _p(kd), ld, _p(wqd), _p(wkd), _p(pe), _p(of[0]), _p(of[1]), B, H, L, 64, 0, None) == -4
+    assert lib.fmi_rmsnorm_rope(_p(qd), _p(kd), H * 128 - 8, _p(wqd), _p(wkd), _p(pe), _p(of[0]), _p(of[1]), B, H, L, 128, 0, None) == -1
+    assert lib.fmi_rmsnorm_rope(_p(qd), _p(kd), ld, _p(wqd), _p(wkd), _p(pe), _p(of[0]), _p(of[1]), B, H, L, 128, 1, None) == -1  # f16 output: not offered
+
+
+def _sdpa_case(torch, seed, B, H, L):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    mk = lambda: torch.randn(B, H, L, 128, device="cuda", generator=g).to(torch.bfloat16)
+    return mk(), mk(), mk()
+
+
+def test_two_host_threads_share_one_stream_and_the_op_scratch(env):
+    """the plain op-level forms keep ONE scratch block per (device, stream); each call enqueues two kernels (build V^T in the
+    block, then the attention that reads it).  Two host threads calling on the SAME stream must not interleave those pairs — the block is
+    taken and both kernels are enqueued under one lock (ABI 6).  Here: two threads, different problems (so a mixed-up V^T is a wrong
+    result, not a coincidence), 200 calls each on the null stream, every output bit-identical to the single-threaded answer."""
+    torch, L, lib = env["torch"], env["L"], env["lib"]
+    scale = 1.0 / 128 ** 0.5
+    cases = [_sdpa_case(torch, 1, 1, 4, 640), _sdpa_case(torch, 2, 1, 4, 1088)]
+    refs = []
+    for q, k, v in cases:
+        o = torch.empty(q.shape[0], q.shape[2], q.shape[1] * 128, device="cuda", dtype=torch.bfloat16)
+        L.check(lib.fmi_sdpa_bf16(_p(q), _p(k), _p(v), _p(o), q.shape[0], q.shape[1], q.shape[2], q.shape[2], 128, scale, 1, None))
+        torch.cuda.synchronize()
+        refs.append(o.clone())
+    n_calls = 200
+    outs = [[torch.empty_like(refs[i]) for _ in range(n_calls)] for i in range(2)]
+    errs = []
+    start = threading.Barrier(2)
+
+    def run(i):
+        try:
+            q, k, v = cases[i]
+            start.wait()
+            for j in range(n_calls):
+                rc = lib.fmi_sdpa_bf16(_p(q), _p(k), _p(v), _p(outs[i][j]), q.shape[0], q.shape[1], q.shape[2], q.shape[2], 128, scale, 1, None)
+                if rc:
+                    errs.append((i, j, rc, lib.fmi_last_error()))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    assert not errs, errs[:3]
+    bad = [(i, j) for i in range(2) for j in range(n_calls) if not torch.equal(outs[i][j], refs[i])]
+    print(f"2 threads x {n_calls} fmi_sdpa_bf16 calls on the null stream, two problem sizes: {len(bad)} results differ from the single-threaded ones")
+    assert not bad, bad[:5]
+
+
+def test_stream_per_thread_gets_a_block_per_thread_and_release_scratch_returns_them(env):
+    torch, L, lib = env["torch"], env["L"], env["lib"]
+    scale = 1.0 / 128 ** 0.5
+    HIP_STREAM_PER_THREAD = C.c_void_p(2)
+    cases = [_sdpa_case(torch, 3, 1, 2, 512), _sdpa_case(torch, 4, 1, 2, 960)]
+    refs = []
+    for q, k, v in cases:
+        o = torch.empty(1, q.shape[2], 2 * 128, device="cuda", dtype=torch.bfloat16)
+        L.check(lib.fmi_sdpa_bf16(_p(q), _p(k), _p(v), _p(o), 1, 2, q.shape[2], q.shape[2], 128, scale, 1, None))
+        torch.cuda.synchronize()
+        refs.append(o.clone())
+    outs = [[torch.empty_like(refs[i]) for _ in range(50)] for i in range(2)]
+    errs = []
+
+    def run(i):
+        q, k, v = cases[i]
+        for j in range(50):
+            rc = lib.fmi_sdpa_bf16(_p(q), _p(k), _p(v), _p(outs[i][j]), 1, 2, q.shape[2], q.shape[2], 128, scale, 1, HIP_STREAM_PER_THREAD)
+            if rc:
+                errs.append((i, j, rc))
+                return
+        lib.fmi_stream_synchronize(HIP_STREAM_PER_THREAD)
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert all(torch.equal(outs[i][j], refs[i]) for i in range(2) for j in range(50))
+    # release: everything back (at least the null stream's block and the two per-thread blocks: >= 3 MiB), then the next call simply allocates again
+    freed = C.c_size_t(0)
+    L.check(lib.fmi_release_scratch(C.byref(freed)))
+    print(f"fmi_release_scratch freed {freed.value / 2**20:.1f} MiB")
+    assert freed.value >= 3 << 20
+    L.check(lib.fmi_release_scratch(C.byref(freed)))
+    assert freed.value == 0
+    q, k, v = cases[0]
+    o = torch.empty_like(refs[0])
+    L.check(lib.fmi_sdpa_bf16(_p(q), _p(k), _p(v), _p(o), 1, 2, q.shape[2], q.shape[2], 128, scale, 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(o, refs[0])
+
+
+def test_exact_synthetic_tensors_are_the_same_bits_on_the_device_and_on_the_cpu(env):
+    """diffusion-rs_amd/synth.py "exact synthetic tensors": what lets the committed full-size fixtures (tests/golden/c2_trajectory.npz) be compared with
+    the HIP path on another machine — the GPU regenerates the checkpoint from fmi_philox_u32, the fixture was computed from the oracle's Philox."""
+    torch, orc = env["torch"], env["orc"]
+    import diffusion_rs_amd as d
+    S = d.synth
+    raw = lambda n, seed: orc.philox_u32_c(n, 1, seed)[0]
+    for name, shape, fam in (("transformer_blocks.3.attn.to_q.weight", (3072, 3072), "flux"), ("transformer_blocks.3.attn.norm_q.weight", (128,), "flux"),
+                             ("single_transformer_blocks.5.norm.linear.weight", (9216, 3072), "flux"), ("x_embedder.bias", (3072,), "flux"),
+                             ("decoder.conv_in.weight", (512, 16, 3, 3), "vae"), ("decoder.conv_norm_out.weight", (128,), "vae"), ("input.c2.t5", (1, 512, 4096), "input")):
+        a = S.exact_tensor_np(name, shape, raw, fam)
+        g = S.exact_tensor_device(name, shape, fam)
+        assert g.dtype == torch.bfloat16 and tuple(g.shape) == tuple(shape)
+        assert np.array_equal(host(g), a), name

@@ -98,10 +98,11 @@ MASK_BITS = ["double q|k|v", "double attention out", "double MLP in", "double ML
 
 
 def mask_table(om, inputs, ref, masks, mode=5, attention=False):
-    """The int8 recipe (mode 5) on a SUBSET of the block linears (orc_flux_set_q8_mask): which linears carry the error?"""
+    """An 8-bit recipe (mode 5 = int8, 1 = e4m3 per row, ...) on a SUBSET of the block linears (orc_flux_set_q8_mask): which linears carry the error?"""
     img, ids, txt, txt_ids, t, y, g = inputs
     om.set_fp8(True, attention=attention, study_mode=mode)
-    print(f"int8 per row (W and A) on a subset of the block linears{' + e4m3 q, k in the attention (static scales)' if attention else ''}{', e4m3 P and V too' if attention == 2 else ''}; rel-L2 vs f32:")
+    recipe = dict(MODES).get(mode, {7: "int8 per row, one scale per segment of linear2's input"}.get(mode, f"study mode {mode}"))
+    print(f"{recipe} on a subset of the block linears{' + e4m3 q, k in the attention (static scales)' if attention else ''}{', e4m3 P and V too' if attention == 2 else ''}; rel-L2 vs f32:")
     for mask in masks:
         om.set_q8_mask(mask)
         out = om.forward(img, ids, txt, txt_ids, t, y, g)
