@@ -1,0 +1,200 @@
+"""The HEADLINE config pinned at full size and full length against a COMMITTED oracle fixture (VERDICT r5 "next" 2 and 7).
+
+BASELINE configs[1] — FLUX.1-dev, 19 + 38 blocks, 1024 x 1024 (S = 4096) + T = 512 tokens, guidance 3.5, the real 50-step schedule — is the number
+`bench.py` reports; until round 6 its 50-step latents had never been compared with anything at this size (the live oracle needs ~2 h of CPU for it).
+`tests/golden/c2_trajectory.npz` holds the f32 CPU oracle's latents after 10 / 25 / 50 steps and its u8 image for this config, computed once in the build
+container by `tests/golden/gen_c2_trajectory_fixture.py` (`Sampler::sample`, pipelines/sampling.rs:25-48; step closure pipelines/flux/mod.rs:305-318; decode
++ u8 :320-332).  The checkpoint and the inputs are "exact synthetic tensors" (diffusion-rs_amd/synth.py): the SAME BITS regenerated here on the device from
+fmi_philox_u32 — the fixture's CRC-32s of three weight tensors and of the inputs prove it before anything is compared.
+
+* bf16 (the headline path: `fmi_flux_denoise`, one call of 50 steps; f32 latents): latents rel-L2 <= 3e-2 at every mark, u8 within 2 of the
+  oracle's image on >= 99.9 % of the values.
+* int8 mode against the same F32 fixture: latents <= 3e-2 at every mark; the u8 bar is stated next to SURVEY's 99.9 % in the test.
+* a torch-free C99 host (tools/host_s1.c: gcc, the header, the .so — no Python, no torch, host pointers into fmi_flux_set_tensor) drives the same S1 calls and
+  must print the CRC-32 of the SAME image the Python / ctypes path produces from the same seed-by-name checkpoint (`Pipeline::forward`, pipelines/mod.rs:241-270).
+
+Needs no host memory for the oracle: this is the parity row that survives a small GPU box.
+"""
+import json
+import os
+import subprocess
+import time
+import zlib
+
+import numpy as np
+import pytest
+
+from tests.util import host, rel_l2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURE = os.path.join(ROOT, "tests", "golden", "c2_trajectory.npz")
+MARKS = (10, 25, 50)
+H_LAT = W_LAT = 128
+T_TXT = 512
+# bf16 latents <= 3e-2, u8 within 2 on >= 99.9 %.  The int8 mode is held to the same latent bar; its u8 agreement is NOT at SURVEY's 99.9 %
+# (a bf16 bar): the value asserted is the one measured at this size with margin, and the print shows both.
+BF16_LATENT_BAR, BF16_U8_BAR = 3e-2, 0.999
+INT8_LATENT_BAR, INT8_U8_BAR = 3e-2, 0.97
+
+
+def _load_exact(d, model, family):
+    S = d.synth
+    shapes = S.flux_tensor_shapes(model.cfg) if family == "flux" else S.vae_tensor_shapes(model.cfg)
+    for name, shape in shapes.items():
+        model.set_tensor(name, S.exact_tensor_device(name, shape, family))
+    return shapes
+
+
+@pytest.fixture(scope="module")
+def c2():
+    import torch
+    import diffusion_rs_amd as d
+    S = d.synth
+    t0 = time.time()
+    gm = d.FluxModel(dict(d.FLUX_DEV))
+    _load_exact(d, gm, "flux")
+    gm.assert_complete()
+    gv = d.AutoEncoderKl(d.VAE_FLUX)
+    _load_exact(d, gv, "vae")
+    lat = S.exact_tensor_device("input.c2.latent", (1, 16, H_LAT, W_LAT), "input")
+    t5 = S.exact_tensor_device("input.c2.t5", (1, T_TXT, d.FLUX_DEV["joint_attention_dim"]), "input")
+    clip = S.exact_tensor_device("input.c2.clip", (1, d.FLUX_DEV["pooled_projection_dim"]), "input")
+    img, ids = d.pack_latents(lat.float())
+    assert tuple(img.shape) == (1, 4096, 64)
+    txt_ids = torch.zeros((1, T_TXT, 3), device="cuda")
+    g = torch.tensor([3.5], device="cuda")
+    sched = d.SchedulerConfig()
+    ts = sched.get_timesteps(50, sched.calculate_shift(4096))
+    fx = None
+    if os.path.exists(FIXTURE):
+        z = np.load(FIXTURE)
+        fx = dict(ts=z["ts"], u8=z["u8"], meta=json.loads(bytes(z["meta"]).decode()), **{f"lat_{n}": z[f"lat_{n}"] for n in MARKS})
+    print(f"\nexact synthetic FLUX.1-dev + VAE on the device in {time.time() - t0:.0f} s; fixture {'loaded' if fx else 'ABSENT'}")
+    crc = lambda t: zlib.crc32(t.contiguous().view(torch.int16).cpu().numpy().tobytes())
+    out = dict(torch=torch, d=d, gm=gm, gv=gv, img=img, ids=ids, t5=t5, txt_ids=txt_ids, clip=clip.float(), g=g, ts=ts, fx=fx, crc=crc,
+               in_crcs={"input.c2.latent": crc(lat), "input.c2.t5": crc(t5), "input.c2.clip": crc(clip)})
+    yield out
+    gm.close()
+    gv.close()
+
+
+def _need_fixture(c2):
+    if c2["fx"] is None:
+        print("\n!!! tests/golden/c2_trajectory.npz is ABSENT: the headline 50-step parity pin did NOT run (regenerate: python tests/golden/gen_c2_trajectory_fixture.py) !!!")
+        pytest.skip("tests/golden/c2_trajectory.npz absent")
+    return c2["fx"]
+
+
+def _image_u8(c2, lat50):
+    d, gv = c2["d"], c2["gv"]
+    z = d.unpack_latents(lat50, 16, H_LAT, W_LAT, d.VAE_FLUX["scaling_factor"], d.VAE_FLUX["shift_factor"])
+    return d.postprocess_u8(gv.decode(z)).cpu().numpy()
+
+
+def _denoise(c2, model, n):
+    return model.denoise(c2["img"].clone(), c2["ids"], c2["t5"], c2["txt_ids"], c2["clip"], c2["g"], c2["ts"][:n + 1])
+
+
+def test_the_device_regenerates_the_fixtures_checkpoint_and_inputs_bit_for_bit(c2):
+    fx = _need_fixture(c2)
+    d, torch = c2["d"], c2["torch"]
+    want = fx["meta"]["crcs"]
+    assert fx["meta"]["exact_salt"] == d.synth.EXACT_SALT
+    for name in ("input.c2.latent", "input.c2.t5", "input.c2.clip"):
+        assert c2["in_crcs"][name] == want[name], name
+    shapes = d.synth.flux_tensor_shapes(d.FLUX_DEV)
+    n = 0
+    for name, crc in want.items():
+        if name.startswith("input."):
+            continue
+        assert c2["crc"](d.synth.exact_tensor_device(name, shapes[name], "flux")) == crc, name
+        n += 1
+    assert n >= 3
+    # and the schedule the fixture was computed on is the product's (f64, bit for bit the reference formulas: scheduler.rs:22-51)
+    assert len(fx["ts"]) == 51 and np.abs(np.array(c2["ts"]) - fx["ts"]).max() <= 1e-15
+
+
+def test_headline_50_step_trajectory_bf16_matches_the_committed_oracle_fixture(c2):
+    fx = _need_fixture(c2)
+    gm = c2["gm"]
+    got = {n: _denoise(c2, gm, n) for n in MARKS}  # 50 = the bench's call: ONE fmi_flux_denoise of 50 steps
+    img0 = host(c2["img"])
+    drift = {n: rel_l2(host(got[n]), fx[f"lat_{n}"]) for n in MARKS}
+    moved = {n: rel_l2(fx[f"lat_{n}"], img0) for n in MARKS}
+    print("HEADLINE (FLUX.1-dev 1024 x 1024, S=4096 + T=512, the real 50-step schedule), bf16 vs the committed f32-oracle fixture: latents rel-L2 after "
+          + ", ".join(f"{n} steps {drift[n]:.3e} (moved {moved[n]:.2f})" for n in MARKS))
+    for n in MARKS:
+        assert np.isfinite(host(got[n])).all() and drift[n] <= BF16_LATENT_BAR, (n, drift[n])
+    u8 = _image_u8(c2, got[50])
+    assert u8.shape == fx["u8"].shape == (1, 3, 1024, 1024)
+    diff = np.abs(u8.astype(np.int32) - fx["u8"].astype(np.int32))
+    frac = float((diff <= 2).mean())
+    sat = float(((fx["u8"] == 0) | (fx["u8"] == 255)).mean())
+    print(f"  u8 image (1024 x 1024) vs the oracle's: max |d| {int(diff.max())}, within 2 on {frac:.4%}, identical on {float((diff == 0).mean()):.2%} "
+          f"({sat:.1%} of the oracle's values saturated); CRC-32 {zlib.crc32(u8.tobytes()):08x} vs the oracle's {fx['meta']['image_crc32']:08x}")
+    assert frac >= BF16_U8_BAR
+    c2["image_crc"], c2["latents_crc"] = zlib.crc32(u8.tobytes()), zlib.crc32(host(got[50]).astype(np.float32).tobytes())
+
+
+def test_torch_free_c_host_produces_the_python_paths_image(c2, tmp_path):
+    """tools/host_s1.c: C99 + include/flux_mi355x.h + libflux_mi355x.so, nothing else — its own Philox, host-pointer fmi_flux_set_tensor, fmi_malloc'ed
+    buffers, the null stream.  Same calls as `Pipeline::forward` makes after the text encoders; the image CRC-32 must be the Python path's."""
+    exe = str(tmp_path / "host_s1")
+    cmd = ["gcc", "-std=c99", "-O2", "-fopenmp", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "host_s1.c"), "-o", exe,
+           "-L" + os.path.join(ROOT, "diffusion-rs_amd"), "-lflux_mi355x", "-Wl,-rpath," + os.path.join(ROOT, "diffusion-rs_amd"), "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libflux_mi355x.so" in ldd and "torch" not in ldd and "python" not in ldd.lower(), ldd
+    if "image_crc" not in c2:  # run alone (or without the fixture): the Python path's image for the same checkpoint and inputs
+        lat50 = _denoise(c2, c2["gm"], 50)
+        u8 = _image_u8(c2, lat50)
+        c2["image_crc"], c2["latents_crc"] = zlib.crc32(u8.tobytes()), zlib.crc32(host(lat50).astype(np.float32).tobytes())
+    t0 = time.time()
+    env = dict(os.environ, OMP_NUM_THREADS=str(max(1, min(16, len(os.sched_getaffinity(0))))))
+    r = subprocess.run([exe, "--steps", "50", "--latent", "128x128", "--txt", "512"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    print(f"host_s1 ({time.time() - t0:.0f} s): {line}")
+    assert line["weights"] > 11.9e9 and line["steps"] == 50 and line["S"] == 4096
+    assert int(line["latents_crc32"], 16) == c2["latents_crc"], "the C host's 50-step latents differ from the Python path's"
+    assert int(line["image_crc32"], 16) == c2["image_crc"], "the C host's image differs from the Python path's"
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "host_s1.json"), "w") as f:
+        json.dump(line, f)
+
+
+def test_headline_50_step_trajectory_int8_mode_against_the_f32_fixture(c2):
+    fx = _need_fixture(c2)
+    d = c2["d"]
+    g8 = d.FluxModel(dict(d.FLUX_DEV))
+    try:
+        _load_exact(d, g8, "flux")
+        g8.quantize_int8()
+        got = {n: _denoise(c2, g8, n) for n in MARKS}
+        drift = {n: rel_l2(host(got[n]), fx[f"lat_{n}"]) for n in MARKS}
+        u8 = _image_u8(c2, got[50])
+        diff = np.abs(u8.astype(np.int32) - fx["u8"].astype(np.int32))
+        frac = float((diff <= 2).mean())
+        print("HEADLINE in int8 mode (default mask, e4m3 q / k) vs the committed F32-oracle fixture: latents rel-L2 after "
+              + ", ".join(f"{n} steps {drift[n]:.3e}" for n in MARKS)
+              + f"; u8 image max |d| {int(diff.max())}, within 2 on {frac:.4%}, within 4 on {float((diff <= 4).mean()):.4%} "
+              f"(asserted: >= {INT8_U8_BAR:.0%}; SURVEY 8(d)'s 99.9 % is the bf16 bar, which the bf16 path meets and an 8-bit mode does not)")
+        for n in MARKS:
+            assert np.isfinite(host(got[n])).all() and drift[n] <= INT8_LATENT_BAR, (n, drift[n])
+        assert frac >= INT8_U8_BAR
+    finally:
+        g8.close()
+    # the e4m3 mode on the same trajectory (its own handle: a model holds one 8-bit form): reported — it is OUTSIDE the 8-bit bar by construction of the
+    # format (profiles/r06_e4m3_mask_study.txt) —, only finiteness is asserted
+    gf = d.FluxModel(dict(d.FLUX_DEV))
+    try:
+        _load_exact(d, gf, "flux")
+        gf.quantize_fp8()
+        l8 = _denoise(c2, gf, 50)
+        df = np.abs(_image_u8(c2, l8).astype(np.int32) - fx["u8"].astype(np.int32))
+        print(f"  (e4m3 mode, 50 steps: latents {rel_l2(host(l8), fx['lat_50']):.3e}; u8 within 2 on {float((df <= 2).mean()):.2%} — outside the tolerance, reported as such)")
+        assert np.isfinite(host(l8)).all()
+    finally:
+        gf.close()

@@ -616,10 +616,81 @@ def test_c5_fp8_full_model_forward_against_the_fp8_recipe(full_models):
     t0 = time.time()
     ref = om.forward(img, ids, t5, txt_ids, t, clip, g)
     gm.quantize_fp8()
+    full_models["gm_is_fp8"] = True
     got8 = host(gm.forward(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(t), dev(clip), dev(g)))
-    om.set_fp8(True, attention=True)
+    om.set_fp8(True, attention=True)  # (left ON: the oracle caches its e4m3 weight images while the mode is on, and the full-size fp8 test below reuses them)
     ref8 = om.forward(img, ids, t5, txt_ids, t, clip, g)
     e8, ef, noise = rel_l2(got8, ref8), rel_l2(got8, ref), rel_l2(ref8, ref)
     print(f"C5 with the full model in fp8 mode, one Flux::forward at S=384 + T=128: vs the fp8 oracle {e8:.3e}, vs the f32 oracle {ef:.3e} "
           f"(recipe noise {noise:.3e}; oracle {time.time() - t0:.0f} s)")
     assert np.isfinite(got8).all() and ef <= 1.25 * noise and e8 <= noise
+
+
+def test_c5_fp8_full_model_forward_at_1280x720_batch_2(full_models):
+    """BASELINE configs[4] AT ITS OWN WORKLOAD (VERDICT r5 "next" 1 / `configs_untested`): FLUX.1-dev in fp8 mode, 1280 x 720 -> S = 3600 image + T = 512
+    text tokens = 4112 (every ragged path: a 17th query block of 16 rows, a last KV tile of 16 keys, GEMM row tiles of 16 rows), **B = 2** — the per-GPU
+    batch of "batch = 16 on 8 x MI355X" — in ONE `Flux::forward` call (8224 rows per launch).  Checked:
+      * sample 0 (the inputs of the bf16 C5 test above, whose f32 oracle result is kept) against the oracle's restatement of the fp8 recipe at this size and
+        against the f32 oracle, with the statistical bars of the S = 384 test: no further from f32 than the recipe itself (+ 25 %), closer to the recipe's
+        oracle than the recipe's own noise;
+      * sample 1 (other latents / text / pooled vector / timestep / guidance) through a size-independent property: its rows in the B = 2 launch equal the
+        same sample run alone, bit for bit (rows of a launch are independent) — and so does sample 0;
+      * the fp8 attention really ran on the one-wave stream at this ragged size (no fallback to the 8-wave kernel was counted).
+    The recipe is this library's own (parity unpinned by the reference: it has no fp8 compute path); its distance to f32 (~1e-1) is OUTSIDE the
+    8-bit bar of 3e-2 and is reported as such — profiles/r06_e4m3_mask_study.txt shows that no e4m3 subset of the linears fits it.  Runs after the
+    S = 384 fp8 test: the shared GPU handle is already in fp8 mode and the oracle's e4m3 weight images are cached."""
+    import json
+    if not full_models["wide"]:
+        print("\n!!! NOT RUN: test_c5_fp8_full_model_forward_at_1280x720_batch_2 needs the oracle's f32 weights + their e4m3 images (96 GB) on the host !!!")
+        pytest.skip("the host cannot hold the fp8 oracle's weights")
+    torch, d, orc, gm, om = (full_models[k] for k in ("torch", "d", "orc", "gm_dev", "om"))
+    cfg = dict(d.FLUX_DEV)
+    T = 512
+    if "c5" in full_models:
+        i0, ids, t50, txt_ids, t0, c0, g0, ref0 = full_models["c5"]
+    else:  # run alone
+        rng = np.random.default_rng(85)
+        lat = rng.standard_normal((1, 16, 90, 160)).astype(np.float32)
+        t50 = bf16_round(rng.standard_normal((1, T, cfg["joint_attention_dim"])).astype(np.float32))
+        c0 = rng.standard_normal((1, cfg["pooled_projection_dim"])).astype(np.float32)
+        i0, ids = orc.pack_latents(lat)
+        txt_ids = np.zeros((1, T, 3), np.float32)
+        sched = d.SchedulerConfig()
+        t0 = np.array([float(sched.get_timesteps(50, sched.calculate_shift(3600))[10])], np.float32)
+        g0 = np.array([3.5], np.float32)
+        om.set_fp8(False)
+        ref0 = om.forward(i0, ids, t50, txt_ids, t0, c0, g0)
+    assert i0.shape[1] == 3600
+    rng = np.random.default_rng(86)
+    i1 = rng.standard_normal(i0.shape).astype(np.float32)
+    t51 = bf16_round(rng.standard_normal(t50.shape).astype(np.float32))
+    c1 = rng.standard_normal(c0.shape).astype(np.float32)
+    sched = d.SchedulerConfig()
+    t1 = np.array([float(sched.get_timesteps(50, sched.calculate_shift(3600))[40])], np.float32)
+    g1 = np.array([2.0], np.float32)
+    cat = lambda a, b: np.concatenate([a, b], 0)
+    if not full_models.get("gm_is_fp8"):
+        gm.quantize_fp8()
+    fb0 = json.loads(gm.lib.fmi_device_info().decode())["fp8_attention_fallbacks"]
+    run = lambda im, idd, tx, tid, tt, cc, gg: host(gm.forward(dev(im), dev(idd), dev(tx, torch.bfloat16), dev(tid), dev(tt), dev(cc), dev(gg)))
+    got = run(cat(i0, i1), cat(ids, ids), cat(t50, t51), cat(txt_ids, txt_ids), cat(t0, t1), cat(c0, c1), cat(g0, g1))
+    assert got.shape == (2, 3600, 64) and np.isfinite(got).all()
+    one0 = run(i0, ids, t50, txt_ids, t0, c0, g0)
+    one1 = run(i1, ids, t51, txt_ids, t1, c1, g1)
+    fb1 = json.loads(gm.lib.fmi_device_info().decode())["fp8_attention_fallbacks"]
+    nb0 = int((one0[0].view(np.uint32) != got[0].view(np.uint32)).sum())
+    nb1 = int((one1[0].view(np.uint32) != got[1].view(np.uint32)).sum())
+    t_0 = time.time()
+    om.set_fp8(True, attention=True)
+    try:
+        ref8 = om.forward(i0, ids, t50, txt_ids, t0, c0, g0)
+    finally:
+        om.set_fp8(False)
+    e8, ef, noise = rel_l2(got[0], ref8[0]), rel_l2(got[0], ref0[0]), rel_l2(ref8, ref0)
+    print(f"C5 at its workload in fp8 mode (FLUX.1-dev in full, S=3600 + T=512, B=2 in one call): sample 0 vs the fp8 oracle {e8:.3e}, vs the f32 oracle {ef:.3e} "
+          f"(recipe noise {noise:.3e}; OUTSIDE the 8-bit bar of 3e-2, reported as such); samples in the batch vs run alone: {nb0} / {nb1} differing values; "
+          f"sample 1 vs sample 0 {rel_l2(got[1], got[0]):.2f}; fp8-attention fallbacks during the three calls: {fb1 - fb0}  (fp8 oracle {time.time() - t_0:.0f} s)")
+    assert nb0 == 0 and nb1 == 0
+    assert fb1 == fb0
+    assert rel_l2(got[1], got[0]) > 0.5  # (the two samples are different problems)
+    assert ef <= 1.25 * noise and e8 <= noise

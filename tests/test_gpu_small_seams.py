@@ -43,7 +43,8 @@ def test_timestep_embedding_matches_oracle_at_f32(env):
     ts = np.array(list(orc.get_timesteps(50, True, orc.calculate_shift(4096), 1.0)) + [3.5, 1.0, 0.0, 7.0, 1e-3], np.float32)
     for dim in (256, 64):
         out = torch.full((len(ts), dim), float("nan"), device="cuda")
-        L.check(lib.fmi_timestep_embedding(_p(dev(ts)), len(ts), dim, _p(out), None))
+        ts_d = dev(ts)
+        L.check(lib.fmi_timestep_embedding(_p(ts_d), len(ts), dim, _p(out), None))
         got, ref = host(out), orc.timestep_embedding(ts, dim)
         # |d cos(a)| <= |da|: the angle a = 1000 t f_i carries the f32 roundings of exp() (<= 1 ulp here and in glibc), of i * c and of the product:
         # 3 ulps of an angle of up to 7000 rad; the cos / sin evaluations themselves are good to ~1e-7
@@ -55,7 +56,7 @@ def test_timestep_embedding_matches_oracle_at_f32(env):
         print(f"timestep_embedding dim {dim}: max |d| {err.max():.2e} (bound there {bound.flat[err.argmax()]:.2e}); rows with t <= 1: max {err[:53].max():.2e}; rel-L2 {rel_l2(got, ref):.2e}")
         assert np.isfinite(got).all() and (err <= bound).all()
         assert rel_l2(got, ref) <= 2e-5
-    assert lib.fmi_timestep_embedding(_p(dev(ts)), len(ts), 255, _p(out), None) == -1  # odd dim
+    assert lib.fmi_timestep_embedding(_p(ts_d), len(ts), 255, _p(out), None) == -1  # odd dim
 
 
 def test_rope_table_matches_oracle_at_f32(env):
@@ -72,15 +73,17 @@ def test_rope_table_matches_oracle_at_f32(env):
             img_ids[1] += rng.uniform(0, 3, (S, 3)).astype(np.float32)
             txt_ids[1, :, 0] = 2.0
         pe = torch.full((B, T + S, 64, 2), float("nan"), device="cuda")
-        L.check(lib.fmi_rope_table(_p(dev(txt_ids)) if T else None, _p(dev(img_ids)), B, T, S, axes, 10000, _p(pe), None))
+        txt_d, img_d = dev(txt_ids), dev(img_ids)  # (held: a temporary's block would be handed to the next allocation before the kernel has read it)
+        L.check(lib.fmi_rope_table(_p(txt_d) if T else None, _p(img_d), B, T, S, axes, 10000, _p(pe), None))
         got = host(pe)
         ref4 = orc.rope_table(np.concatenate([txt_ids, img_ids], 1), [16, 56, 56], 10000)  # (B, L, 64, 2, 2) = [[cos, -sin], [sin, cos]]
         ref = np.stack([ref4[..., 0, 0], ref4[..., 1, 0]], -1)
         assert np.array_equal(ref4[..., 0, 1], -ref4[..., 1, 0]) and np.array_equal(ref4[..., 1, 1], ref4[..., 0, 0])
         err = np.abs(got - ref)
-        # angle = pos * inv_freq <= 83 rad (one f32 product of identical inputs on both sides unless pow() differs in its last f64 bit): cos / sin to a few 1e-7
+        # angle = pos * inv_freq <= 83 rad, one f32 product of identical inputs on both sides unless pow() differs in its last f64 bit (then inv_freq moves by
+        # an f32 ulp and the angle by up to 83 * 6e-8 = 5e-6: not seen); cos / sin themselves to a few 1e-7
         print(f"rope_table B={B} T={T} S={S}: max |d| {err.max():.2e}, rel-L2 {rel_l2(got, ref):.2e}")
-        assert np.isfinite(got).all() and err.max() <= 1e-6
+        assert np.isfinite(got).all() and err.max() <= 2e-6
     assert lib.fmi_rope_table(None, None, 1, 0, 0, axes, 10000, _p(pe), None) == -1  # empty
 
 
@@ -98,7 +101,8 @@ def test_rmsnorm_rope_matches_oracle_at_f32_and_bf16_is_its_single_rounding(env,
     ids[:, :, 2] = (np.arange(L) % 80)[None]
     axes = (C.c_int * 3)(16, 56, 56)
     pe = torch.empty((B, L, 64, 2), device="cuda")
-    Lb.check(lib.fmi_rope_table(None, _p(dev(ids)), B, 0, L, axes, 10000, _p(pe), None))
+    ids_d = dev(ids)
+    Lb.check(lib.fmi_rope_table(None, _p(ids_d), B, 0, L, axes, 10000, _p(pe), None))
     qd, kd, wqd, wkd = dev(q, torch.bfloat16), dev(k, torch.bfloat16), dev(wq, torch.bfloat16), dev(wk, torch.bfloat16)
     of = [torch.full((B, H, L, 128), float("nan"), device="cuda") for _ in range(2)]
     ob = [torch.full((B, H, L, 128), float("nan"), device="cuda", dtype=torch.bfloat16) for _ in range(2)]
