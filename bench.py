@@ -178,6 +178,7 @@ def main():
                     help="nf4: block linears stored bitsandbytes-nf4, fused dequant-GEMM (config C3); fp8: block linears on the e4m3 MFMA path (config C5); "
                          "int8: the int8 MFMA on the default linear mask (all but the double blocks' MLP); both 8-bit modes hand q and k to the attention as e4m3 (static scales), P.V stays bf16")
     ap.add_argument("--int8-mask", type=lambda v: int(v, 0), default=None, help="--quant int8: the FMI_Q8_* linear mask (default: the library's FMI_INT8_DEFAULT_MASK)")
+    ap.add_argument("--int8-unsmoothed", action="store_true", help="int8 legs: round 5's recipe without the calibrated per-channel smoothing (fmi_flux_calibrate_int8)")
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU per image step (C5: 2)")
     ap.add_argument("--sequence-parallel", action="store_true",
                     help="N > 1: all ranks denoise ONE image together (token shards, two all-to-alls per block; strong scaling) instead of one image each")
@@ -274,8 +275,7 @@ def main():
     bcast = fdist.broadcast_state(flux, dev) if world > 1 else None
     if args.quant == "fp8":
         flux.quantize_fp8()
-    if args.quant == "int8":
-        flux.quantize_int8(args.int8_mask)
+    int8_main_pending = args.quant == "int8"  # (calibrated below, once the workload's inputs exist)
     synth.fill_vae_random_device(vae, seed=1, device=dev)
     torch.cuda.synchronize()
     load_s = time.time() - t_load
@@ -306,6 +306,18 @@ def main():
             self.guidance = torch.full((B,), 3.5, dtype=torch.float32, device=dev)
             self.txt_ids = torch.zeros((B, T, 3), dtype=torch.float32, device=dev)
             self.timesteps = sched.get_timesteps(NS, sched.calculate_shift(self.S))
+
+        def calibrate_int8(self, model):
+            """The int8 mode's calibration (round 6, fmi_flux_calibrate_int8; what Pipeline(dtype=I8) does at its first request): four bf16 evaluations of
+            one sample across the schedule record the per-channel absmax of every block linear's input; quantize_int8 then folds the smoothing factors
+            in.  Outside every timed region."""
+            lat = d.randn_latents(1, 16, self.h, self.w, seed=4321, device=dev)
+            img, img_ids = d.pack_latents(lat)
+            model.calibrate_int8(True)
+            n = len(self.timesteps) - 1
+            for i in sorted({0, n // 3, 2 * n // 3, n - 1}):
+                t = torch.full((1,), float(self.timesteps[i]), dtype=torch.float32, device=dev)
+                model.forward(img, img_ids, self.txt[:1], self.txt_ids[:1], t, self.y[:1], self.guidance[:1])
 
         def one_image(self, model, i):
             if spg is not None and model is flux:  # same latents everywhere; each rank denoises its token shard, all get the result
@@ -347,6 +359,10 @@ def main():
             return roof, ex, img
 
     wl = Workload(args.height, args.width, args.batch)
+    if int8_main_pending:
+        if not args.int8_unsmoothed:
+            wl.calibrate_int8(flux)
+        flux.quantize_int8(args.int8_mask)
     H, W, B, S, h, w = wl.H, wl.W, wl.B, wl.S, wl.h, wl.w
 
     def one_image(i):
@@ -547,9 +563,11 @@ def main():
         # int8 mode (round 4): its own handle (bf16 weights + int8 codes of the masked linears), default mask = all but the double blocks' MLP
         fi = d.FluxModel(d.FLUX_DEV, local_rank)
         fill_flux(fi, "none")
+        if not args.int8_unsmoothed:
+            wl.calibrate_int8(fi)
         fi.quantize_int8()
         leg(fi, wl, "int8_1024", KDESC["int8"], 5000.0,
-            "int8 block linears (symmetric per-channel weight / per-token activation scales, exact int32 accumulate) for double q|k|v + attention out and single "
+            "int8 block linears (per-channel weight / per-token activation scales on per-input-channel smoothed operands — s = sqrt(amax_x / amax_W) from a 4-evaluation calibration —, exact int32 accumulate) for double q|k|v + attention out and single "
             "linear1 + linear2; attention with e4m3 q / k operands (static per-block scales, QK^T on the fp8 MFMA) and bf16 P.V; the double blocks' MLP and everything else bf16; f32 residual stream")
         leg(fi, wl_c5, "int8_c5_shape", KDESC["int8"], 5000.0, "as int8_1024 (BASELINE configs[4]'s shape, 1280x720 batch 2, in the 8-bit mode that is within tolerance)")
         fi.close()

@@ -193,6 +193,9 @@ def _declare(lib):
     lib.fmi_gemm_q8.argtypes = [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]
     lib.fmi_quantize_rows_i8_asym.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fmi_rowsum_i8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.fmi_quantize_rows_i8_scaled.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fmi_col_absmax.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.fmi_flux_calibrate_int8.argtypes = [C.c_void_p, C.c_int]
     lib.fmi_gemm_i8_asym.argtypes = [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p]
     lib.fmi_flux_quantize_fp8.argtypes = [C.c_void_p, C.c_void_p]
     lib.fmi_flux_quantize_int8.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
@@ -261,14 +264,14 @@ def check(rc, lib=None):
 # every symbol include/flux_mi355x.h declares (tests/test_host_logic.py::test_library_exports_every_header_symbol checks they are all exported)
 EXPORTED = [
     "fmi_last_error", "fmi_abi_version", "fmi_init", "fmi_device_info", "fmi_build_id", "fmi_has_alt_kernels", "fmi_flux_default_config", "fmi_flux_create", "fmi_flux_destroy",
-    "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_set_linear_int8", "fmi_flux_set_quant_dense_cache", "fmi_flux_set_sequence_parallel", "fmi_flux_set_split_k", "fmi_set_bnb4_onewave_min_rows", "fmi_flux_set_attention_rescale_threshold", "fmi_flux_set_attention_kernel", "fmi_flux_state_buffer_count", "fmi_flux_state_export", "fmi_flux_state_adopt", "fmi_flux_state_buffer", "fmi_flux_set_modulation_gemm", "fmi_flux_quantize_fp8", "fmi_flux_quantize_int8", "fmi_flux_set_fp8_attention", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
+    "fmi_flux_set_tensor", "fmi_flux_set_linear_bnb4", "fmi_flux_set_linear_int8", "fmi_flux_set_quant_dense_cache", "fmi_flux_set_sequence_parallel", "fmi_flux_set_split_k", "fmi_set_bnb4_onewave_min_rows", "fmi_flux_set_attention_rescale_threshold", "fmi_flux_set_attention_kernel", "fmi_flux_state_buffer_count", "fmi_flux_state_export", "fmi_flux_state_adopt", "fmi_flux_state_buffer", "fmi_flux_set_modulation_gemm", "fmi_flux_quantize_fp8", "fmi_flux_quantize_int8", "fmi_flux_calibrate_int8", "fmi_flux_set_fp8_attention", "fmi_flux_missing_count", "fmi_flux_missing_name", "fmi_flux_size_in_bytes",
     "fmi_flux_forward", "fmi_flux_denoise", "fmi_flux_set_profiling", "fmi_flux_set_fused_qkv_relayout", "fmi_flux_phase_count", "fmi_flux_phase_name", "fmi_flux_phase_ms",
     "fmi_vae_default_config", "fmi_vae_create", "fmi_vae_destroy", "fmi_vae_set_tensor", "fmi_vae_missing_count", "fmi_vae_missing_name",
     "fmi_vae_scale_factor", "fmi_vae_shift_factor", "fmi_vae_decode", "fmi_vae_encode", "fmi_vae_mid_attention",
     "fmi_t5_default_config", "fmi_t5_create", "fmi_t5_destroy", "fmi_t5_set_tensor", "fmi_t5_set_linear_bnb4", "fmi_t5_set_linear_int8", "fmi_t5_missing_count", "fmi_t5_missing_name",
     "fmi_t5_size_in_bytes", "fmi_t5_forward", "fmi_clip_default_config", "fmi_clip_create", "fmi_clip_destroy", "fmi_clip_set_tensor",
     "fmi_clip_missing_count", "fmi_clip_missing_name", "fmi_clip_size_in_bytes", "fmi_clip_forward", "fmi_pack_latents", "fmi_unpack_latents", "fmi_postprocess_u8",
-    "fmi_randn", "fmi_philox_u32", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_linear_int8_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_quantize_rows_i8", "fmi_linear_i8", "fmi_gemm_q8", "fmi_quantize_rows_i8_asym", "fmi_rowsum_i8", "fmi_gemm_i8_asym", "fmi_linear_q8_workspace_bytes", "fmi_linear_fp8_ws", "fmi_linear_i8_ws", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_sdpa_workspace_bytes", "fmi_sdpa_bf16_ws", "fmi_sdpa_fp8qk_ws", "fmi_sdpa_fp8", "fmi_sdpa_fp8_ws", "fmi_set_attention_kernel", "fmi_layernorm_mod",
+    "fmi_randn", "fmi_philox_u32", "fmi_calculate_shift", "fmi_get_timesteps", "fmi_linear_bf16", "fmi_linear_bnb4_bf16", "fmi_linear_int8_bf16", "fmi_quantize_rows_fp8", "fmi_linear_fp8", "fmi_quantize_rows_i8", "fmi_linear_i8", "fmi_gemm_q8", "fmi_quantize_rows_i8_asym", "fmi_rowsum_i8", "fmi_quantize_rows_i8_scaled", "fmi_col_absmax", "fmi_gemm_i8_asym", "fmi_linear_q8_workspace_bytes", "fmi_linear_fp8_ws", "fmi_linear_i8_ws", "fmi_sdpa_bf16", "fmi_sdpa_fp8qk", "fmi_sdpa_workspace_bytes", "fmi_sdpa_bf16_ws", "fmi_sdpa_fp8qk_ws", "fmi_sdpa_fp8", "fmi_sdpa_fp8_ws", "fmi_set_attention_kernel", "fmi_layernorm_mod",
     "fmi_release_scratch", "fmi_timestep_embedding", "fmi_rope_table", "fmi_rmsnorm_rope",
     "fmi_groupnorm_nhwc", "fmi_conv2d_nhwc",
     "fmi_comm_probe", "fmi_comm_unique_id", "fmi_comm_create", "fmi_comm_destroy", "fmi_comm_rank", "fmi_comm_world_size", "fmi_comm_stats", "fmi_comm_all_to_all",

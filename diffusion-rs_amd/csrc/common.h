@@ -348,22 +348,27 @@ int launch_layernorm_mod2(const float* x, const float* scale, const float* shift
                           hipStream_t stream);
 int launch_layernorm_mod_fp8_2(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch, uint8_t* out,
                                float* out_scale, int rows, const float* x2, const float* scale2, const float* shift2, int rows_per_batch2, uint8_t* out2,
-                               float* out_scale2, int rows2, int D, float eps, hipStream_t stream, int kind = 1);
+                               float* out_scale2, int rows2, int D, float eps, hipStream_t stream, int kind = 1, const float* smooth = nullptr,
+                               const float* smooth2 = nullptr);
 int launch_layernorm_mod(const float* x, const float* scale, const float* shift, int mod_bstride,
                          int rows_per_batch, bf16_t* out, int rows, int D, float eps, hipStream_t stream);
 // y(M,N) f32 (+)= act_in(x(M,K) f32) W(N,K)^T bf16 + bias bf16 ; M <= 8
 // fp8 path (fp8.hip).  Row-wise dynamic quantisation: scale[r] = max(absmax(x[r,:]), 1e-30) / 448,
 // out[r,k] = e4m3_rne(x[r,k] * (448 / max(absmax, 1e-30))); x bf16 with row stride ld, out (rows, K) dense.
 // kind 2: the int8 form (scale = absmax / 127, codes = clamp(rint(x * 127 / absmax), -127, 127)) — fp8.hip's header
-int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* out, float* scale, hipStream_t stream, int kind = 1);
+// vec (optional, K floats, 16-byte aligned): every column is multiplied by vec[k] in f32 before the recipe (the smoothed int8 recipe: 1 / s for activations, s for weights)
+int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* out, float* scale, hipStream_t stream, int kind = 1, const float* vec = nullptr);
 // int8, post-GELU form (fp8.hip's header): columns [0, d0) symmetric, columns [d0, K) on 256 levels over their [min, max], one step per row;
 // offset[r] = lo + 128 * scale[r].  d0 % 8 == 0, 0 <= d0 < K.
-int launch_quantize_rows_i8_asym(const bf16_t* x, int ld, int rows, int K, int d0, uint8_t* out, float* scale, float* offset, hipStream_t stream);
+int launch_quantize_rows_i8_asym(const bf16_t* x, int ld, int rows, int K, int d0, uint8_t* out, float* scale, float* offset, hipStream_t stream, const float* vec = nullptr);
 // w_sum[n] = w_scale[n] * float(sum_{k >= d0} wq[n,k]) over int8 codes (N, K) row-major: the column term of the offset segment
 int launch_rowsum_i8(const int8_t* wq, const float* w_scale, int N, int K, int d0, float* w_sum, hipStream_t stream);
 // launch_layernorm_mod with the row quantisation fused (values quantised from f32, not via bf16)
 int launch_layernorm_mod_fp8(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch,
-                             uint8_t* out, float* out_scale, int rows, int D, float eps, hipStream_t stream, int kind = 1);
+                             uint8_t* out, float* out_scale, int rows, int D, float eps, hipStream_t stream, int kind = 1, const float* smooth = nullptr);
+// calibration of the smoothed int8 recipe (fp8.hip): column absmax of a bf16 matrix folded into amax (atomic max), and s = sqrt(a / w), 1 / s
+int launch_col_absmax(const bf16_t* x, int ld, int rows, int K, float* amax, hipStream_t stream);
+int launch_smooth_factors(const float* act_amax, const float* w_amax, int K, float* s_out, float* inv_out, hipStream_t stream);
 int launch_gemv(const float* x, const bf16_t* W, const bf16_t* bias, float* y, int M, int N, int K,
                 int silu_in, int accumulate, hipStream_t stream);
 // bf16 out = w_i8 * SCB[row] / 127 (dequant.cu:205-214) on `stream`

@@ -24,6 +24,8 @@
 //   y[m,n] = float(sum_k q[m,k] q_w[n,k]) * (s[m] * scale_w[n]) + offset[m] * wsum[n] + bias[n],  wsum[n] = scale_w[n] * float(sum_{k >= d0} q_w[n,k])
 // Both kernels are one pass over HBM per row block: a 256-thread block owns a row, keeps it in
 // registers between the absmax reduction and the conversion, 16-byte loads, 8-byte stores.
+#include <algorithm>
+
 #include "common.h"
 
 namespace fmi {
@@ -61,9 +63,24 @@ __device__ __forceinline__ uint32_t pack_q8x4(float a, float b, float c, float d
 
 constexpr int QR_MAXC = 8;  // 16-byte chunks per thread held in registers: K <= 256 * 8 * 8 = 16384
 
-template <bool I8>
+// the 8 bf16 of a 16-byte chunk as f32, times the per-column vector of the smoothed int8 recipe when there is one (VEC; header: "Round 6")
+template <bool VEC>
+__device__ __forceinline__ void widen8(const uint4& raw, const float* __restrict vec, int i, float (&f)[8]) {
+  const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f[2 * e] = __uint_as_float(u[e] << 16);
+    f[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+  }
+  if constexpr (VEC) {
+    const float4 a = reinterpret_cast<const float4*>(vec)[2 * i], b = reinterpret_cast<const float4*>(vec)[2 * i + 1];
+    f[0] *= a.x, f[1] *= a.y, f[2] *= a.z, f[3] *= a.w, f[4] *= b.x, f[5] *= b.y, f[6] *= b.z, f[7] *= b.w;
+  }
+}
+
+template <bool I8, bool VEC>
 __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __restrict x, int ld, int K, uint8_t* __restrict out,
-                                                                float* __restrict scale) {
+                                                                float* __restrict scale, const float* __restrict vec) {
   __shared__ float red[4];
   const int row = blockIdx.x;
   const uint4* xr = reinterpret_cast<const uint4*>(x + (int64_t)row * ld);
@@ -75,12 +92,10 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __
     const int i = threadIdx.x + c * 256;
     if (i < nc) {
       v[c] = xr[i];
-      const uint32_t u[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+      float f[8];
+      widen8<VEC>(v[c], vec, i, f);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        am = fmaxf(am, fabsf(__uint_as_float(u[e] << 16)));
-        am = fmaxf(am, fabsf(__uint_as_float(u[e] & 0xffff0000u)));
-      }
+      for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(f[e]));
     }
   }
   am = fmaxf(block_max_256(am, red), 1e-30f);
@@ -92,13 +107,10 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __
   for (int c = 0; c < QR_MAXC; ++c) {
     const int i = threadIdx.x + c * 256;
     if (i < nc) {
-      const uint32_t u[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
       float f[8];
+      widen8<VEC>(v[c], vec, i, f);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        f[2 * e] = __uint_as_float(u[e] << 16) * inv;
-        f[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u) * inv;
-      }
+      for (int e = 0; e < 8; ++e) f[e] *= inv;
       o[i] = make_uint2(pack_q8x4<I8>(f[0], f[1], f[2], f[3]), pack_q8x4<I8>(f[4], f[5], f[6], f[7]));
     }
   }
@@ -111,8 +123,9 @@ __device__ __forceinline__ float block_min_256(float v, float* red) {
   return fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
 }
 // the post-GELU form (header): chunks of 8 columns below d0 / 8 are the symmetric front segment
+template <bool VEC>
 __global__ __launch_bounds__(256) void quantize_rows_i8_asym_kernel(const bf16_t* __restrict x, int ld, int K, int d0c, uint8_t* __restrict out,
-                                                                    float* __restrict scale, float* __restrict offset) {
+                                                                    float* __restrict scale, float* __restrict offset, const float* __restrict vec) {
   __shared__ float red[3][4];
   const int row = blockIdx.x;
   const uint4* xr = reinterpret_cast<const uint4*>(x + (int64_t)row * ld);
@@ -124,13 +137,11 @@ __global__ __launch_bounds__(256) void quantize_rows_i8_asym_kernel(const bf16_t
     const int i = threadIdx.x + c * 256;
     if (i < nc) {
       v[c] = xr[i];
-      const uint32_t u[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+      float f[8];
+      widen8<VEC>(v[c], vec, i, f);
       float cmin = INFINITY, cmax = -INFINITY;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float a = __uint_as_float(u[e] << 16), b = __uint_as_float(u[e] & 0xffff0000u);
-        cmin = fminf(cmin, fminf(a, b)), cmax = fmaxf(cmax, fmaxf(a, b));
-      }
+      for (int e = 0; e < 8; ++e) cmin = fminf(cmin, f[e]), cmax = fmaxf(cmax, f[e]);
       if (i < d0c) am = fmaxf(am, fmaxf(fabsf(cmin), fabsf(cmax)));
       else lo = fminf(lo, cmin), hi = fmaxf(hi, cmax);
     }
@@ -149,13 +160,8 @@ __global__ __launch_bounds__(256) void quantize_rows_i8_asym_kernel(const bf16_t
   for (int c = 0; c < QR_MAXC; ++c) {
     const int i = threadIdx.x + c * 256;
     if (i < nc) {
-      const uint32_t u[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
       float f[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        f[2 * e] = __uint_as_float(u[e] << 16);
-        f[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
-      }
+      widen8<VEC>(v[c], vec, i, f);
       uint32_t w[2];
       if (i < d0c) {
         w[0] = pack_i8x4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv);
@@ -198,7 +204,8 @@ __global__ __launch_bounds__(256) void layernorm_mod_fp8_kernel(const float* __r
                                                                 uint8_t* __restrict out1, float* __restrict out_scale1, int D, float eps, int rows1,
                                                                 const float* __restrict x2, const float* __restrict scale2,
                                                                 const float* __restrict shift2, int rows_per_batch2, uint8_t* __restrict out2,
-                                                                float* __restrict out_scale2) {
+                                                                float* __restrict out_scale2, const float* __restrict smooth1,
+                                                                const float* __restrict smooth2) {
   __shared__ float red[2][4];
   __shared__ float redm[4];
   // (a second row set in the same launch, as layernorm_mod_kernel)
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_fp8_kernel(const float* __r
   const int rows_per_batch = second ? rows_per_batch2 : rows_per_batch1;
   uint8_t* out = second ? out2 : out1;
   float* out_scale = second ? out_scale2 : out_scale1;
+  const float4* sm = reinterpret_cast<const float4*>(second ? smooth2 : smooth1);  // 1 / s per channel of the consuming linear (smoothed int8 recipe), or null
   const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
   const int nv = D >> 2;
   float4 v[LN_MAXV], ksc[LN_MAXV], ksh[LN_MAXV];
@@ -255,6 +263,10 @@ __global__ __launch_bounds__(256) void layernorm_mod_fp8_kernel(const float* __r
         const float4 k = ksh[c];
         a += k.x, b += k.y, cc += k.z, d += k.w;
       }
+      if (sm) {
+        const float4 k = sm[i];
+        a *= k.x, b *= k.y, cc *= k.z, d *= k.w;
+      }
       v[c] = make_float4(a, b, cc, d);
       am = fmaxf(fmaxf(am, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(cc), fabsf(d)));
     }
@@ -271,23 +283,51 @@ __global__ __launch_bounds__(256) void layernorm_mod_fp8_kernel(const float* __r
   }
 }
 
+
+__global__ __launch_bounds__(256) void col_absmax_kernel(const bf16_t* __restrict x, int ld, int rows, int chunks, float* __restrict amax) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= chunks) return;
+  float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(x + (int64_t)r * ld + 8 * i);
+    float f[8];
+    widen8<false>(raw, nullptr, 0, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], fabsf(f[e]));
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (m[e] == m[e]) atomicMax(reinterpret_cast<unsigned int*>(amax) + 8 * i + e, __float_as_uint(m[e]));  // (a NaN would order above everything: dropped)
+}
+__global__ void smooth_factors_kernel(const float* __restrict a, const float* __restrict w, int K, float* __restrict s_out, float* __restrict inv_out) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const float s = fminf(fmaxf(sqrtf(fmaxf(a[k], 1e-5f) / fmaxf(w[k], 1e-5f)), 0.0009765625f), 1024.0f);
+  s_out[k] = s;
+  inv_out[k] = 1.0f / s;
+}
 }  // namespace
 
-int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* out, float* scale, hipStream_t stream, int kind) {
+int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* out, float* scale, hipStream_t stream, int kind, const float* vec) {
   if (rows <= 0) return FMI_OK;
   if (kind != 1 && kind != 2) return fail(FMI_ERR_INVALID, "quantize_rows: kind must be 1 (e4m3) or 2 (int8)");
   if (K <= 0 || K % 8 || ld % 8 || K > 256 * 8 * QR_MAXC) return fail(FMI_ERR_INVALID, "quantize_rows_fp8: K and ld must be multiples of 8, K <= 16384");
-  if (kind == 2) hipLaunchKernelGGL(quantize_rows_fp8_kernel<true>, dim3(rows), dim3(256), 0, stream, x, ld, K, out, scale);
-  else hipLaunchKernelGGL(quantize_rows_fp8_kernel<false>, dim3(rows), dim3(256), 0, stream, x, ld, K, out, scale);
+  if (vec && (reinterpret_cast<uintptr_t>(vec) & 15)) return fail(FMI_ERR_INVALID, "quantize_rows: the per-column vector must be 16-byte aligned");
+  if (kind == 2 && vec) hipLaunchKernelGGL((quantize_rows_fp8_kernel<true, true>), dim3(rows), dim3(256), 0, stream, x, ld, K, out, scale, vec);
+  else if (kind == 2) hipLaunchKernelGGL((quantize_rows_fp8_kernel<true, false>), dim3(rows), dim3(256), 0, stream, x, ld, K, out, scale, vec);
+  else if (vec) hipLaunchKernelGGL((quantize_rows_fp8_kernel<false, true>), dim3(rows), dim3(256), 0, stream, x, ld, K, out, scale, vec);
+  else hipLaunchKernelGGL((quantize_rows_fp8_kernel<false, false>), dim3(rows), dim3(256), 0, stream, x, ld, K, out, scale, vec);
   FMI_LAUNCH_CHECK();
   return FMI_OK;
 }
 
-int launch_quantize_rows_i8_asym(const bf16_t* x, int ld, int rows, int K, int d0, uint8_t* out, float* scale, float* offset, hipStream_t stream) {
+int launch_quantize_rows_i8_asym(const bf16_t* x, int ld, int rows, int K, int d0, uint8_t* out, float* scale, float* offset, hipStream_t stream, const float* vec) {
   if (rows <= 0) return FMI_OK;
   if (K <= 0 || K % 8 || ld % 8 || K > 256 * 8 * QR_MAXC) return fail(FMI_ERR_INVALID, "quantize_rows_i8_asym: K and ld must be multiples of 8, K <= 16384");
   if (d0 < 0 || d0 >= K || d0 % 16) return fail(FMI_ERR_INVALID, "quantize_rows_i8_asym: the offset segment starts at a multiple of 16 below K (fmi_rowsum_i8's rule)");
-  hipLaunchKernelGGL(quantize_rows_i8_asym_kernel, dim3(rows), dim3(256), 0, stream, x, ld, K, d0 >> 3, out, scale, offset);
+  if (vec && (reinterpret_cast<uintptr_t>(vec) & 15)) return fail(FMI_ERR_INVALID, "quantize_rows_i8_asym: the per-column vector must be 16-byte aligned");
+  if (vec) hipLaunchKernelGGL(quantize_rows_i8_asym_kernel<true>, dim3(rows), dim3(256), 0, stream, x, ld, K, d0 >> 3, out, scale, offset, vec);
+  else hipLaunchKernelGGL(quantize_rows_i8_asym_kernel<false>, dim3(rows), dim3(256), 0, stream, x, ld, K, d0 >> 3, out, scale, offset, vec);
   FMI_LAUNCH_CHECK();
   return FMI_OK;
 }
@@ -301,23 +341,41 @@ int launch_rowsum_i8(const int8_t* wq, const float* w_scale, int N, int K, int d
 
 int launch_layernorm_mod_fp8_2(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch, uint8_t* out,
                                float* out_scale, int rows, const float* x2, const float* scale2, const float* shift2, int rows_per_batch2, uint8_t* out2,
-                               float* out_scale2, int rows2, int D, float eps, hipStream_t stream, int kind) {
+                               float* out_scale2, int rows2, int D, float eps, hipStream_t stream, int kind, const float* smooth, const float* smooth2) {
   if (rows + rows2 <= 0) return FMI_OK;
   if (kind != 1 && kind != 2) return fail(FMI_ERR_INVALID, "layernorm_mod_fp8: kind must be 1 (e4m3) or 2 (int8)");
   if (D % 4 || D > 256 * 4 * LN_MAXV) return fail(FMI_ERR_INVALID, "layernorm_mod_fp8: D must be a multiple of 4 and <= 4096");
   if (kind == 2)
     hipLaunchKernelGGL(layernorm_mod_fp8_kernel<true>, dim3(rows + rows2), dim3(256), 0, stream, x, scale, shift, mod_bstride, rows_per_batch, out, out_scale,
-                       D, eps, rows, x2, scale2, shift2, rows_per_batch2, out2, out_scale2);
+                       D, eps, rows, x2, scale2, shift2, rows_per_batch2, out2, out_scale2, smooth, smooth2);
   else
     hipLaunchKernelGGL(layernorm_mod_fp8_kernel<false>, dim3(rows + rows2), dim3(256), 0, stream, x, scale, shift, mod_bstride, rows_per_batch, out, out_scale,
-                       D, eps, rows, x2, scale2, shift2, rows_per_batch2, out2, out_scale2);
+                       D, eps, rows, x2, scale2, shift2, rows_per_batch2, out2, out_scale2, smooth, smooth2);
   FMI_LAUNCH_CHECK();
   return FMI_OK;
 }
 int launch_layernorm_mod_fp8(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch, uint8_t* out,
-                             float* out_scale, int rows, int D, float eps, hipStream_t stream, int kind) {
+                             float* out_scale, int rows, int D, float eps, hipStream_t stream, int kind, const float* smooth) {
   return launch_layernorm_mod_fp8_2(x, scale, shift, mod_bstride, rows_per_batch, out, out_scale, rows, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0,
-                                    D, eps, stream, kind);
+                                    D, eps, stream, kind, smooth, nullptr);
+}
+
+// ---- the calibration side of the smoothed int8 recipe (header: "Round 6")
+// max |x[r, k]| over the rows of a bf16 matrix, folded into amax[k] (>= 0, so the f32 bit patterns order like unsigned integers: atomicMax on them)
+int launch_col_absmax(const bf16_t* x, int ld, int rows, int K, float* amax, hipStream_t stream) {
+  if (rows <= 0 || K <= 0) return FMI_OK;
+  if (K % 8 || ld % 8) return fail(FMI_ERR_INVALID, "col_absmax: K and ld must be multiples of 8");
+  const int chunks = K / 8, rblocks = std::min((rows + 63) / 64, 512);
+  hipLaunchKernelGGL(col_absmax_kernel, dim3((chunks + 255) / 256, rblocks), dim3(256), 0, stream, x, ld, rows, chunks, amax);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
+}
+// s[k] = clamp(sqrt(max(a[k], 1e-5) / max(w[k], 1e-5)), 2^-10, 2^10), inv_s[k] = 1 / s[k]   (SmoothQuant with alpha = 1/2)
+int launch_smooth_factors(const float* act_amax, const float* w_amax, int K, float* s_out, float* inv_out, hipStream_t stream) {
+  if (K <= 0) return FMI_OK;
+  hipLaunchKernelGGL(smooth_factors_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, act_amax, w_amax, K, s_out, inv_out);
+  FMI_LAUNCH_CHECK();
+  return FMI_OK;
 }
 
 }  // namespace fmi

@@ -146,6 +146,12 @@ class FluxModel:
         MFMA; P.V stays bf16).  set_fp8_attention(0) keeps bf16 operands."""
         L.check(self.lib.fmi_flux_quantize_int8(self.h, INT8_DEFAULT_MASK if mask is None else int(mask), stream), self.lib)
 
+    def calibrate_int8(self, on: bool = True):
+        """Start (or drop) the calibration of the smoothed int8 recipe: while on, every forward / denoise evaluation (bf16 mode) also records the per-channel
+        absmax of each block linear's input; the next quantize_int8() folds s = sqrt(amax_x / amax_W) per channel into the weight codes and 1 / s into the
+        activation quantisation (include/flux_mi355x.h: fmi_flux_calibrate_int8).  Without it quantize_int8() is the unsmoothed recipe."""
+        L.check(self.lib.fmi_flux_calibrate_int8(self.h, int(bool(on))), self.lib)
+
     def set_fp8_attention(self, mode: int):
         """q and k of the attention as e4m3 with static scales, QK^T on the fp8 MFMA: 0 never, 1 (default) in the 8-bit modes, 2 in every
         mode — the bf16 block linears included (opt-in: a reduced-precision attention operand, not the reference's semantics)."""

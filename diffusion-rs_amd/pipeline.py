@@ -189,7 +189,9 @@ class Pipeline:
         if dtype == ModelDType.F8E4M3:
             self.flux.quantize_fp8()
         elif dtype == ModelDType.I8:
-            self.flux.quantize_int8()
+            # the int8 mode is CALIBRATED (round 6: per-channel smoothing, include/flux_mi355x.h fmi_flux_calibrate_int8): the statistics come from the first
+            # request — four model evaluations across its schedule on its first prompt — so the weights are quantised there, not here (generate_tensor)
+            self._int8_pending = True
 
     # Pipeline::load (pipelines/mod.rs:120-236) for a local diffusers directory or a DDUF file:
     # model_index.json -> FluxPipeline only; scheduler / transformer / vae components, plus text_encoder (CLIP),
@@ -317,6 +319,8 @@ class Pipeline:
             mu = self.scheduler.calculate_shift(img.shape[1])
             timesteps = self.scheduler.get_timesteps(params.num_steps, mu)
             guidance = torch.full((B,), float(params.guidance_scale), dtype=torch.float32, device=dev) if self.flux.is_guidance() else None
+            if getattr(self, "_int8_pending", False):
+                self._int8_calibrate_and_quantize(img[:1], img_ids[:1], t5_emb[:1], txt_ids[:1], clip_emb[:1], None if guidance is None else guidance[:1], timesteps)
             if sp is not None:  # every rank holds the same inputs; each denoises its token shard, then all get the latents
                 img = sp.gather(self.flux.denoise(sp.shard(img), sp.shard(img_ids), sp.shard(t5_emb), sp.shard(txt_ids), clip_emb, guidance, timesteps))
             else:
@@ -324,6 +328,21 @@ class Pipeline:
             z = F.unpack_latents(img, 16, h, w, self.vae.scale_factor(), self.vae.shift_factor())
             image = self.vae.decode(z)
             return F.postprocess_u8(image)
+
+    INT8_CALIBRATION_POINTS = 4
+
+    def _int8_calibrate_and_quantize(self, img, img_ids, t5_emb, txt_ids, clip_emb, guidance, timesteps):
+        """ModelDType.I8, first request: INT8_CALIBRATION_POINTS evaluations of the bf16 model on ONE sample at timesteps spread over the request's schedule
+        record the per-channel absmax of every block linear's input (the outlier channels of a DiT are the same at every step and for every prompt: they
+        come from the AdaLN weights), then the block linears are quantised with the smoothing factors folded in.  ~0.25 s once per model at 1024 x 1024."""
+        n = len(timesteps) - 1
+        pts = sorted({min(n - 1, max(0, round(i * (n - 1) / max(1, self.INT8_CALIBRATION_POINTS - 1)))) for i in range(self.INT8_CALIBRATION_POINTS)})
+        self.flux.calibrate_int8(True)
+        for i in pts:
+            t = torch.full((1,), float(timesteps[i]), dtype=torch.float32, device=self.device)
+            self.flux.forward(img, img_ids, t5_emb, txt_ids, t, clip_emb, guidance)
+        self.flux.quantize_int8()
+        self._int8_pending = False
 
     def enable_sequence_parallel(self, group=None):
         """Single-image latency mode: the ranks of `group` (default: all of torch.distributed) denoise every
@@ -351,6 +370,17 @@ class Pipeline:
                 return None
         elif world > 1:
             n = len(prompts)
+            if getattr(self, "_int8_pending", False) and n > 0:
+                # every rank calibrates on the SAME sample — global sample 0 of this request — so that all ranks hold the same int8 weights and an image does
+                # not depend on the rank that produced it (one extra image per rank, once per model)
+                sub = dict(kw)
+                for key in ("embeddings", "token_ids"):
+                    if sub.get(key) is not None:
+                        sub[key] = tuple(t[:1] for t in sub[key])
+                if sub.get("latents") is not None:
+                    sub["latents"] = sub["latents"][:1]
+                first = sub.pop("first_sample", 0)
+                self.generate_tensor(prompts[:1], params, sample_ids=[first], **sub)
 
             def pick(x, ids):
                 return None if x is None else x[torch.as_tensor(ids, dtype=torch.long)] if isinstance(x, torch.Tensor) else [x[i] for i in ids]

@@ -284,6 +284,59 @@ def exact_tensor_device(name, shape, family="flux", salt=0, device="cuda", **kw)
     return v.to(torch.bfloat16).reshape(tuple(shape))
 
 
+# ------------------------------------------------------------------------------- outlier-channel profile
+# Real DiT checkpoints are not N(0, 0.02^2): the AdaLN modulation gives a handful of hidden channels a (1 + scale) of 30-100, so the operand of the
+# q|k|v / MLP-in / linear1 GEMMs has a few channels two orders of magnitude above the rest; a couple of residual-stream channels carry "massive
+# activations"; QkNorm weights have a few large dimensions.  Per-token 8-bit grids are exactly what such channels break.  This
+# profile turns any synthetic checkpoint (numpy arrays or torch tensors: plain slicing and in-place arithmetic) into one with those statistics:
+#   * OUT: 12 of the D hidden channels (0.39 %) with amplitudes 30 .. 100, alternating sign — added to the bias of the SCALE rows of every modulation
+#     linear of the blocks (norm1 / norm1_context: rows D..2D and 4D..5D of [shift, scale, gate] x 2; single .norm: rows D..2D; model.rs:211-300), so
+#     LN(x) * (1 + scale) + shift has those channels at 30-100x the others in every block and at every timestep;
+#   * the weight columns that READ those channels (to_q/k/v, add_q/k/v_proj, ff.net.0.proj, ff_context.net.0.proj, single to_q/k/v, proj_mlp) x 1/8: an
+#     outlier channel still contributes ~4-12x a normal one to an output (it stays an important channel), the outputs stay O(1);
+#   * RES: 2 residual-stream channels with +-30 in the bias of x_embedder / context_embedder (massive activations: LayerNorm statistics are dominated by them);
+#   * QkNorm weights (norm_q / norm_k / norm_added_q / norm_added_k): dims 5, 77, 100 of the 128 x 3 (q . k then weighs them 9x).  (x 8 — 64x in the score — makes
+#     the softmax so peaked that the PROBLEM is ill-conditioned: the bf16 path alone is 0.42 from f32 on it, profiles/r06_outlier_study.txt; not a recipe matter.)
+OUTLIER_SEED = 20260930
+
+
+def outlier_channels(D):
+    rng = np.random.default_rng(OUTLIER_SEED)
+    ch = np.sort(rng.choice(D, 14, replace=False))
+    out, res = ch[:12], ch[12:]
+    amp = np.round(np.geomspace(30.0, 100.0, 12)) * np.where(np.arange(12) % 2 == 0, 1.0, -1.0)
+    amp = amp[rng.permutation(12)]
+    return [int(c) for c in out], [float(a) for a in amp], [int(c) for c in res]
+
+
+def apply_outlier_profile(name, t, D, parts=("mod", "cols", "res", "qk"), qk_gain=3.0):
+    """In-place on a numpy array or torch tensor holding tensor `name` of a FLUX checkpoint (already at its final dtype); returns t.
+    `parts` / `qk_gain`: the pieces of the profile one at a time (tools/outlier_study.py)."""
+    out, amp, res = outlier_channels(D)
+    if "mod" not in parts:
+        amp = [0.0] * len(amp)
+    mod_double = name.endswith(("norm1.linear.bias", "norm1_context.linear.bias"))
+    mod_single = ".norm.linear.bias" in name and name.startswith("single_transformer_blocks.")
+    if mod_double or mod_single:
+        for base in ((D, 4 * D) if mod_double else (D,)):
+            for c, a in zip(out, amp):
+                t[base + c] += a
+    elif name.endswith(".weight") and any(name.endswith(k + ".weight") for k in (
+            "attn.to_q", "attn.to_k", "attn.to_v", "attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj", "ff.net.0.proj", "ff_context.net.0.proj", "proj_mlp")):
+        if "cols" in parts:
+            for c in out:
+                t[:, c] *= 0.125
+    elif name in ("x_embedder.bias", "context_embedder.bias"):
+        if "res" in parts:
+            t[res[0]] += 30.0
+            t[res[1]] -= 30.0
+    elif name.endswith(("norm_q.weight", "norm_k.weight", "norm_added_q.weight", "norm_added_k.weight")):
+        if "qk" in parts:
+            for i in (5, 77, 100):
+                t[i] *= qk_gain
+    return t
+
+
 NF4_CODE = [-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635, -0.18477343022823334,
             -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725, 0.24611230194568634, 0.33791524171829224,
             0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0]

@@ -39,7 +39,8 @@ extern "C" {
  *   fmi_sdpa_* / fmi_linear_fp8 / fmi_linear_i8 no longer synchronise the stream or call hipMalloc; + fmi_quantize_rows_i8_asym, fmi_rowsum_i8,
  *   fmi_gemm_i8_asym (the int8 mode's post-GELU operand form); fmi_flux_set_quant_dense_cache accepts -1 (default: by memory) and 3.
  *   + fmi_sdpa_fp8 / fmi_sdpa_fp8_ws (e4m3 P and V as well; op-level only: fmi_flux_set_fp8_attention still accepts 0..2).
- * 6 (round 6): + fmi_release_scratch; + the small f32 seams fmi_timestep_embedding, fmi_rope_table, fmi_rmsnorm_rope.  The op-level entries that use
+ * 6 (round 6): + fmi_release_scratch; + the small f32 seams fmi_timestep_embedding, fmi_rope_table, fmi_rmsnorm_rope; + fmi_flux_calibrate_int8
+ *   (per-channel smoothing of the int8 mode from a calibration; fmi_flux_quantize_int8 without one is unchanged).  The op-level entries that use
  *   the library's per-stream scratch (fmi_sdpa_*, fmi_linear_fp8 / _i8, fmi_groupnorm_nhwc) now enqueue their kernels under one lock: host threads
  *   may share a stream.
  * Additions only: a host bound against version 3 keeps working. */
@@ -264,6 +265,17 @@ int fmi_flux_quantize_fp8(fmi_flux*, void* stream);
 #define FMI_Q8_SINGLE_LINEAR2 32u /* single blocks: proj_out over cat(attention, gelu(mlp)) */
 #define FMI_INT8_DEFAULT_MASK (FMI_Q8_DOUBLE_QKV | FMI_Q8_DOUBLE_OUT | FMI_Q8_SINGLE_LINEAR1 | FMI_Q8_SINGLE_LINEAR2)
 int fmi_flux_quantize_int8(fmi_flux*, unsigned linear_mask, void* stream);
+/* Calibration of the SMOOTHED int8 recipe (ABI 6, round 6).  The per-token grid above is sized by a row's largest element; real DiT activations have a
+ * few hidden channels two orders of magnitude above the rest (their AdaLN (1 + scale) is 30-100 at every step), which would leave the other ~3 000
+ * channels of the row a handful of levels.  fmi_flux_calibrate_int8(m, 1) — bf16 mode, all tensors set — zeroes a set of statistics; from then on every
+ * fmi_flux_forward / fmi_flux_denoise evaluation ALSO folds max |x[:, k]| of each block linear's input into them (the results are unchanged; a handful of
+ * evaluations at timesteps across the schedule is enough: the outlier channels are the same at every step).  The next fmi_flux_quantize_int8 consumes them:
+ *   s[k] = clamp(sqrt(max(amax_x[k], 1e-5) / max(amax_W[k], 1e-5)), 2^-10, 2^10)         (SmoothQuant with alpha = 1/2; amax_W[k] = max_n |W[n, k]|)
+ *   weight codes from W[n, k] * s[k], activation rows from x[m, k] * (1 / s[k]) — both in f32 before the per-row recipe; x W^T is unchanged in exact arithmetic
+ * (the 1 / s multiply rides in the AdaLN-modulate kernel or the row pass that quantises the activation; the GEMMs are untouched) and ends the recording.
+ * fmi_flux_calibrate_int8(m, 0) drops the statistics.  Without a calibration fmi_flux_quantize_int8 is bit for bit the unsmoothed recipe; the e4m3 mode
+ * never smooths (a floating-point grid has no use for it).  Oracle: orc_flux_set_calibration (flux_oracle.cpp, lin_blk mode 5). */
+int fmi_flux_calibrate_int8(fmi_flux*, int enable);
 /* fp8 and int8 modes, attention operands: 1 (default) = q and k leave the fused QKV epilogue as e4m3 with static per-block
  * scales 448 / (sqrt(128) * max|QkNorm weight|) (no element of a normalised, rotated head vector can exceed them) and
  * QK^T runs on the fp8 MFMA; P and V stay bf16.  Applies when both streams of a block take the fused epilogue (token
@@ -546,6 +558,12 @@ int fmi_gemm_q8(const void* xq, const float* x_scale, const void* wq, const floa
  * blocks' MLP-out and the single blocks' linear2.  Stream-ordered, nothing allocated. */
 int fmi_quantize_rows_i8_asym(const void* x, int rows, int K, int d0, int8_t* out, float* scale, float* offset, void* stream);
 int fmi_rowsum_i8(const int8_t* wq, const float* w_scale, int N, int K, int d0, float* w_sum, void* stream);
+/* The smoothed int8 recipe (fmi_flux_calibrate_int8) at the op level (ABI 6): fmi_quantize_rows_i8_scaled = fmi_quantize_rows_i8 (d0 < 0; `offset` unused)
+ * or fmi_quantize_rows_i8_asym (d0 >= 0) on x[r, k] * col_scale[k], the product taken in f32 (col_scale: K floats, 16-byte aligned; 1 / s for an
+ * activation, s for a weight).  fmi_col_absmax folds max_r |x[r, k]| of a bf16 matrix (rows, K) with row stride ld into amax_inout[k] (a running maximum:
+ * zero it first; K, ld % 8 == 0) — the statistic s[k] = sqrt(amax_x[k] / amax_W[k]) is made of. */
+int fmi_quantize_rows_i8_scaled(const void* x, int rows, int K, int d0, const float* col_scale, int8_t* out, float* scale, float* offset, void* stream);
+int fmi_col_absmax(const void* x, int rows, int K, int ld, float* amax_inout, void* stream);
 int fmi_gemm_i8_asym(const void* xq, const float* x_scale, const float* x_offset, const void* wq, const float* w_scale, const float* w_sum,
                      const void* bias, void* y, int M, int N, int K, fmi_epilogue epi, void* stream);
 /* softmax(q k^T * scale) v, q,k,v,o (B,H,L,d) bf16, d == 128, non-causal; o is written

@@ -909,6 +909,12 @@ struct orc_flux {
   int q8_mask = 0x3f;
   int q8_sym = 0;  // 1 = round 4's int8 recipe: every operand symmetric, the post-GELU ones included (orc_flux_set_q8_symmetric; the library's FMI_INT8_SYMMETRIC study switch)
   std::map<const float*, Fp8Weight> fp8_w;
+  // Smoothed int8 recipe (round 6; the library's fmi_flux_calibrate_int8; parity unpinned like the recipe it extends): calib = 1 -> every lin_blk call records
+  // max |x[:, k]| of its input under the weight's address and runs in f32; afterwards the int8 recipe (mode 5) uses, for a linear that has statistics,
+  //   s[k] = clamp(sqrt(max(amax_x[k], 1e-5) / max(amax_W[k], 1e-5)), 2^-10, 2^10), codes of W[n, k] * s[k] and of x[m, k] * (1 / s[k])
+  // (SmoothQuant, alpha = 1/2; x W^T is unchanged in exact arithmetic).  orc_flux_set_calibration: 1 record, 0 stop recording (keep), -1 drop.
+  int calib = 0;
+  std::map<const float*, std::vector<float>> sm_amax, sm_inv;
   int in_channels, pooled_dim, joint_dim, heads, n_double, n_single, guidance;
   int axes[3], theta;
   int D, M;
@@ -1001,6 +1007,11 @@ extern "C" void orc_flux_set_fp8(orc_flux* m, int on) {
 extern "C" void orc_flux_set_fp8_attention(orc_flux* m, int on) { m->fp8_attn = on; }
 extern "C" void orc_flux_set_q8_mask(orc_flux* m, int mask) { m->q8_mask = mask; }
 extern "C" void orc_flux_set_q8_symmetric(orc_flux* m, int on) { m->q8_sym = on; }
+extern "C" void orc_flux_set_calibration(orc_flux* m, int on) {
+  m->calib = on == 1;
+  if (on == 1 || on == -1) m->sm_amax.clear(), m->sm_inv.clear();
+  m->fp8_w.clear();  // (cached weight codes depend on the statistics)
+}
 extern "C" int orc_flux_set_tensor(orc_flux* m, const char* name, const float* data, int64_t numel) {
   m->t[name] = std::vector<float>(data, data + numel);
   m->t16.erase(name);
@@ -1084,9 +1095,43 @@ static void study_quantise(const float* x, int rows, int K, int kind, float* out
 }
 enum { LIN_DBL_QKV = 0, LIN_DBL_OUT = 1, LIN_DBL_MLP1 = 2, LIN_DBL_MLP2 = 3, LIN_SGL_1 = 4, LIN_SGL_2 = 5 };
 void lin_blk(orc_flux* m, const Lin& l, const float* x, int rows, float* y, int which) {
+  if (m->calib) {  // calibration of the smoothed int8 recipe: record the input's column absmax, compute in f32
+    std::vector<float>& a = m->sm_amax[l.w];
+    if (a.empty()) a.assign(l.in, 0.f);
+    for (int r = 0; r < rows; ++r)
+      for (int k = 0; k < l.in; ++k) a[k] = fmaxf(a[k], fabsf(x[(size_t)r * l.in + k]));
+    return lin_fwd(l, x, rows, y);
+  }
   if (!m->fp8 || !((m->q8_mask >> which) & 1)) return lin_fwd(l, x, rows, y);
   if (m->fp8 == 5) {  // THE int8 recipe (what fmi_flux_quantize_int8 implements): exact integer sums, see gemm_i8_exact
     Fp8Weight& fw = m->fp8_w[l.w];
+    std::vector<float> xsm;  // the smoothed input, when this linear has calibration statistics
+    auto st = m->sm_amax.find(l.w);
+    if (st != m->sm_amax.end()) {
+      std::vector<float>& inv = m->sm_inv[l.w];
+      if (inv.empty() || fw.q.empty()) {
+        std::vector<float> s(l.in), ws((size_t)l.out * l.in);
+        inv.resize(l.in);
+        for (int k = 0; k < l.in; ++k) {
+          float wm = 0.f;
+          for (int n = 0; n < l.out; ++n) wm = fmaxf(wm, fabsf(l.w[(size_t)n * l.in + k]));
+          s[k] = fminf(fmaxf(sqrtf(fmaxf(st->second[k], 1e-5f) / fmaxf(wm, 1e-5f)), 0.0009765625f), 1024.0f);
+          inv[k] = 1.0f / s[k];
+        }
+        for (int n = 0; n < l.out; ++n)
+          for (int k = 0; k < l.in; ++k) ws[(size_t)n * l.in + k] = l.w[(size_t)n * l.in + k] * s[k];
+        std::vector<int8_t> codes(ws.size());
+        fw.s.resize(l.out);
+        orc_quantize_rows_i8(ws.data(), l.out, l.in, codes.data(), fw.s.data());
+        fw.q.resize(codes.size());
+        for (size_t i = 0; i < codes.size(); ++i) fw.q[i] = (float)codes[i];
+        fw.wsum.clear();
+      }
+      xsm.resize((size_t)rows * l.in);
+      for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < l.in; ++k) xsm[(size_t)r * l.in + k] = x[(size_t)r * l.in + k] * inv[k];
+      x = xsm.data();
+    }
     if (fw.q.empty()) {
       std::vector<int8_t> codes((size_t)l.out * l.in);
       fw.s.resize(l.out);

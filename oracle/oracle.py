@@ -64,6 +64,8 @@ def lib():
         _lib.orc_linear_i8_asym.restype = None
         _lib.orc_flux_set_q8_symmetric.argtypes = [C.c_void_p, C.c_int]
         _lib.orc_flux_set_q8_symmetric.restype = None
+        _lib.orc_flux_set_calibration.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_flux_set_calibration.restype = None
     return _lib
 
 
@@ -516,6 +518,12 @@ class Flux:
         lib().orc_flux_set_fp8(self.h, 5 if on else 0)
         lib().orc_flux_set_fp8_attention(self.h, (1 | (4 if attention_everywhere else 0)) if (on and attention) else 0)
         lib().orc_flux_set_q8_mask(self.h, int(mask) if on else 0x3f)
+
+    def set_calibration(self, mode):
+        """The smoothed int8 recipe's calibration (flux_oracle.cpp: orc_flux_set_calibration; the library's fmi_flux_calibrate_int8): 1 = record the
+        per-channel absmax of every block linear's input during the following forwards (which run in f32), 0 = stop recording and keep the
+        statistics (set_int8 then uses them: s = sqrt(amax_x / amax_W) per input channel), -1 = drop them (the unsmoothed recipe)."""
+        lib().orc_flux_set_calibration(self.h, int(mode))
 
     def set_q8_mask(self, mask=0x3f):
         """Which block linears take the 8-bit recipe while set_fp8 is on (the others stay f32): bit 0 double q|k|v, 1 double attention

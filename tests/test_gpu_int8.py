@@ -379,3 +379,135 @@ def test_pipeline_int8_end_to_end(env):
     diff = np.abs(a.astype(np.int32) - b.astype(np.int32))
     print(f"int8 pipeline vs bf16 pipeline: max |du8| {int(diff.max())}, mean {float(diff.mean()):.3f}, differing {float((diff > 0).mean()):.3f}")
     assert float((diff <= 8).mean()) >= 0.99
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 6: the smoothed recipe
+@pytest.mark.parametrize("rows,K,d0", [(5, 64, -1), (64, 3072, -1), (300, 15360, 3072), (33, 12288, 0), (7, 4096, -1)])
+def test_quantize_rows_i8_scaled_bit_exact(env, rows, K, d0):
+    """fmi_quantize_rows_i8_scaled = the two row recipes on x[r, k] * col_scale[k] (one f32 product per element): codes, steps and offsets bit for bit
+    against the oracle's quantisers applied to the same f32 products — with a col_scale that spans 2^-10 .. 2^10 like the smoothing factors do, and rows
+    that carry outlier channels (what the factors are for)."""
+    torch, L, lib, orc = env["torch"], env["L"], env["lib"], env["orc"]
+    rng = np.random.default_rng(rows + K + max(d0, 0) + 17)
+    x = _post_gelu_rows(rng, rows, K, max(d0, 0)) if d0 >= 0 else rng.standard_normal((rows, K)).astype(np.float32)
+    out_ch = rng.choice(K, 6, replace=False)
+    x[:, out_ch] *= 60.0
+    x = bf16_round(x)
+    vec = (2.0 ** rng.uniform(-10, 10, K)).astype(np.float32)
+    vec[out_ch] = (1.0 / 60.0)
+    xd, vd = dev(x, torch.bfloat16), dev(vec)
+    q = torch.empty(rows, K, dtype=torch.int8, device="cuda")
+    sc = torch.full((rows,), float("nan"), device="cuda")
+    of = torch.full((rows,), float("nan"), device="cuda")
+    L.check(lib.fmi_quantize_rows_i8_scaled(_p(xd), rows, K, d0, _p(vd), _p(q), _p(sc), _p(of), None))
+    torch.cuda.synchronize()
+    xs = (x * vec[None, :]).astype(np.float32)
+    if d0 >= 0:
+        rq, rs, ro = orc.quantize_rows_i8_asym(xs, d0)
+        np.testing.assert_array_equal(of.cpu().numpy(), ro)
+    else:
+        rq, rs = orc.quantize_rows_i8(xs)
+    np.testing.assert_array_equal(sc.cpu().numpy(), rs)
+    np.testing.assert_array_equal(q.cpu().numpy(), rq)
+    # a vector of ones = the plain entry points, bit for bit
+    ones = dev(np.ones(K, np.float32))
+    q1, s1 = torch.empty_like(q), torch.empty_like(sc)
+    L.check(lib.fmi_quantize_rows_i8_scaled(_p(xd), rows, K, d0, _p(ones), _p(q1), _p(s1), _p(of), None))
+    q2, s2, o2 = torch.empty_like(q), torch.empty_like(sc), torch.empty_like(sc)
+    if d0 >= 0:
+        L.check(lib.fmi_quantize_rows_i8_asym(_p(xd), rows, K, d0, _p(q2), _p(s2), _p(o2), None))
+    else:
+        L.check(lib.fmi_quantize_rows_i8(_p(xd), rows, K, _p(q2), _p(s2), None))
+    torch.cuda.synchronize()
+    assert torch.equal(q1, q2) and torch.equal(s1, s2)
+    assert lib.fmi_quantize_rows_i8_scaled(_p(xd), rows, K, d0, None, _p(q), _p(sc), _p(of), None) < 0
+
+
+def test_col_absmax(env):
+    torch, L, lib = env["torch"], env["L"], env["lib"]
+    rng = np.random.default_rng(5)
+    for rows, K, ld in ((1, 8, 8), (300, 3072, 3072), (4608, 15360, 21504), (70000, 64, 72)):
+        x = bf16_round(rng.standard_normal((rows, ld)).astype(np.float32) * (10.0 ** rng.uniform(-3, 3, (1, ld))).astype(np.float32))
+        xd = dev(x, torch.bfloat16)
+        am = torch.zeros(K, device="cuda")
+        L.check(lib.fmi_col_absmax(_p(xd), rows // 2, K, ld, _p(am), None))                      # a running maximum: two calls over the two halves
+        L.check(lib.fmi_col_absmax(_p(xd[rows // 2:]), rows - rows // 2, K, ld, _p(am), None))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(am.cpu().numpy(), np.abs(x[:, :K]).max(0))
+    assert lib.fmi_col_absmax(_p(xd), 4, 64, 60, _p(am), None) < 0
+
+
+def test_flux_forward_int8_smoothed_on_outlier_channels(env):
+    """The smoothed int8 recipe end to end at a small config WITH the outlier-channel profile (synth.apply_outlier_profile: 12 hidden channels whose AdaLN
+    (1 + scale) is 30-100, massive residual channels, x 8 QkNorm dimensions): fmi_flux_calibrate_int8 + 3 evaluations + fmi_flux_quantize_int8 against
+    (i) the f32 oracle — inside the 8-bit bar where the unsmoothed recipe is far outside —, (ii) the oracle's restatement of the smoothed recipe
+    (orc_flux_set_calibration on the same calibration inputs), statistically as for the other 8-bit recipes, (iii) calibration leaves the bf16 results
+    untouched, (iv) the guards."""
+    torch, d, orc = env["torch"], env["d"], env["orc"]
+    cfg = dict(SMALL_FLUX, num_attention_heads=4)  # D = 512: room for 12 outlier channels (2.3 %)
+    D = 512
+    sd = d.synth.flux_state_dict_numpy(cfg, seed=21)
+    sd = {k: bf16_round(d.synth.apply_outlier_profile(k, v.copy(), D)) for k, v in sd.items()}
+    B, S_hw, T = 1, (16, 16), 64
+    img, ids, txt, txt_ids, y = flux_inputs(cfg, B, S_hw, T, seed=3)
+    g = np.full(B, 3.5, np.float32)
+    cal_ts = (0.95, 0.6, 0.2)
+    t_eval = np.array([0.45], np.float32)
+    mk = lambda tt: (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(np.array([tt], np.float32)), dev(y), dev(g))
+    of_ = orc.Flux(cfg)
+    of_.load(sd)
+    ref = of_.forward(img, ids, txt, txt_ids, t_eval, y, g)
+    rows = {}
+    for smooth in (False, True):
+        m = d.FluxModel(cfg)
+        try:
+            m.load_state_dict(sd)
+            base = host(m.forward(*mk(float(t_eval[0]))))
+            if smooth:
+                m.calibrate_int8(True)
+                for tt in cal_ts:
+                    m.forward(*mk(tt))
+                np.testing.assert_array_equal(host(m.forward(*mk(float(t_eval[0])))), base)  # recording does not change results
+            m.quantize_int8()
+            got = host(m.forward(*mk(float(t_eval[0]))))
+            rows[smooth] = (rel_l2(got, ref), rel_l2(base, ref), got)
+            if smooth:
+                with pytest.raises(env["L"].FmiError):
+                    m.calibrate_int8(True)  # the model already holds an 8-bit form
+        finally:
+            m.close()
+    # the oracle's restatement: calibrate on the same evaluations (f32), then the int8 recipe with the same mask and e4m3 q / k
+    o8 = orc.Flux(cfg)
+    o8.load(sd)
+    o8.set_calibration(1)
+    for tt in cal_ts + (float(t_eval[0]),):
+        o8.forward(img, ids, txt, txt_ids, np.array([tt], np.float32), y, g)
+    o8.set_calibration(0)
+    o8.set_int8(True, d.flux.INT8_DEFAULT_MASK, attention=True)
+    ref8 = o8.forward(img, ids, txt, txt_ids, t_eval, y, g)
+    o8.set_int8(False)
+    o8.set_calibration(-1)
+    o8.set_int8(True, d.flux.INT8_DEFAULT_MASK, attention=True)
+    ref8_plain = o8.forward(img, ids, txt, txt_ids, t_eval, y, g)
+    o8.set_int8(False)
+    e_plain, e_bf16, _ = rows[False]
+    e_sm, _, got_sm = rows[True]
+    noise, noise_plain = rel_l2(ref8, ref), rel_l2(ref8_plain, ref)
+    print(f"outlier-profile small model (D=512, 2 + 2 blocks): bf16 {e_bf16:.3e}; int8 unsmoothed {e_plain:.3e} (its oracle: {noise_plain:.3e}); "
+          f"int8 SMOOTHED {e_sm:.3e} vs f32, {rel_l2(got_sm, ref8):.3e} vs the smoothed-recipe oracle (recipe noise {noise:.3e})")
+    assert np.isfinite(got_sm).all() and not np.array_equal(got_sm, rows[False][2])
+    # at 2 + 2 blocks the gates (~1e-2) keep every recipe's noise far below the bf16 path's own 1.6e-3, so the GPU rows can only be held to the bf16 bars; what the
+    # smoothing buys shows in the ORACLE's recipe noise (f32 everywhere else) — and, at full depth, in tests/test_gpu_outlier_stats.py (1.9e-1 -> 2.4e-2)
+    assert e_sm <= 1e-2 and rel_l2(got_sm, ref8) <= 1e-2
+    assert noise <= 0.6 * noise_plain
+    m2 = d.FluxModel(cfg)
+    try:
+        m2.load_state_dict(sd)
+        m2.calibrate_int8(True)
+        with pytest.raises(env["L"].FmiError):
+            m2.quantize_int8()  # calibration on, no evaluation yet
+        m2.calibrate_int8(False)
+        m2.quantize_int8()      # dropped: the unsmoothed recipe, as before
+        np.testing.assert_array_equal(host(m2.forward(*mk(float(t_eval[0])))), rows[False][2])
+    finally:
+        m2.close()
