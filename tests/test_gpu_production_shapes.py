@@ -550,6 +550,31 @@ def test_c2_int8_full_model_forward_is_within_the_8_bit_tolerance(full_models):
             e5 = rel_l2(got5, r5)
             print(f"  C5 shape (S=3600 + T=512) in int8 mode vs the f32 oracle: {e5:.3e}")
             assert np.isfinite(got5).all() and e5 <= 3e-2
+        # round 6: the CALIBRATED recipe (per-channel smoothing, fmi_flux_calibrate_int8 — what Pipeline(dtype=I8) and bench.py's int8 legs run) on the same forward
+        # and the C5 shape: on this Gaussian checkpoint it must be neutral (the outlier-channel checkpoint is tests/test_gpu_outlier_stats.py)
+        g8s = d.FluxModel(cfg)
+        try:
+            for name, shape in d.synth.flux_tensor_shapes(d.FLUX_DEV).items():
+                g8s.set_tensor(name, _seeded_weight(torch, name, shape, d))
+            g8s.calibrate_int8(True)
+            for tt in (1.0, 0.75, 0.5, 0.25):
+                g8s.forward(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(np.array([tt], np.float32)), dev(clip), dev(g))
+            g8s.quantize_int8()
+            es = rel_l2(host(g8s.forward(dev(img), dev(ids), dev(t5, torch.bfloat16), dev(txt_ids), dev(t), dev(clip), dev(g))), ref)
+            line = f"  CALIBRATED (smoothed) int8 recipe on the same forward: {es:.3e}"
+            assert es <= 3e-2
+            if "c5" in full_models:
+                es5 = rel_l2(host(g8s.forward(dev(i5), dev(d5), dev(t55, torch.bfloat16), dev(x5), dev(tt5), dev(c5), dev(g5))), r5)
+                line += f"; at the C5 shape {es5:.3e}"
+                assert es5 <= 3e-2
+            if "traj50" in full_models:
+                gs50 = host(g8s.denoise(dev(tj["img"]), *a8, tj["ts"]))
+                es50 = rel_l2(gs50, tj["ref"][50])
+                line += f"; 50-step latents (S=192 + T=64; calibrated at S=4096) {es50:.3e}"
+                assert es50 <= INT8_TRAJ_BAR
+            print(line)
+        finally:
+            g8s.close()
         # the other mask worth knowing at full size (round 5): with / without the double blocks' MLP-out in 8 bits — the knapsack of DESIGN 4.3c, measured
         other = d.flux.INT8_DEFAULT_MASK ^ d.flux.Q8_DOUBLE_MLP_OUT
         g8b = d.FluxModel(cfg)

@@ -288,3 +288,18 @@ def test_no_entry_point_of_the_op_seam_synchronises_or_allocates_in_source():
     ops = code[code.index('extern "C" size_t fmi_linear_q8_workspace_bytes'):code.index('extern "C" int fmi_set_attention_kernel')]
     for banned in ("hipMalloc", "hipFree", "Synchronize", "hipMemcpy("):
         assert banned not in ops, banned
+
+
+def test_design_status_table_is_generated():
+    """DESIGN.md section 0's status table is the output of tools/status_table.py on the round's committed bench line (generated, not typed)."""
+    import subprocess
+    import sys
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import status_table as st
+    a, b = design.index(st.BEGIN), design.index(st.END) + len(st.END)
+    block = design[a:b]
+    src = block.split("Source: `")[1].split("`")[0]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "status_table.py"), os.path.join(ROOT, src)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert r.stdout.strip() == block.strip(), "DESIGN.md's status block differs from tools/status_table.py's output: run `python tools/status_table.py --write <bench json>`"
