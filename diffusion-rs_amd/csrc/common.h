@@ -366,9 +366,9 @@ int launch_rowsum_i8(const int8_t* wq, const float* w_scale, int N, int K, int d
 // launch_layernorm_mod with the row quantisation fused (values quantised from f32, not via bf16)
 int launch_layernorm_mod_fp8(const float* x, const float* scale, const float* shift, int mod_bstride, int rows_per_batch,
                              uint8_t* out, float* out_scale, int rows, int D, float eps, hipStream_t stream, int kind = 1, const float* smooth = nullptr);
-// calibration of the smoothed int8 recipe (fp8.hip): column absmax of a bf16 matrix folded into amax (atomic max), and s = sqrt(a / w), 1 / s
+// calibration of the smoothed int8 recipe (fp8.hip): column absmax of a bf16 matrix folded into amax (atomic max), and the factors s, 1 / s from the two statistics
 int launch_col_absmax(const bf16_t* x, int ld, int rows, int K, float* amax, hipStream_t stream);
-int launch_smooth_factors(const float* act_amax, const float* w_amax, int K, float* s_out, float* inv_out, hipStream_t stream);
+void smooth_factors_host(const float* act_amax, const float* w_amax, int K, float* s_out, float* inv_out);  // host arrays; median-floored SmoothQuant (fp8.hip)
 int launch_gemv(const float* x, const bf16_t* W, const bf16_t* bias, float* y, int M, int N, int K,
                 int silu_in, int accumulate, hipStream_t stream);
 // bf16 out = w_i8 * SCB[row] / 127 (dequant.cu:205-214) on `stream`

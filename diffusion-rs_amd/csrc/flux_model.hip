@@ -1717,7 +1717,15 @@ static int quantize_8bit(fmi_flux* m, int kind, unsigned mask, void* stream) {
       // s[k] = sqrt(max |x[:, k]| / max |W[:, k]|): the weights' column absmax into the scratch row, then the factors; the codes come from W * s
       FMI_HIP_TRY(hipMemsetAsync(m->calib_wmax, 0, (size_t)d->K * sizeof(float), s));
       FMI_TRY(launch_col_absmax(d->w, d->K, d->N, d->K, m->calib_wmax, s));
-      FMI_TRY(launch_smooth_factors(d->sm_amax, m->calib_wmax, d->K, d->sm_s, d->sm_inv_store, s));
+      // the factors are made on the host (medians; once per linear, K <= 16384): two small copies down, two up, ordered on `s`
+      std::vector<float> ha(d->K), hw(d->K), hs(d->K), hi(d->K);
+      FMI_HIP_TRY(hipMemcpyAsync(ha.data(), d->sm_amax, (size_t)d->K * sizeof(float), hipMemcpyDeviceToHost, s));
+      FMI_HIP_TRY(hipMemcpyAsync(hw.data(), m->calib_wmax, (size_t)d->K * sizeof(float), hipMemcpyDeviceToHost, s));
+      FMI_HIP_TRY(hipStreamSynchronize(s));
+      smooth_factors_host(ha.data(), hw.data(), d->K, hs.data(), hi.data());
+      FMI_HIP_TRY(hipMemcpyAsync(d->sm_s, hs.data(), (size_t)d->K * sizeof(float), hipMemcpyHostToDevice, s));
+      FMI_HIP_TRY(hipMemcpyAsync(d->sm_inv_store, hi.data(), (size_t)d->K * sizeof(float), hipMemcpyHostToDevice, s));
+      FMI_HIP_TRY(hipStreamSynchronize(s));  // (the host vectors go out of scope)
       d->sm_inv = d->sm_inv_store;
       wvec = d->sm_s;
     }

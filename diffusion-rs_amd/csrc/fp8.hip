@@ -25,6 +25,8 @@
 // Both kernels are one pass over HBM per row block: a 256-thread block owns a row, keeps it in
 // registers between the absmax reduction and the conversion, 16-byte loads, 8-byte stores.
 #include <algorithm>
+#include <cmath>
+#include <vector>
 
 #include "common.h"
 
@@ -299,13 +301,6 @@ __global__ __launch_bounds__(256) void col_absmax_kernel(const bf16_t* __restric
   for (int e = 0; e < 8; ++e)
     if (m[e] == m[e]) atomicMax(reinterpret_cast<unsigned int*>(amax) + 8 * i + e, __float_as_uint(m[e]));  // (a NaN would order above everything: dropped)
 }
-__global__ void smooth_factors_kernel(const float* __restrict a, const float* __restrict w, int K, float* __restrict s_out, float* __restrict inv_out) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= K) return;
-  const float s = fminf(fmaxf(sqrtf(fmaxf(a[k], 1e-5f) / fmaxf(w[k], 1e-5f)), 0.0009765625f), 1024.0f);
-  s_out[k] = s;
-  inv_out[k] = 1.0f / s;
-}
 }  // namespace
 
 int launch_quantize_rows_fp8(const bf16_t* x, int ld, int rows, int K, uint8_t* out, float* scale, hipStream_t stream, int kind, const float* vec) {
@@ -370,12 +365,29 @@ int launch_col_absmax(const bf16_t* x, int ld, int rows, int K, float* amax, hip
   FMI_LAUNCH_CHECK();
   return FMI_OK;
 }
-// s[k] = clamp(sqrt(max(a[k], 1e-5) / max(w[k], 1e-5)), 2^-10, 2^10), inv_s[k] = 1 / s[k]   (SmoothQuant with alpha = 1/2)
-int launch_smooth_factors(const float* act_amax, const float* w_amax, int K, float* s_out, float* inv_out, hipStream_t stream) {
-  if (K <= 0) return FMI_OK;
-  hipLaunchKernelGGL(smooth_factors_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, act_amax, w_amax, K, s_out, inv_out);
-  FMI_LAUNCH_CHECK();
-  return FMI_OK;
+// The smoothing factors of one linear, on the HOST (K <= 16384 values, once per linear at quantise time): SmoothQuant with alpha = 1/2 FOR OUTLIERS ONLY —
+//   A[k] = amax_x[k] / median(amax_x),  W[k] = amax_W[k] / median(amax_W);  s[k] = sqrt(ra / rw) (<= 2^10), ra = A - 1 if A > 2 else 1, rw = W / (1 - W) if W < 1/2 (W >= 1/64) else 1;  inv[k] = 1 / s[k].
+// A channel within twice the median activation whose weight column is not unusually small has s = 1 EXACTLY: on a checkpoint without outlier channels the smoothed recipe IS
+// the unsmoothed one, and a short calibration cannot create outliers of its own.  (Plain SmoothQuant — every channel's factor from its own maxima — does: a channel that was quiet
+// while calibrating, an AdaLN (1 + scale) near 0 at those timesteps or for that prompt, is amplified at inference; measured on a model calibrated on one sample and evaluated on
+// another: 2.46e-2 -> 3.45e-2.  Equalising the two segments of linear2's input was measured too: 2.2e-2 -> 2.7e-2, it fights the offset grid's shared step.)  Only the genuine
+// outliers — the 30-100x channels the smoothing exists for — get a factor: sqrt of how far they stand out, times sqrt of how small their weight column is.
+// Same function in the oracle (flux_oracle.cpp: smooth_factors_host).
+void smooth_factors_host(const float* act_amax, const float* w_amax, int K, float* s_out, float* inv_out) {
+  std::vector<float> t(act_amax, act_amax + K);
+  std::nth_element(t.begin(), t.begin() + K / 2, t.end());
+  const float med_a = std::max(t[K / 2], 1e-20f);
+  t.assign(w_amax, w_amax + K);
+  std::nth_element(t.begin(), t.begin() + K / 2, t.end());
+  const float med_w = std::max(t[K / 2], 1e-20f);
+  for (int k = 0; k < K; ++k) {
+    const float A = act_amax[k] / med_a, W = w_amax[k] / med_w;  // how far the channel stands out of the median, on either side
+    const float ra = A > 2.0f ? A - 1.0f : 1.0f;                                           // 1 up to twice the median, then continuous and ~A for a genuine outlier
+    const float rw = W < 0.5f ? std::max(W, 0.015625f) / (1.0f - std::max(W, 0.015625f)) : 1.0f;  // 1 down to half the median, then continuous and ~W for a small column
+    const float s = std::min(sqrtf(ra / rw), 1024.0f);
+    s_out[k] = s;
+    inv_out[k] = 1.0f / s;
+  }
 }
 
 }  // namespace fmi

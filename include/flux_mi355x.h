@@ -270,7 +270,10 @@ int fmi_flux_quantize_int8(fmi_flux*, unsigned linear_mask, void* stream);
  * channels of the row a handful of levels.  fmi_flux_calibrate_int8(m, 1) — bf16 mode, all tensors set — zeroes a set of statistics; from then on every
  * fmi_flux_forward / fmi_flux_denoise evaluation ALSO folds max |x[:, k]| of each block linear's input into them (the results are unchanged; a handful of
  * evaluations at timesteps across the schedule is enough: the outlier channels are the same at every step).  The next fmi_flux_quantize_int8 consumes them:
- *   s[k] = clamp(sqrt(max(amax_x[k], 1e-5) / max(amax_W[k], 1e-5)), 2^-10, 2^10)         (SmoothQuant with alpha = 1/2; amax_W[k] = max_n |W[n, k]|)
+ *   A[k] = amax_x[k] / median(amax_x),  W[k] = amax_W[k] / median(amax_W)      (amax_W[k] = max_n |W[n, k]|)
+ *   s[k] = min(sqrt(ra / rw), 2^10),  ra = A - 1 if A > 2 else 1,  rw = W / (1 - W) if W < 1/2 (W floored at 1/64) else 1      (continuous; ~sqrt(A / W) for a genuine outlier)
+ *   — SmoothQuant with alpha = 1/2 for the channels that stand out of the median ONLY: every other channel has s = 1 exactly, so a checkpoint without outlier channels
+ *   quantises as without calibration, and a short calibration cannot create outliers of its own
  *   weight codes from W[n, k] * s[k], activation rows from x[m, k] * (1 / s[k]) — both in f32 before the per-row recipe; x W^T is unchanged in exact arithmetic
  * (the 1 / s multiply rides in the AdaLN-modulate kernel or the row pass that quantises the activation; the GEMMs are untouched) and ends the recording.
  * fmi_flux_calibrate_int8(m, 0) drops the statistics.  Without a calibration fmi_flux_quantize_int8 is bit for bit the unsmoothed recipe; the e4m3 mode

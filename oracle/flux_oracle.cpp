@@ -911,8 +911,8 @@ struct orc_flux {
   std::map<const float*, Fp8Weight> fp8_w;
   // Smoothed int8 recipe (round 6; the library's fmi_flux_calibrate_int8; parity unpinned like the recipe it extends): calib = 1 -> every lin_blk call records
   // max |x[:, k]| of its input under the weight's address and runs in f32; afterwards the int8 recipe (mode 5) uses, for a linear that has statistics,
-  //   s[k] = clamp(sqrt(max(amax_x[k], 1e-5) / max(amax_W[k], 1e-5)), 2^-10, 2^10), codes of W[n, k] * s[k] and of x[m, k] * (1 / s[k])
-  // (SmoothQuant, alpha = 1/2; x W^T is unchanged in exact arithmetic).  orc_flux_set_calibration: 1 record, 0 stop recording (keep), -1 drop.
+  //   s[k] from smooth_factors_host (SmoothQuant, alpha = 1/2, for the channels that stand out of the median only), codes of W[n, k] * s[k] and of x[m, k] * (1 / s[k])
+  // (x W^T is unchanged in exact arithmetic).  orc_flux_set_calibration: 1 record, 0 stop recording (keep), -1 drop.
   int calib = 0;
   std::map<const float*, std::vector<float>> sm_amax, sm_inv;
   int in_channels, pooled_dim, joint_dim, heads, n_double, n_single, guidance;
@@ -1093,6 +1093,25 @@ static void study_quantise(const float* x, int rows, int K, int kind, float* out
     }
   }
 }
+// The smoothing factors of one linear (the library's fp8.hip: smooth_factors_host, same arithmetic): SmoothQuant, alpha = 1/2, for outliers only —
+//   A[k] = amax_x[k] / median(amax_x), W[k] = amax_W[k] / median(amax_W); s[k] = sqrt(ra / rw) (<= 2^10), ra = A - 1 if A > 2 else 1, rw = W / (1 - W) if W < 1/2 (W >= 1/64) else 1; inv[k] = 1 / s[k]
+// (s = 1 exactly for every channel that is no outlier: a short calibration cannot create outliers of its own, and without outlier channels the recipe is the unsmoothed one).
+static void smooth_factors_host(const float* act_amax, const float* w_amax, int K, float* s_out, float* inv_out) {
+  std::vector<float> t(act_amax, act_amax + K);
+  std::nth_element(t.begin(), t.begin() + K / 2, t.end());
+  const float med_a = std::max(t[K / 2], 1e-20f);
+  t.assign(w_amax, w_amax + K);
+  std::nth_element(t.begin(), t.begin() + K / 2, t.end());
+  const float med_w = std::max(t[K / 2], 1e-20f);
+  for (int k = 0; k < K; ++k) {
+    const float A = act_amax[k] / med_a, W = w_amax[k] / med_w;  // how far the channel stands out of the median, on either side
+    const float ra = A > 2.0f ? A - 1.0f : 1.0f;                                           // 1 up to twice the median, then continuous and ~A for a genuine outlier
+    const float rw = W < 0.5f ? std::max(W, 0.015625f) / (1.0f - std::max(W, 0.015625f)) : 1.0f;  // 1 down to half the median, then continuous and ~W for a small column
+    const float s = std::min(sqrtf(ra / rw), 1024.0f);
+    s_out[k] = s;
+    inv_out[k] = 1.0f / s;
+  }
+}
 enum { LIN_DBL_QKV = 0, LIN_DBL_OUT = 1, LIN_DBL_MLP1 = 2, LIN_DBL_MLP2 = 3, LIN_SGL_1 = 4, LIN_SGL_2 = 5 };
 void lin_blk(orc_flux* m, const Lin& l, const float* x, int rows, float* y, int which) {
   if (m->calib) {  // calibration of the smoothed int8 recipe: record the input's column absmax, compute in f32
@@ -1110,14 +1129,11 @@ void lin_blk(orc_flux* m, const Lin& l, const float* x, int rows, float* y, int 
     if (st != m->sm_amax.end()) {
       std::vector<float>& inv = m->sm_inv[l.w];
       if (inv.empty() || fw.q.empty()) {
-        std::vector<float> s(l.in), ws((size_t)l.out * l.in);
+        std::vector<float> s(l.in), ws((size_t)l.out * l.in), wmx(l.in, 0.f);
         inv.resize(l.in);
-        for (int k = 0; k < l.in; ++k) {
-          float wm = 0.f;
-          for (int n = 0; n < l.out; ++n) wm = fmaxf(wm, fabsf(l.w[(size_t)n * l.in + k]));
-          s[k] = fminf(fmaxf(sqrtf(fmaxf(st->second[k], 1e-5f) / fmaxf(wm, 1e-5f)), 0.0009765625f), 1024.0f);
-          inv[k] = 1.0f / s[k];
-        }
+        for (int n = 0; n < l.out; ++n)
+          for (int k = 0; k < l.in; ++k) wmx[k] = fmaxf(wmx[k], fabsf(l.w[(size_t)n * l.in + k]));
+        smooth_factors_host(st->second.data(), wmx.data(), l.in, s.data(), inv.data());
         for (int n = 0; n < l.out; ++n)
           for (int k = 0; k < l.in; ++k) ws[(size_t)n * l.in + k] = l.w[(size_t)n * l.in + k] * s[k];
         std::vector<int8_t> codes(ws.size());

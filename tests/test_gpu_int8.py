@@ -454,6 +454,8 @@ def test_flux_forward_int8_smoothed_on_outlier_channels(env):
     cal_ts = (0.95, 0.6, 0.2)
     t_eval = np.array([0.45], np.float32)
     mk = lambda tt: (dev(img), dev(ids), dev(txt, torch.bfloat16), dev(txt_ids), dev(np.array([tt], np.float32)), dev(y), dev(g))
+    c_img, _, c_txt, _, c_y = flux_inputs(cfg, B, S_hw, T, seed=4)  # the calibration sees another sample than the evaluation
+    mkc = lambda tt: (dev(c_img), dev(ids), dev(c_txt, torch.bfloat16), dev(txt_ids), dev(np.array([tt], np.float32)), dev(c_y), dev(g))
     of_ = orc.Flux(cfg)
     of_.load(sd)
     ref = of_.forward(img, ids, txt, txt_ids, t_eval, y, g)
@@ -466,7 +468,7 @@ def test_flux_forward_int8_smoothed_on_outlier_channels(env):
             if smooth:
                 m.calibrate_int8(True)
                 for tt in cal_ts:
-                    m.forward(*mk(tt))
+                    m.forward(*mkc(tt))
                 np.testing.assert_array_equal(host(m.forward(*mk(float(t_eval[0])))), base)  # recording does not change results
             m.quantize_int8()
             got = host(m.forward(*mk(float(t_eval[0]))))
@@ -480,8 +482,8 @@ def test_flux_forward_int8_smoothed_on_outlier_channels(env):
     o8 = orc.Flux(cfg)
     o8.load(sd)
     o8.set_calibration(1)
-    for tt in cal_ts + (float(t_eval[0]),):
-        o8.forward(img, ids, txt, txt_ids, np.array([tt], np.float32), y, g)
+    for tt in cal_ts:
+        o8.forward(c_img, ids, c_txt, txt_ids, np.array([tt], np.float32), c_y, g)
     o8.set_calibration(0)
     o8.set_int8(True, d.flux.INT8_DEFAULT_MASK, attention=True)
     ref8 = o8.forward(img, ids, txt, txt_ids, t_eval, y, g)

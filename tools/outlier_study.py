@@ -3,7 +3,8 @@
 
 FLUX.1-dev at full width and depth, one Flux::forward at 1024 + 128 tokens against the f32 oracle on the same weights, for several subsets of the profile
 (AdaLN scale outliers "mod", the reading columns x 1/8 "cols", massive residual channels "res", QkNorm x gain "qk") and per mode: bf16; bf16 + e4m3 q / k;
-int8 unsmoothed / smoothed, each with bf16 and with e4m3 attention operands; e4m3.
+int8 unsmoothed / smoothed (calibrated on a DIFFERENT sample: other latents, text and pooled vector, timesteps 1 / .75 / .5 / .25), each with bf16 and with e4m3 attention
+operands; e4m3.
 
     python tools/outlier_study.py [--variants all] > profiles/r06_outlier_study.txt
 """
@@ -40,6 +41,10 @@ def main():
     t = torch.tensor([0.6], device="cuda")
     g = torch.tensor([3.5], device="cuda")
     args = (img, ids, t5, txt_ids, t, clip, g)
+    # the calibration sees ANOTHER sample (latents, text, pooled vector) at four other timesteps: the statistics must carry over
+    c_img, _ = d.pack_latents(S.exact_tensor_device("input.calib.latent", (1, 16, 2 * h2, 2 * w2), "input").float())
+    c_t5 = S.exact_tensor_device("input.calib.t5", (1, a.txt, cfg["joint_attention_dim"]), "input")
+    c_clip = S.exact_tensor_device("input.calib.clip", (1, cfg["pooled_projection_dim"]), "input").float()
     print(f"# FLUX.1-dev 19 + 38 blocks, one Flux::forward at {h2 * w2} + {a.txt} tokens, rel-L2 vs the f32 oracle on the same weights")
     print(f"# {'profile':28s} {'bf16':>9s} {'bf16+qk8':>9s} {'i8':>9s} {'i8 qk-bf16':>10s} {'i8 smooth':>9s} {'i8s qk-bf16':>11s} {'e4m3':>9s} {'e4m3 qk-bf16':>12s}")
     for var in a.variants.split(";"):
@@ -75,7 +80,7 @@ def main():
         def calib(m):
             m.calibrate_int8(True)
             for tt in (1.0, 0.75, 0.5, 0.25):
-                m.forward(img, ids, t5, txt_ids, torch.tensor([tt], device="cuda"), clip, g)
+                m.forward(c_img, ids, c_t5, txt_ids, torch.tensor([tt], device="cuda"), c_clip, g)
 
         row.append(run(lambda m: None))
         row.append(run(lambda m: m.set_fp8_attention(2)))
