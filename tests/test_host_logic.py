@@ -303,3 +303,29 @@ def test_design_status_table_is_generated():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "status_table.py"), os.path.join(ROOT, src)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr[-500:]
     assert r.stdout.strip() == block.strip(), "DESIGN.md's status block differs from tools/status_table.py's output: run `python tools/status_table.py --write <bench json>`"
+
+
+def test_outlier_profile_is_deterministic_and_the_same_on_numpy_and_torch():
+    """synth.apply_outlier_profile (the off-Gaussian stress checkpoint of tests/test_gpu_outlier_stats.py): fixed channels and amplitudes, the same edit whether
+    the tensor is a numpy array (oracle side of the small-config test) or a torch tensor (device side), and untouched tensors stay untouched."""
+    import torch
+    S = d.synth
+    D = 3072
+    out, amp, res = S.outlier_channels(D)
+    assert (out, res) == S.outlier_channels(D)[::2] and len(out) == 12 and len(set(out) | set(res)) == 14
+    assert sorted(abs(a) for a in amp)[0] >= 30 and sorted(abs(a) for a in amp)[-1] <= 100 and any(a < 0 for a in amp) and any(a > 0 for a in amp)
+    rng = np.random.default_rng(0)
+    cases = {"transformer_blocks.3.norm1.linear.bias": (6 * D,), "single_transformer_blocks.9.norm.linear.bias": (3 * D,), "transformer_blocks.0.attn.to_q.weight": (64, D),
+             "single_transformer_blocks.1.proj_mlp.weight": (32, D), "x_embedder.bias": (D,), "transformer_blocks.2.attn.norm_added_k.weight": (128,),
+             "transformer_blocks.0.ff.net.2.weight": (16, 4 * D), "proj_out.weight": (64, D), "transformer_blocks.3.norm1.linear.weight": (12, D)}
+    for name, shape in cases.items():
+        a = rng.standard_normal(shape).astype(np.float32)
+        n = S.apply_outlier_profile(name, a.copy(), D)
+        t = S.apply_outlier_profile(name, torch.from_numpy(a.copy()), D).numpy()
+        np.testing.assert_array_equal(n, t)
+        touched = not np.array_equal(n, a)
+        assert touched == (name not in ("transformer_blocks.0.ff.net.2.weight", "proj_out.weight", "transformer_blocks.3.norm1.linear.weight")), name
+    b = S.apply_outlier_profile("transformer_blocks.3.norm1.linear.bias", np.zeros(6 * D, np.float32), D)
+    assert sorted(np.nonzero(b)[0].tolist()) == sorted([D + c for c in out] + [4 * D + c for c in out])  # the SCALE rows of (shift, scale, gate) x 2
+    q = S.apply_outlier_profile("transformer_blocks.0.attn.norm_q.weight", np.ones(128, np.float32), D)
+    assert q[[5, 77, 100]].tolist() == [3.0, 3.0, 3.0] and q.sum() == 128 + 6

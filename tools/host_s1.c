@@ -305,12 +305,11 @@ int main(int argc, char** argv) {
   fmi_vae* vae = NULL;
   CHECK(fmi_vae_create(&vc, FMI_MODEL_BF16, &vae));
   load_vae(vae, &vc);
-  if (!strcmp(mode, "int8")) CHECK(fmi_flux_quantize_int8(flux, 0x33, NULL));
-  else if (!strcmp(mode, "fp8")) CHECK(fmi_flux_quantize_fp8(flux, NULL));
-  else if (strcmp(mode, "bf16")) {
+  if (strcmp(mode, "int8") && strcmp(mode, "fp8") && strcmp(mode, "bf16")) {
     fprintf(stderr, "host_s1: unknown mode %s\n", mode);
     return 2;
   }
+  if (!strcmp(mode, "fp8")) CHECK(fmi_flux_quantize_fp8(flux, NULL));
   const double t_loaded = now_s();
 
   /* ---- FluxPipeline::forward for one prompt: conditioning (what T5 / CLIP would hand over), noise, schedule */
@@ -355,6 +354,27 @@ int main(int argc, char** argv) {
   in.txt = t5_d, in.txt_dtype = FMI_BF16, in.txt_ids = (const float*)txt_ids_d;
   in.y = clip_d, in.y_dtype = FMI_F32, in.guidance = (const float*)g_d;
   in.B = B, in.S = S, in.T = T, in.ids_per_sample = 0;
+  if (!strcmp(mode, "int8")) {
+    /* the int8 mode is calibrated (ABI 6): four bf16 evaluations across the schedule record the per-channel maxima of every block linear's input, then the
+     * block linears are quantised with the smoothing factors folded in — what Pipeline(dtype = I8) does at its first request */
+    void *t_d, *pred_d;
+    CHECK(fmi_malloc(&t_d, 4));
+    CHECK(fmi_malloc(&pred_d, (size_t)S * 64 * 4));
+    CHECK(fmi_flux_calibrate_int8(flux, 1));
+    const int pts[4] = {0, (steps - 1) / 3, 2 * (steps - 1) / 3, steps - 1};
+    for (int i = 0; i < 4; ++i) {
+      if (i && pts[i] == pts[i - 1]) continue;
+      const float t_h = (float)ts[pts[i]];
+      CHECK(fmi_memcpy(t_d, &t_h, 4, NULL));
+      CHECK(fmi_stream_synchronize(NULL));
+      in.timesteps = (const float*)t_d;
+      CHECK(fmi_flux_forward(flux, &in, (float*)pred_d, NULL));
+    }
+    in.timesteps = NULL;
+    CHECK(fmi_flux_quantize_int8(flux, FMI_INT8_DEFAULT_MASK, NULL));
+    CHECK(fmi_free(t_d));
+    CHECK(fmi_free(pred_d));
+  }
   void *e0, *e1, *e2;
   CHECK(fmi_event_create(&e0));
   CHECK(fmi_event_create(&e1));
