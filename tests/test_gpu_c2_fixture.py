@@ -9,7 +9,8 @@ fmi_philox_u32 — the fixture's CRC-32s of three weight tensors and of the inpu
 
 * bf16 (the headline path: `fmi_flux_denoise`, one call of 50 steps; f32 latents): latents rel-L2 <= 3e-2 at every mark, u8 within 2 of the
   oracle's image on >= 99.9 % of the values.
-* int8 mode against the same F32 fixture: latents <= 3e-2 at every mark; the u8 bar is stated next to SURVEY's 99.9 % in the test.
+* int8 mode (calibrated, as the product runs it) against the same F32 fixture: latents <= 3e-2 at every mark; u8 within 2 on >= 99.5 % (measured 99.75 %; SURVEY's 99.9 % is
+  the bf16 bar — the bf16 path is at 100 % — and is stated next to it in the test).
 * a torch-free C99 host (tools/host_s1.c: gcc, the header, the .so — no Python, no torch, host pointers into fmi_flux_set_tensor) drives the same S1 calls and
   must print the CRC-32 of the SAME image the Python / ctypes path produces from the same seed-by-name checkpoint (`Pipeline::forward`, pipelines/mod.rs:241-270).
 
@@ -35,7 +36,7 @@ T_TXT = 512
 # bf16 latents <= 3e-2, u8 within 2 on >= 99.9 %.  The int8 mode is held to the same latent bar; its u8 agreement is NOT at SURVEY's 99.9 %
 # (a bf16 bar): the value asserted is the one measured at this size with margin, and the print shows both.
 BF16_LATENT_BAR, BF16_U8_BAR = 3e-2, 0.999
-INT8_LATENT_BAR, INT8_U8_BAR = 3e-2, 0.97
+INT8_LATENT_BAR, INT8_U8_BAR = 3e-2, 0.995  # (measured: 99.75 % within 2, 99.9999 % within 4, max 5)
 
 
 def _load_exact(d, model, family):
@@ -171,13 +172,18 @@ def test_headline_50_step_trajectory_int8_mode_against_the_f32_fixture(c2):
     g8 = d.FluxModel(dict(d.FLUX_DEV))
     try:
         _load_exact(d, g8, "flux")
+        # the product's int8 path (Pipeline(dtype=I8), bench.py): calibrated — four evaluations of this sample across the schedule — then quantised
+        torch = c2["torch"]
+        g8.calibrate_int8(True)
+        for i in (0, 16, 33, 49):
+            g8.forward(c2["img"], c2["ids"], c2["t5"], c2["txt_ids"], torch.tensor([float(c2["ts"][i])], device="cuda"), c2["clip"], c2["g"])
         g8.quantize_int8()
         got = {n: _denoise(c2, g8, n) for n in MARKS}
         drift = {n: rel_l2(host(got[n]), fx[f"lat_{n}"]) for n in MARKS}
         u8 = _image_u8(c2, got[50])
         diff = np.abs(u8.astype(np.int32) - fx["u8"].astype(np.int32))
         frac = float((diff <= 2).mean())
-        print("HEADLINE in int8 mode (default mask, e4m3 q / k) vs the committed F32-oracle fixture: latents rel-L2 after "
+        print("HEADLINE in int8 mode (calibrated, default mask, e4m3 q / k) vs the committed F32-oracle fixture: latents rel-L2 after "
               + ", ".join(f"{n} steps {drift[n]:.3e}" for n in MARKS)
               + f"; u8 image max |d| {int(diff.max())}, within 2 on {frac:.4%}, within 4 on {float((diff <= 4).mean()):.4%} "
               f"(asserted: >= {INT8_U8_BAR:.0%}; SURVEY 8(d)'s 99.9 % is the bf16 bar, which the bf16 path meets and an 8-bit mode does not)")
