@@ -34,7 +34,11 @@ from oracle import oracle as orc  # noqa: E402
 
 S_ = d.synth
 MARKS = (10, 25, 50)
+# --config: c2 = BASELINE configs[1] (1024 x 1024: latent 128 x 128, S = 4096), c5 = the shape of configs[4] (1280 x 720: latent 90 x 160, S = 3600: every ragged path)
+CONFIGS = {"c2": (128, 128, "FLUX.1-dev 1024x1024 50-step, S=4096 + T=512, guidance 3.5 (BASELINE configs[1])"),
+           "c5": (90, 160, "FLUX.1-dev 1280x720 50-step, S=3600 + T=512, guidance 3.5 (the shape of BASELINE configs[4], one sample, f32 semantics)")}
 H_LAT = W_LAT = 128
+TAG = "c2"
 T_TXT = 512
 GUIDANCE = 3.5
 N_STEPS = 50
@@ -48,9 +52,9 @@ def raw(n, seed):
 def inputs():
     """(latent (1,16,128,128), t5 (1,512,4096), clip (1,768)): f32 arrays of bf16-representable values; the GPU test builds the same"""
     cfg = d.FLUX_DEV
-    lat = S_.exact_tensor_np("input.c2.latent", (1, 16, H_LAT, W_LAT), raw, "input")
-    t5 = S_.exact_tensor_np("input.c2.t5", (1, T_TXT, cfg["joint_attention_dim"]), raw, "input")
-    clip = S_.exact_tensor_np("input.c2.clip", (1, cfg["pooled_projection_dim"]), raw, "input")
+    lat = S_.exact_tensor_np(f"input.{TAG}.latent", (1, 16, H_LAT, W_LAT), raw, "input")
+    t5 = S_.exact_tensor_np(f"input.{TAG}.t5", (1, T_TXT, cfg["joint_attention_dim"]), raw, "input")
+    clip = S_.exact_tensor_np(f"input.{TAG}.clip", (1, cfg["pooled_projection_dim"]), raw, "input")
     return lat, t5, clip
 
 
@@ -61,10 +65,16 @@ def bits_crc(a_f32):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=max(1, orc.usable_cpus() - 1))
-    ap.add_argument("--scratch", default="/tmp/c2_traj")
-    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "c2_trajectory.npz"))
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--scratch", default=None)
+    ap.add_argument("--out", default=None)
     ap.add_argument("--steps", type=int, default=N_STEPS, help="(debug) stop after this many steps; the fixture is only written at 50")
     a = ap.parse_args()
+    global H_LAT, W_LAT, TAG
+    TAG = a.config
+    H_LAT, W_LAT, desc = CONFIGS[TAG]
+    a.scratch = a.scratch or f"/tmp/{TAG}_traj"
+    a.out = a.out or os.path.join(ROOT, "tests", "golden", f"{TAG}_trajectory.npz")
     os.makedirs(a.scratch, exist_ok=True)
     orc.set_threads(a.threads)
     cfg = dict(d.FLUX_DEV)
@@ -84,9 +94,9 @@ def main():
         n_w += n
     print(f"[gen] {n_w / 1e9:.2f}e9 exact synthetic weights in the oracle (bf16 bits, widened per block) in {time.time() - t0:.0f} s", flush=True)
     lat, t5, clip = inputs()
-    crcs["input.c2.latent"], crcs["input.c2.t5"], crcs["input.c2.clip"] = bits_crc(lat), bits_crc(t5), bits_crc(clip)
+    crcs[f"input.{TAG}.latent"], crcs[f"input.{TAG}.t5"], crcs[f"input.{TAG}.clip"] = bits_crc(lat), bits_crc(t5), bits_crc(clip)
     img, ids = orc.pack_latents(lat)
-    assert img.shape == (1, 4096, 64)
+    assert img.shape == (1, (H_LAT // 2) * (W_LAT // 2), 64)
     txt_ids = np.zeros((1, T_TXT, 3), np.float32)
     g = np.array([GUIDANCE], np.float32)
     ts = np.array(orc.get_timesteps(N_STEPS, True, orc.calculate_shift(img.shape[1]), 1.0), np.float64)
@@ -121,7 +131,7 @@ def main():
     t1 = time.time()
     u8 = orc.postprocess_u8(ov.decode(z.astype(np.float32)))
     print(f"[gen] VAE decode + u8 in {time.time() - t1:.0f} s; image CRC-32 {zlib.crc32(u8.tobytes()):08x}, saturated {float(((u8 == 0) | (u8 == 255)).mean()):.3f}", flush=True)
-    meta = dict(config="FLUX.1-dev 1024x1024 50-step, S=4096 + T=512, guidance 3.5 (BASELINE configs[1])", marks=list(MARKS), crcs=crcs,
+    meta = dict(config=desc, tag=TAG, latent_hw=[H_LAT, W_LAT], marks=list(MARKS), crcs=crcs,
                 image_crc32=zlib.crc32(u8.tobytes()), oracle_threads=a.threads, total_oracle_s=float(np.sum(step_s)), exact_salt=S_.EXACT_SALT,
                 generator="tests/golden/gen_c2_trajectory_fixture.py")
     np.savez_compressed(a.out, ts=ts, u8=u8, step_s=np.array(step_s, np.float32), meta=np.frombuffer(json.dumps(meta).encode(), np.uint8),
