@@ -1065,7 +1065,7 @@ int forward_core(fmi_flux* m, const fmi_flux_inputs* in, const float* img_f32, c
       Dense* dn1[2] = {&bw.mlp1[0], &bw.mlp1[1]};
       FMI_TRY(gemm2(m, p, dn1, 2, s));
       if (q_m2) {  // hid is (B*L, M) with the txt rows first, like a8
-        if (bw.mlp2[0].sm_inv) {  // (smoothed: each stream's MLP-out has its own per-channel factors)
+        if (bw.mlp2[0].sm_inv || bw.mlp2[1].sm_inv) {  // (smoothed: each stream's MLP-out has its own per-channel factors)
           FMI_TRY(quantize_act(m, bw.mlp2[1], hid_txt, Mh, B * T, 0, s));
           FMI_TRY(quantize_act(m, bw.mlp2[0], hid_img, Mh, B * S, BT, s));
         } else {
@@ -1723,11 +1723,15 @@ static int quantize_8bit(fmi_flux* m, int kind, unsigned mask, void* stream) {
       FMI_HIP_TRY(hipMemcpyAsync(hw.data(), m->calib_wmax, (size_t)d->K * sizeof(float), hipMemcpyDeviceToHost, s));
       FMI_HIP_TRY(hipStreamSynchronize(s));
       smooth_factors_host(ha.data(), hw.data(), d->K, hs.data(), hi.data());
-      FMI_HIP_TRY(hipMemcpyAsync(d->sm_s, hs.data(), (size_t)d->K * sizeof(float), hipMemcpyHostToDevice, s));
-      FMI_HIP_TRY(hipMemcpyAsync(d->sm_inv_store, hi.data(), (size_t)d->K * sizeof(float), hipMemcpyHostToDevice, s));
-      FMI_HIP_TRY(hipStreamSynchronize(s));  // (the host vectors go out of scope)
-      d->sm_inv = d->sm_inv_store;
-      wvec = d->sm_s;
+      // a linear without a single outlier channel (every factor exactly 1) keeps the plain kernels: multiplying by 1 changes no bit, skipping it saves the
+      // per-channel loads in the row kernels (measured on the Gaussian bench checkpoint: 51.1 -> 50.5 ms per step when no linear smooths)
+      if (std::any_of(hs.begin(), hs.end(), [](float v) { return v != 1.0f; })) {
+        FMI_HIP_TRY(hipMemcpyAsync(d->sm_s, hs.data(), (size_t)d->K * sizeof(float), hipMemcpyHostToDevice, s));
+        FMI_HIP_TRY(hipMemcpyAsync(d->sm_inv_store, hi.data(), (size_t)d->K * sizeof(float), hipMemcpyHostToDevice, s));
+        FMI_HIP_TRY(hipStreamSynchronize(s));  // (the host vectors go out of scope)
+        d->sm_inv = d->sm_inv_store;
+        wvec = d->sm_s;
+      }
     }
     FMI_TRY(launch_quantize_rows_fp8(d->w, d->K, d->N, d->K, d->w8, d->w8_scale, s, kind, wvec));
     if (d->w8_d0 >= 0) {
