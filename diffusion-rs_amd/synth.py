@@ -309,6 +309,14 @@ def outlier_channels(D):
     return [int(c) for c in out], [float(a) for a in amp], [int(c) for c in res]
 
 
+def outlier_profile_touches(name):
+    """does apply_outlier_profile edit this tensor at all?  (the full-size fixture generator skips the f32 round trip for the 11.5e9 weights it leaves alone)"""
+    return (name.endswith(("norm1.linear.bias", "norm1_context.linear.bias")) or (".norm.linear.bias" in name and name.startswith("single_transformer_blocks."))
+            or any(name.endswith(k + ".weight") for k in ("attn.to_q", "attn.to_k", "attn.to_v", "attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj", "ff.net.0.proj",
+                                                          "ff_context.net.0.proj", "proj_mlp"))
+            or name in ("x_embedder.bias", "context_embedder.bias") or name.endswith(("norm_q.weight", "norm_k.weight", "norm_added_q.weight", "norm_added_k.weight")))
+
+
 def apply_outlier_profile(name, t, D, parts=("mod", "cols", "res", "qk"), qk_gain=3.0):
     """In-place on a numpy array or torch tensor holding tensor `name` of a FLUX checkpoint (already at its final dtype); returns t.
     `parts` / `qk_gain`: the pieces of the profile one at a time (tools/outlier_study.py)."""

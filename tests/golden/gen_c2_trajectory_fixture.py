@@ -95,7 +95,7 @@ def main():
         n = int(np.prod(shape))
         off, sc = S_.exact_rule(name, shape, "flux")
         b = orc.exact_bf16(n, S_.exact_seed(name), off, S_.exact_coeff(sc), buf)
-        if TAG == "o2":
+        if TAG == "o2" and S_.outlier_profile_touches(name):
             # the profile edits a few rows / columns / entries: in f32 on the bf16 values, re-rounded to bf16 — the arithmetic of the same in-place edit on a torch bf16 tensor
             f = (b.astype(np.uint32) << 16).view(np.float32).reshape(shape)
             g2 = S_.apply_outlier_profile(name, f.copy(), D_MODEL)
